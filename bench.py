@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+"""bench.py — decode tokens/s of LLaMA-7B fp32 on MI355X, as a fraction of the per-token HBM-read roofline.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run with one
+rank per GPU.  W untimed warm-up steps, then exactly K steps timed between barrier + torch.cuda.synchronize() pairs, MAX over
+ranks, rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): LLaMA-7B shape (d 4096, 32 heads, 32 layers, ff 11008, vocab 32000), fp32,
+random-init weights from the counter-based generator (seed 1234, generated directly in HBM), --context 128, prompt = 8 fixed
+token ids evaluated as one prefill, then greedy decode at positions P = 8, 9, ...  A "step" is one pass of the hot path
+(llama.Eval with N = 1: 32 x [rmsnorm, wq|wk|wv, rope, attention, wo, rmsnorm, w1|w3, silu*mul, w2] + lm_head) per stream.
+
+N = 1: one stream; steps run device-resident (argmax on the GPU feeds the next step, hipGraph replay).
+N > 1: layers are sharded in contiguous blocks over the ranks; N independent streams ("pods", server.go:88-101)
+       keep the pipeline full: in one step every stream advances one token, so per-GPU work per step is constant
+       (scaling: weak) and value = N*K tokens / time.  The residual stream [4096 f32] hops rank r -> r+1 with RCCL send/recv;
+       the sampled token id returns from the last rank to rank 0 the same way.
+
+Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed live), "cpu_baseline" (oracle on the host cores,
+N = 1 only), "parity" (token ids / logits vs that oracle run).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy ceiling)
+SEED = 1234
+
+
+def bytes_per_token(hp_d, L, F, V, T):
+    """weights touched once + KV read of T cached positions + KV write of one."""
+    weights = 4 * (L * (4 * hp_d * hp_d + 3 * hp_d * F + 2 * hp_d) + V * hp_d + 2 * hp_d)
+    kv = 2 * L * T * hp_d * 4 + 2 * L * hp_d * 4
+    return weights, kv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="7B")
+    ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the bounded CPU-baseline sample")
+    ap.add_argument("--pods", type=int, default=0, help="streams in flight for N > 1 (default N)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # first: the process then uses ONE HIP runtime (torch's), libllamahip binds to it by SONAME
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    os.environ["LLAMAGO_DEVICE"] = str(local_rank)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as graft
+    if rank == 0:
+        graft.build()
+    if world > 1:
+        dist.barrier()
+    from llama_go_amd.mlapi import (MLLib, PROMPT, SHAPES, decode_greedy_resident, load_product, make_hparams, profile_decode)
+    prod = load_product()
+
+    kw = dict(SHAPES[args.shape])
+    if args.layers:
+        kw["layers"] = args.layers
+    K, W = args.steps, args.warmup
+    ctx_size = max(128, len(PROMPT) + max(K, W) + 1)
+    hp = make_hparams(**kw, ctx=ctx_size)
+    d, L, V = hp.embdSize, hp.layersCount, hp.vocabSize
+    P0 = len(PROMPT)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = {}
+    if world == 1:
+        model = prod.NewSyntheticModel(hp, SEED)
+        F = model.ffSize
+        ctx = model.NewContext(ctx_size, 1)
+        logits0 = ctx.Eval(PROMPT, 0)  # prefill through ml.GraphCompute (fused plan)
+        first = int(np.argmax(logits0))
+        # warm-up steps (also captures the hipGraph), then the timed region from the same state
+        if W > 0:
+            decode_greedy_resident(ctx, first, P0, W)
+        sync_all()
+        t0 = time.perf_counter()
+        toks, last_logits = decode_greedy_resident(ctx, first, P0, K, want_logits=True)
+        sync_all()
+        dt = time.perf_counter() - t0
+        tokens_total = K
+        tokens = [first] + toks[:-1]  # ids evaluated by the timed steps; toks = ids they produced
+        produced = toks
+        # ---- dominant kernel, HIP-event timed with eager launches of the same kernels (all weights distinct: HBM-cold)
+        prof = profile_decode(ctx, first, P0, repeats=2)
+        result["kernels"] = {k["name"]: {"avg_us": round(k["avg_us"], 2), "launches": k["launches"], "GBps": round(k["gbps"], 1)} for k in prof}
+        dom = max(prof, key=lambda k: k["avg_us"] * k["launches"])
+        result["roofline"] = {
+            "bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+            "bytes_per_launch": dom["bytes_per_launch"], "avg_us": round(dom["avg_us"], 2),
+            "note": "algorithmic bytes = rows*cols*4 of the weights one launch streams (SURVEY 8d); traffic (PMC) in profiles/",
+        }
+        # ---- CPU baseline + parity on the same inputs (oracle = test infrastructure; only used here as the checker / baseline)
+        if not args.no_cpu_baseline:
+            orc = MLLib(os.path.join(ROOT, "oracle", "liboracle.so"))
+            ncpu = os.cpu_count() or 1
+            t_gen = time.perf_counter()
+            om = orc.NewSyntheticModel(hp, SEED)
+            t_gen = time.perf_counter() - t_gen
+            nsteps = max(1, min(args.cpu_steps, K))
+            # (B) "--avx-equivalent": the reference's own vdot (oracle/_ref), rows over all host cores
+            oc = om.NewContext(ctx_size, ncpu, True)
+            lg = oc.Eval(PROMPT, 0)
+            tok = int(np.argmax(lg))
+            t1 = time.perf_counter()
+            for s in range(nsteps):
+                lg = oc.Eval([tok], P0 + s)
+                tok = int(np.argmax(lg))
+            avx_dt = (time.perf_counter() - t1) / nsteps
+            oc.free()
+            # (A) "pure-Go-equivalent" scalar order = the PARITY reference: all cores only redistribute rows (same values)
+            oc = om.NewContext(ctx_size, ncpu, False)
+            otoks, ologits = oc.GreedyDecode(PROMPT, nsteps + 1)
+            oc.free()
+            # one scalar step on ONE thread for the 1-thread figure of BASELINE.md row A
+            oc1 = om.NewContext(ctx_size, 1, False)
+            t2 = time.perf_counter()
+            oc1.Eval([7], 0)
+            scalar1_dt = time.perf_counter() - t2
+            oc1.free()
+            om.free()
+            result["cpu_baseline"] = {
+                "value": round(1.0 / avx_dt, 3), "unit": "tokens/s", "cores": ncpu, "kind": "port",
+                "sample": f"oracle Eval schedule with the reference's own utils/floats_avx.c vdot (oracle/_ref) = '--avx' path; full {args.shape} model, "
+                          f"{nsteps} decode steps at P={P0}.. after an {P0}-token prefill; rows split over {ncpu} host threads",
+                "ms_per_token": round(avx_dt * 1e3, 1),
+                "pure_go_scalar_1thread_ms_per_token": round(scalar1_dt * 1e3, 1),
+                "weights_gen_s": round(t_gen, 1),
+            }
+            # parity: GPU ids/logits vs the scalar-order oracle on the overlapping steps
+            gl = [logits0]
+            c2 = model.NewContext(ctx_size, 1)
+            c2.Eval(PROMPT, 0)
+            gt, glog = [first], []
+            for s in range(nsteps):
+                l2 = c2.Eval([gt[-1]], P0 + s)
+                glog.append(l2)
+                gt.append(int(np.argmax(l2)))
+            c2.free()
+            rel0 = float(np.abs(logits0 - ologits[0]).max() / np.abs(ologits[0]).max())
+            rels = [float(np.abs(glog[s] - ologits[s + 1]).max() / np.abs(ologits[s + 1]).max()) for s in range(nsteps)]
+            srt = np.sort(ologits, axis=-1)
+            result["parity"] = {
+                "token_ids_match": gt[: nsteps + 1] == list(otoks[: nsteps + 1]) and gt[1: nsteps + 1] == produced[:nsteps],
+                "max_rel_logit_err": max([rel0] + rels), "tolerance": 1e-4, "steps_compared": nsteps + 1,
+                "min_top2_margin_rel": float(((srt[:, -1] - srt[:, -2]) / np.abs(ologits).max(axis=-1)).min()),
+            }
+        ctx.free()
+        model.free()
+        parallelism = "single GPU, device-resident decode loop (hipGraph replay)"
+        pods = 1
+    else:
+        # ---------------- layer-sharded pipeline over `world` ranks ----------------
+        R = world
+        pods = args.pods or R
+        l0, l1 = rank * L // R, (rank + 1) * L // R
+        stream = torch.cuda.current_stream().cuda_stream
+        prod.lib.llamago_SetStream(C.c_void_p(stream))
+        model = prod.NewSyntheticModel(hp, SEED, l0, l1)
+        F = model.ffSize
+        ctxs = [model.NewContext(ctx_size, 1) for _ in range(pods)]
+        dev = torch.device("cuda", local_rank)
+        first_stage, last_stage = rank == 0, rank == R - 1
+        xin = [torch.empty(P0 * d, dtype=torch.float32, device=dev) for _ in range(pods)]
+        xout = [torch.empty(P0 * d, dtype=torch.float32, device=dev) for _ in range(pods)]
+        tok_in = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(pods)]     # rank 0: id received from the last rank
+        tok_first = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(pods)]  # rank 0: id produced by the prefill
+        tok_out = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(pods)]    # last rank: argmax of this step
+        produced_dev = torch.zeros((pods, K), dtype=torch.int32, device=dev)
+        prompt_arr = (C.c_uint32 * P0)(*PROMPT)
+
+        def rows_past(step, phase):
+            if phase == "warm":
+                return (P0, 0) if step == 0 else (1, P0 + step - 1)
+            return 1, P0 + step
+
+        def stage_cb(p, step, phase):
+            n, past = rows_past(step, phase)
+            tokens_host, tokens_dev = None, None
+            if first_stage:
+                if n > 1:
+                    tokens_host = prompt_arr
+                else:
+                    src = tok_first[p] if (phase == "timed" and step == 0) else tok_in[p]
+                    tokens_dev = C.c_void_p(src.data_ptr())
+            rc = prod.lib.llamago_Stage(ctxs[p].h, tokens_host, tokens_dev,
+                                        None if first_stage else C.c_void_p(xin[p].data_ptr()),
+                                        None if last_stage else C.c_void_p(xout[p].data_ptr()),
+                                        n, past, None, C.c_void_p(tok_out[p].data_ptr()) if last_stage else None)
+            if rc:
+                raise RuntimeError(prod.last_error())
+            if last_stage and phase == "timed":
+                produced_dev[p, step] = tok_out[p][0]
+
+        def send_buf(p, step, phase):
+            n, _ = rows_past(step, phase)
+            return tok_out[p] if last_stage else xout[p][: n * d]
+
+        def recv_buf(p, step, phase):
+            n, _ = rows_past(step, phase)
+            return tok_in[p] if first_stage else xin[p][: n * d]
+
+        def on_recv(p, step, phase):
+            if first_stage and phase == "warm" and step == 0:
+                tok_first[p].copy_(tok_in[p])
+
+        from llama_go_amd.pipeline import PipelineRunner
+        runner = PipelineRunner(rank, R, pods, dist, stage_cb, send_buf, recv_buf, on_recv)
+        runner.run_phase(1 + W, "warm")   # prefill + W warm-up decode steps per stream; the pipeline drains at the end
+        sync_all()
+        t0 = time.perf_counter()
+        runner.run_phase(K, "timed")      # K decode steps per stream from (first token, P0): includes pipeline fill + drain
+        sync_all()
+        dt = time.perf_counter() - t0
+        tokens_total = K * pods
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+        prof = profile_decode(ctxs[0], 1, P0, repeats=2)
+        dom = max(prof, key=lambda k: k["avg_us"] * k["launches"])
+        result["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": dom["bytes_per_launch"],
+                              "avg_us": round(dom["avg_us"], 2)}
+        if last_stage:
+            produced = produced_dev[0, :K].tolist()
+            obj = [produced]
+        else:
+            obj = [None]
+        dist.broadcast_object_list(obj, src=R - 1)
+        produced = obj[0]
+        parallelism = f"layer-shard pp{R} ({L // R} layers/rank), {pods} independent greedy streams in flight, RCCL send/recv of the residual stream"
+        for c in ctxs:
+            c.free()
+        model.free()
+
+    Tbar = P0 + (K + 1) / 2.0
+    wbytes, kvbytes = bytes_per_token(d, L, F, V, Tbar)
+    tok_s = tokens_total / dt
+    line = {
+        "metric": "decode tokens/s LLaMA-7B fp32; % HBM-read roofline",
+        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random-init weights, counter-based generator seed 1234; fixed 8-token prompt)",
+        "config": {"workload": f"LLaMA-{args.shape} fp32 greedy decode, context {ctx_size}, positions {P0}..{P0 + K - 1}, batch 1 per stream",
+                   "layers": L, "embd": d, "ff": F, "vocab": V, "streams": pods, "parallelism": parallelism},
+        "roofline_token": {
+            "bytes_per_token": int(wbytes + kvbytes), "weights_bytes": int(wbytes),
+            "roofline_tok_s_per_gpu_stream": round(HBM_PEAK_GBPS * 1e9 / (wbytes + kvbytes), 2),
+            "frac_of_hbm_roofline": round(tok_s * (wbytes + kvbytes) / (HBM_PEAK_GBPS * 1e9 * world), 4),
+        },
+        "tokens_stream0": produced[: min(K, 16)],
+    }
+    line.update(result)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+/* include/llamahip.h — the drop-in C-ABI boundary of the MI355X backend (libllamahip.so).
+ *
+ * The reference (gotzmann/llama.go) has no plugin/FFI interface; the call that keeps its
+ * ml.Tensor / ml.Graph operator surface intact and crosses Go -> C once per Eval is
+ * ml.GraphCompute (pkg/ml/ml.go:1411-1528, called from pkg/llama/llama.go:389).  Every entry point
+ * below is what a cgo shim inside package ml binds (INTEGRATION.md shows that shim); each cites the
+ * reference interface it replaces.  Plain C: opaque handles, pointers and sizes, no torch/HIP types
+ * (a HIP stream is passed as void*).
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative LH_E* code and never aborts the process
+ *    (the reference os.Exit(1)s on "[HALT]" conditions, e.g. ml.go:1538, 2116-2124; the shim maps a
+ *    non-zero code back to that behaviour).  lh_last_error() returns the message.
+ *  - thread-agnostic: a Go goroutine may migrate between OS threads between calls, so every entry
+ *    point re-selects its device and uses the context's explicit stream.  One lh_ctx must not be
+ *    used from two threads at once (the reference has one ml.Context per pod, server.go:151);
+ *    registered weight buffers are shared read-only by all contexts of a device (server.go:45).
+ *  - blocking: lh_graph_compute returns after the results are visible to lh_node_read, matching the
+ *    wg.Wait() join of the reference (ml.go:1652).
+ *  - no host pointer is retained past the call that received it (cgo pointer rule): weights are
+ *    copied to HBM at registration.
+ */
+#ifndef LLAMAHIP_H
+#define LLAMAHIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_ABI_VERSION 1
+
+enum { LH_OK = 0, LH_EINVAL = -1, LH_ENOMEM = -2, LH_EHIP = -3, LH_EUNSUPPORTED = -4, LH_ENODEVICE = -5, LH_ESHAPE = -6 };
+
+typedef struct lh_ctx lh_ctx;   /* device side of one ml.Context (ml.go:50-57): stream, scratch arena, cached plans */
+typedef uint64_t lh_buf;        /* handle of a persistent device buffer (weights, KV cache); 0 = none */
+
+/* ---- contexts:  ml.NewContext ml.go:59-74 / (*Context).ReleaseContext ml.go:77-80 ------------- */
+int lh_abi_version(void);
+int lh_device_count(void);                      /* 0 when no GPU is visible (never an error) */
+/* stream: an existing hipStream_t to enqueue on (e.g. the framework's current stream), or NULL for a
+ * private non-blocking stream. */
+int lh_ctx_create(int device, void* stream, lh_ctx** out);
+void lh_ctx_destroy(lh_ctx* ctx);
+const char* lh_last_error(lh_ctx* ctx);         /* ctx may be NULL: last error of the calling thread */
+int lh_ctx_sync(lh_ctx* ctx);                   /* wait for everything enqueued on the context's stream */
+void* lh_ctx_stream(lh_ctx* ctx);
+
+/* ---- persistent tensors: weights resident after LoadModel (llama.go:975), KV cache of NewContext
+ *      (llama.go:91-98).  `key` is a caller-chosen stable id (the Go shim uses the address of the
+ *      tensor's backing array); registering an existing key returns the existing buffer.  key 0 =
+ *      anonymous.  dtype is ml.DType (ml.go:85-94): 0 = f32; 7 = block-int8 (ours).  host may be NULL
+ *      (buffer zero-filled, as Go's make([]float32) is). ---------------------------------------- */
+int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4], int persistent,
+                       const void* host_or_null, lh_buf* out);
+int lh_buf_upload(lh_ctx* ctx, lh_buf buf, uint64_t off_floats, const float* host, uint64_t n);
+int lh_buf_read(lh_ctx* ctx, lh_buf buf, uint64_t off_floats, float* dst, uint64_t n);
+/* Fill with the synthetic-model generator: w[i] = offset + scale * u(seed, tensor_id, i), in HBM. */
+int lh_buf_fill_synth(lh_ctx* ctx, lh_buf buf, uint64_t off_floats, uint64_t n, uint64_t seed, uint32_t tensor_id,
+                      float scale, float offset);
+int lh_buf_free(lh_ctx* ctx, lh_buf buf);
+void* lh_buf_devptr(lh_ctx* ctx, lh_buf buf);   /* raw device address (interop with a framework's collectives) */
+uint64_t lh_buf_nfloats(lh_ctx* ctx, lh_buf buf);
+
+/* ---- the graph:  ml.GraphCompute ml.go:1411-1528 ---------------------------------------------------
+ * One flat array describes Graph.Leafs (first n_leafs entries) then Graph.Nodes in execution order
+ * (ml.go:42-44).  lh_tensor mirrors ml.Tensor (ml.go:180-203); op and dtype use the reference's
+ * numeric values (ml.go:133-174, 85-94).  Go slices alias invisibly to C, so view identity is carried
+ * explicitly: `storage` is the index of the tensor that owns the bytes (itself if it owns them) and
+ * `view_off` the offset in floats from that owner's first element. */
+typedef struct lh_tensor {
+    uint8_t op;          /* ml.optype */
+    uint8_t dtype;       /* ml.DType */
+    uint16_t flags;      /* LH_T_* */
+    uint32_t ne[4];      /* Tensor.NE */
+    uint64_t nb[4];      /* Tensor.NB, bytes, widened to 64-bit (the reference's uint32 strides cap at 4 GiB) */
+    int32_t src0, src1;  /* indices into this array, -1 = nil */
+    int32_t storage;     /* owner index (== own index when this tensor owns its bytes) */
+    uint32_t reserved;
+    uint64_t view_off;   /* floats from the owner's base */
+    lh_buf buf;          /* owner only: registered persistent buffer, or 0 for per-graph scratch */
+    const float* host;   /* owner leaf with buf == 0: host data uploaded for this call (token ids, op params); else NULL */
+} lh_tensor;
+
+enum { LH_T_OUTPUT = 1 /* host wants to read this node back (kept materialised by fused plans) */ };
+enum { LH_GRAPH_NO_FUSION = 1 /* run every node 1:1 with the generic kernels (debug / op-level parity tests) */ };
+
+int lh_graph_compute(lh_ctx* ctx, const lh_tensor* tensors, uint32_t n_leafs, uint32_t n_nodes, uint32_t flags);
+/* Read elements of a tensor of the LAST computed graph (flat, in storage order from the tensor's first
+ * element).  Replaces the host's direct reads of Tensor.Data after GraphCompute (llama.go:394-401). */
+int lh_node_read(lh_ctx* ctx, uint32_t index, uint64_t off_floats, float* dst, uint64_t n);
+/* 1 if the last lh_graph_compute ran as a fused LLaMA plan, 0 if node-by-node. */
+int lh_last_graph_fused(lh_ctx* ctx);
+
+/* ---- convenience layer over the same fused plan executor (harnesses, bench, pipeline stages) ------
+ * Describes the weights of llama.Model (llama.go:181-193) + one KV cache (llama.go:173-178) for the
+ * layer range [layer0, layer1) held by this process. */
+typedef struct lh_llama_layer { lh_buf attention_norm, wq, wk, wv, wo, ffn_norm, w1, w2, w3; } lh_llama_layer;
+typedef struct lh_llama_desc {
+    uint32_t vocab, embd, heads, layers, ff, ctx; /* whole-model hyper-parameters (llama.go:149-158, 761) */
+    uint32_t layer0, layer1;                      /* this stage's layers; [0, layers) = whole model */
+    lh_buf tok_embeddings, norm, output;          /* needed on the first / last stage only (0 elsewhere) */
+    const lh_llama_layer* layer;                  /* `layers` entries, only [layer0, layer1) are read */
+    lh_buf k_cache, v_cache;                      /* embd * (layer1-layer0) * ctx floats each; layer il at slot (il-layer0) */
+    int weight_dtype;                             /* 0 = f32, 7 = block-int8 matrices */
+} lh_llama_desc;
+typedef struct lh_llama lh_llama;
+
+int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out);
+void lh_llama_destroy(lh_llama* m);
+/* llama.Eval (llama.go:211-426) on a whole model: logits of the last token to host (vocab floats). */
+int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past, float* logits_host);
+/* Device-resident greedy decode: step i evaluates one token at position past+i; the argmax (lowest
+ * index on ties) is taken on the GPU and feeds step i+1 without a host round trip.  out_tokens[i]
+ * = id produced by step i.  logits_last_host (optional) receives the final step's logits. */
+int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uint32_t n_steps,
+                           uint32_t* out_tokens, float* logits_last_host);
+/* One pipeline stage of Eval for a layer-sharded model (residual stream in/out in device memory,
+ * n rows of embd floats).  First stage: x_in = NULL and token ids given either on the host (tokens) or,
+ * for n = 1, in device memory (tokens_dev: the id the last stage produced, received over xGMI, without
+ * a host round trip).  Last stage: writes logits of the last token to logits_dev (vocab floats) and its
+ * argmax to *argmax_dev (both device pointers, optional).  Asynchronous on the context's stream. */
+int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_dev, const float* x_in_dev, float* x_out_dev,
+                   uint32_t n, uint32_t past, float* logits_dev, uint32_t* argmax_dev);
+/* Time each kernel class of one decode step with HIP events on the context's stream (eager launches,
+ * same kernels as the replayed graph).  Writes up to cap entries; returns the number of classes. */
+typedef struct lh_kernel_time { char name[48]; uint32_t launches; float total_ms; uint64_t bytes_per_launch; } lh_kernel_time;
+int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

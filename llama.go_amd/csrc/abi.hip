@@ -1,0 +1,267 @@
+// csrc/abi.hip — contexts, persistent buffers, synthetic-weight generator, RoPE table.
+// C-ABI entry points declared in include/llamahip.h.
+#include "common.h"
+#include <stdarg.h>
+#include <math.h>
+
+namespace lh {
+
+static thread_local std::string g_thread_err;
+
+void set_error(lh_ctx* ctx, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_thread_err = buf;
+    if (ctx) ctx->err = buf;
+}
+
+static std::mutex g_dev_mu;
+static std::unordered_map<int, DeviceState*> g_devs;
+
+DeviceState* device_state(int device) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_devs.find(device);
+    if (it != g_devs.end()) return it->second;
+    DeviceState* ds = new DeviceState();
+    ds->device = device;
+    if (hipGetDeviceProperties(&ds->prop, device) != hipSuccess) { delete ds; return nullptr; }
+    ds->num_cu = ds->prop.multiProcessorCount;
+    g_devs[device] = ds;
+    return ds;
+}
+
+Buffer* find_buffer(DeviceState* ds, lh_buf id) {
+    std::lock_guard<std::mutex> lk(ds->mu);
+    auto it = ds->bufs.find(id);
+    return it == ds->bufs.end() ? nullptr : it->second.get();
+}
+
+int ensure_arena(lh_ctx* ctx, uint64_t bytes) {
+    if (bytes <= ctx->arena_bytes) return 0;
+    uint64_t want = bytes + (bytes >> 2) + (1u << 20);
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) LH_HIP(ctx, hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_bytes = 0;
+    LH_HIP(ctx, hipMalloc((void**)&ctx->arena, want));
+    ctx->arena_bytes = want;
+    return 0;
+}
+
+int ensure_staging(lh_ctx* ctx, uint64_t bytes) {
+    if (bytes <= ctx->staging_bytes) return 0;
+    uint64_t want = bytes * 2 + 4096;
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->staging) LH_HIP(ctx, hipHostFree(ctx->staging));
+    ctx->staging = nullptr;
+    ctx->staging_bytes = 0;
+    LH_HIP(ctx, hipHostMalloc((void**)&ctx->staging, want, hipHostMallocDefault));
+    ctx->staging_bytes = want;
+    return 0;
+}
+
+// RoPE table, computed on the host in f64 with the reference's expressions (ml.go:2307-2310):
+//   theta = pow(10000, -i0/dims);  cos(p*theta), sin(p*theta)     for i0 = 0, 2, .., dims-2.
+int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims) {
+    DeviceState* ds = ctx->ds;
+    std::lock_guard<std::mutex> lk(ds->mu);
+    if (ds->rope_table && ds->rope_dims == dims && ds->rope_positions >= positions) return 0;
+    uint32_t npos = positions < 256 ? 256 : positions;
+    if (ds->rope_dims == dims && ds->rope_positions * 2 > npos) npos = ds->rope_positions * 2;
+    const uint32_t half = dims / 2;
+    std::vector<double2> h((size_t)npos * half);
+    for (uint32_t i = 0; i < half; ++i) {
+        const int i0 = (int)(2 * i);
+        const double theta = pow(10000.0, (double)(-i0) / (double)dims);
+        for (uint32_t p = 0; p < npos; ++p) {
+            h[(size_t)p * half + i].x = cos((double)p * theta);
+            h[(size_t)p * half + i].y = sin((double)p * theta);
+        }
+    }
+    double2* dev = nullptr;
+    LH_HIP(ctx, hipMalloc((void**)&dev, h.size() * sizeof(double2)));
+    LH_HIP(ctx, hipMemcpy(dev, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice));
+    // The old table may still be referenced by captured graphs of other contexts: keep it alive (tables are small).
+    ds->rope_table = dev;
+    ds->rope_positions = npos;
+    ds->rope_dims = dims;
+    return 0;
+}
+
+// ---- synthetic weights (DESIGN.md "Synthetic model") -------------------------------------------------
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_fill_synth(float* __restrict__ dst, uint64_t n, uint64_t key, float scale, float offset) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const uint64_t h = mix64(key + i);
+        const int k = (int)(h >> 40);
+        const float v = (float)(2 * k - (1 << 24)) * (1.0f / 16777216.0f);  // exact
+        const float sv = __fmul_rn(scale, v);                                // one rounding, never fused
+        dst[i] = __fadd_rn(offset, sv);
+    }
+}
+
+}  // namespace lh
+
+using namespace lh;
+
+extern "C" {
+
+int lh_abi_version(void) { return LH_ABI_VERSION; }
+
+int lh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* lh_last_error(lh_ctx* ctx) { return ctx ? ctx->err.c_str() : g_thread_err.c_str(); }
+
+int lh_ctx_create(int device, void* stream, lh_ctx** out) {
+    if (!out) LH_FAIL(nullptr, LH_EINVAL, "lh_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = lh_device_count();
+    if (n <= 0) LH_FAIL(nullptr, LH_ENODEVICE, "lh_ctx_create: no HIP device visible (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= n) LH_FAIL(nullptr, LH_EINVAL, "lh_ctx_create: device %d out of range (0..%d)", device, n - 1);
+    LH_HIP(nullptr, hipSetDevice(device));
+    DeviceState* ds = device_state(device);
+    if (!ds) LH_FAIL(nullptr, LH_EHIP, "lh_ctx_create: cannot query device %d", device);
+    lh_ctx* c = new lh_ctx();
+    c->device = device;
+    c->ds = ds;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; LH_FAIL(nullptr, LH_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    *out = c;
+    return LH_OK;
+}
+
+int lh_ctx_sync(lh_ctx* ctx) {
+    if (!ctx) return LH_EINVAL;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LH_OK;
+}
+
+void* lh_ctx_stream(lh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4], int persistent, const void* host, lh_buf* out) {
+    if (!ctx || !ne || !out) LH_FAIL(ctx, LH_EINVAL, "lh_tensor_register: NULL argument");
+    (void)persistent;
+    if (dtype != 0) LH_FAIL(ctx, LH_EUNSUPPORTED, "lh_tensor_register: dtype %d not supported (f32 only; the reference loader rejects others too, llama.go:956-959)", dtype);
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceState* ds = ctx->ds;
+    if (key) {
+        std::lock_guard<std::mutex> lk(ds->mu);
+        auto it = ds->by_key.find(key);
+        if (it != ds->by_key.end()) { *out = it->second; return LH_OK; }
+    }
+    uint64_t n = (uint64_t)ne[0] * ne[1] * ne[2] * ne[3];
+    if (n == 0) LH_FAIL(ctx, LH_EINVAL, "lh_tensor_register: empty tensor");
+    auto b = std::make_unique<Buffer>();
+    b->nfloats = n;
+    b->bytes = n * 4;
+    b->dtype = dtype;
+    b->key = key;
+    b->device = ctx->device;
+    hipError_t e = hipMalloc((void**)&b->dev, b->bytes);
+    if (e != hipSuccess) LH_FAIL(ctx, LH_ENOMEM, "lh_tensor_register: hipMalloc(%llu bytes): %s", (unsigned long long)b->bytes, hipGetErrorString(e));
+    if (host) LH_HIP(ctx, hipMemcpy(b->dev, host, b->bytes, hipMemcpyHostToDevice));
+    else LH_HIP(ctx, hipMemset(b->dev, 0, b->bytes));
+    std::lock_guard<std::mutex> lk(ds->mu);
+    lh_buf id = ds->next_id++;
+    if (key) ds->by_key[key] = id;
+    ds->bufs[id] = std::move(b);
+    *out = id;
+    return LH_OK;
+}
+
+static int get_buf(lh_ctx* ctx, lh_buf buf, uint64_t off, uint64_t n, Buffer** out, const char* who) {
+    if (!ctx) return LH_EINVAL;
+    Buffer* b = find_buffer(ctx->ds, buf);
+    if (!b) LH_FAIL(ctx, LH_EINVAL, "%s: unknown buffer %llu", who, (unsigned long long)buf);
+    if (off > b->nfloats || n > b->nfloats - off) LH_FAIL(ctx, LH_EINVAL, "%s: range [%llu,+%llu) outside buffer of %llu floats", who, (unsigned long long)off, (unsigned long long)n, (unsigned long long)b->nfloats);
+    *out = b;
+    return LH_OK;
+}
+
+int lh_buf_upload(lh_ctx* ctx, lh_buf buf, uint64_t off, const float* host, uint64_t n) {
+    Buffer* b;
+    int rc = get_buf(ctx, buf, off, n, &b, "lh_buf_upload");
+    if (rc) return rc;
+    if (!host) LH_FAIL(ctx, LH_EINVAL, "lh_buf_upload: host is NULL");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, hipMemcpy(b->dev + off, host, n * 4, hipMemcpyHostToDevice));
+    return LH_OK;
+}
+
+int lh_buf_read(lh_ctx* ctx, lh_buf buf, uint64_t off, float* dst, uint64_t n) {
+    Buffer* b;
+    int rc = get_buf(ctx, buf, off, n, &b, "lh_buf_read");
+    if (rc) return rc;
+    if (!dst) LH_FAIL(ctx, LH_EINVAL, "lh_buf_read: dst is NULL");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, hipMemcpy(dst, b->dev + off, n * 4, hipMemcpyDeviceToHost));
+    return LH_OK;
+}
+
+int lh_buf_fill_synth(lh_ctx* ctx, lh_buf buf, uint64_t off, uint64_t n, uint64_t seed, uint32_t tensor_id, float scale, float offset) {
+    Buffer* b;
+    int rc = get_buf(ctx, buf, off, n, &b, "lh_buf_fill_synth");
+    if (rc) return rc;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t key = mix64(seed ^ ((uint64_t)tensor_id * 0xD6E8FEB86659FD93ull));
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_fill_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b->dev + off, n, key, scale, offset);
+    LH_HIP(ctx, hipGetLastError());
+    return LH_OK;
+}
+
+int lh_buf_free(lh_ctx* ctx, lh_buf buf) {
+    if (!ctx) return LH_EINVAL;
+    DeviceState* ds = ctx->ds;
+    std::unique_ptr<Buffer> b;
+    {
+        std::lock_guard<std::mutex> lk(ds->mu);
+        auto it = ds->bufs.find(buf);
+        if (it == ds->bufs.end()) return LH_EINVAL;
+        b = std::move(it->second);
+        ds->bufs.erase(it);
+        if (b->key) ds->by_key.erase(b->key);
+    }
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(b->dev);
+    return LH_OK;
+}
+
+void* lh_buf_devptr(lh_ctx* ctx, lh_buf buf) {
+    if (!ctx) return nullptr;
+    Buffer* b = find_buffer(ctx->ds, buf);
+    return b ? (void*)b->dev : nullptr;
+}
+
+uint64_t lh_buf_nfloats(lh_ctx* ctx, lh_buf buf) {
+    if (!ctx) return 0;
+    Buffer* b = find_buffer(ctx->ds, buf);
+    return b ? b->nfloats : 0;
+}
+
+}  // extern "C"

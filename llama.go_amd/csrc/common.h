@@ -1,0 +1,90 @@
+// csrc/common.h — internal state of libllamahip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <mutex>
+#include <memory>
+#include "../../include/llamahip.h"
+
+namespace lh {
+
+void set_error(lh_ctx* ctx, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define LH_HIP(ctx, expr)                                                                               \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            lh::set_error(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return LH_EHIP;                                                                             \
+        }                                                                                               \
+    } while (0)
+
+#define LH_FAIL(ctx, code, ...)          \
+    do {                                 \
+        lh::set_error(ctx, __VA_ARGS__); \
+        return code;                     \
+    } while (0)
+
+// A persistent device buffer (weights / KV cache), shared by every context of the device.
+struct Buffer {
+    float* dev = nullptr;
+    uint64_t nfloats = 0;  // f32 elements (for block-int8: logical elements)
+    uint64_t bytes = 0;
+    int dtype = 0;
+    uint64_t key = 0;
+    int device = 0;
+};
+
+// Per-device shared state: buffer registry (Model is shared read-only across pods, server.go:45).
+struct DeviceState {
+    int device = 0;
+    hipDeviceProp_t prop;
+    int num_cu = 0;
+    std::mutex mu;
+    std::unordered_map<lh_buf, std::unique_ptr<Buffer>> bufs;
+    std::unordered_map<uint64_t, lh_buf> by_key;
+    lh_buf next_id = 1;
+    // RoPE table: [positions][dims/2] of (cos, sin) in f64, built on the host with libm exactly as the
+    // reference computes them per element (ml.go:2307-2310); grown on demand.
+    double2* rope_table = nullptr;
+    uint32_t rope_positions = 0, rope_dims = 0;
+};
+DeviceState* device_state(int device);
+Buffer* find_buffer(DeviceState* ds, lh_buf id);
+
+struct Plan;  // fused LLaMA plan (plan.hip)
+
+}  // namespace lh
+
+struct lh_ctx {
+    int device = 0;
+    lh::DeviceState* ds = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // per-graph scratch arena (reset on every lh_graph_compute; grows, never shrinks)
+    char* arena = nullptr;
+    uint64_t arena_bytes = 0;
+    // pinned staging for small host leafs / parameters
+    char* staging = nullptr;
+    uint64_t staging_bytes = 0;
+    // last computed graph: device address + element count of every tensor (for lh_node_read)
+    std::vector<float*> last_ptr;
+    std::vector<uint64_t> last_len;
+    int last_fused = 0;
+    // fused plans cached by structural signature
+    std::vector<lh::Plan*> plans;
+};
+
+namespace lh {
+int ensure_arena(lh_ctx* ctx, uint64_t bytes);
+int ensure_staging(lh_ctx* ctx, uint64_t bytes);
+int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims);
+inline int select_device(lh_ctx* ctx) { return hipSetDevice(ctx->device) == hipSuccess ? 0 : LH_EHIP; }
+}  // namespace lh

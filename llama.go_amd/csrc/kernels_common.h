@@ -1,0 +1,69 @@
+// csrc/kernels_common.h — device helpers shared by every kernel (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lh {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Device-resident per-step parameters of a decode graph: kernels read `past`/`token` from here so a
+// captured hipGraph can be replayed for every position without node updates.
+struct StepParams {
+    uint32_t token;  // token id evaluated by this step
+    uint32_t past;   // llama.Eval's pastCount for this step
+    uint32_t step;   // index into the resident loop's output array
+    uint32_t pad;
+};
+
+// Weights are read exactly once per token and shared by no other CU: stream them with the
+// non-temporal policy (MI355X_MICROARCH "nt-weights": +10-20 % on this access pattern, see
+// profiles/r01_gemv_probe.txt).
+__device__ __forceinline__ f4 ld_nt(const f4* p) { return __builtin_nontemporal_load(p); }
+
+// Sum over each row of 16 lanes with DPP (no LDS traffic); every lane ends with its row's sum.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float rdlane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// Full 64-lane sum, result uniform in every lane.  Fixed association -> deterministic.
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+// Sum over aligned groups of 32 lanes (two DPP rows); result valid in every lane of the group.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v = row16_sum(v);
+    return v + __shfl_xor(v, 16, 64);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// fp32 helpers with the reference's rounding sequence (no contraction):
+//   SiLU  ml.go:2587-2589   x / float32(1 + exp(float64(-x)))
+__device__ __forceinline__ float silu_ref(float x) {
+    const float den = (float)(1.0 + exp((double)(-x)));
+    return __fdiv_rn(x, den);
+}
+//   RoPE  ml.go:2318-2322   rotation in f64, one rounding per output
+__device__ __forceinline__ void rope_rotate(float x0f, float x1f, double2 cs, float* o0, float* o1) {
+    const double x0 = (double)x0f, x1 = (double)x1f;
+    *o0 = (float)__dsub_rn(__dmul_rn(x0, cs.x), __dmul_rn(x1, cs.y));
+    *o1 = (float)__dadd_rn(__dmul_rn(x0, cs.y), __dmul_rn(x1, cs.x));
+}
+
+}  // namespace lh

@@ -1,0 +1,452 @@
+// csrc/kernels_llama.h — fused gfx950 kernels of the LLaMA plan (decode N=1 and small-N prefill).
+//
+// Replaces, per SURVEY §8a: rows 6 (MulMat weights), 8 (GetRows), 9-11 (RMSNorm/Repeat/Mul), 12 (Cpy into
+// cache / merges), 13 (Rope), 15-18 (Scale/DiagMaskInf/SoftMax/KQ/KQV), 19 (Silu), 20 (Add).
+//
+// GEMV layout ("fat workgroup", chosen from profiles/r01_gemv_probe.txt: 6.4-6.7 TB/s on 7B shapes):
+//   grid = #CU workgroups of TH = 1024 threads (16 waves); a dynamic-LDS request > 80 KiB keeps a second
+//   workgroup off the CU, so every CU owns one contiguous, equally sized block of weight rows and the whole
+//   chip finishes together.  Thread t owns columns 4t..4t+3 (+ 4*TH*j): the activation vector lives in KI
+//   float4 REGISTERS for the whole kernel (no LDS staging, no re-reads); weight rows stream through U
+//   rotating float4 slots per thread (non-temporal global_load_dwordx4: 1 KiB contiguous per wave-instruction,
+//   U x 16 KiB in flight per CU).  Per row: 4*KI FMAs, a DPP wave reduction, one LDS word per wave, and a
+//   fixed-order cross-wave sum -> bit-reproducible run to run.
+#pragma once
+#include "kernels_common.h"
+
+namespace lh {
+
+enum { PRO_PLAIN = 0, PRO_RMSNORM = 1 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV_ROPE = 2, EPI_SILU_MUL = 3 };
+enum { MAP_SINGLE = 0, MAP_BLOCK = 1, MAP_PAIR = 2 };
+
+struct GemvArgs {
+    const float* w[3];      // matrix bases (MAP_BLOCK: [wq,wk,wv]; MAP_PAIR: [w1,w3])
+    uint32_t rows_per_mat;  // MAP_BLOCK
+    uint32_t M;             // virtual rows
+    uint32_t K;             // columns
+    const float* x;         // activation [K]
+    const float* gamma;     // PRO_RMSNORM: norm weight [K]
+    float* y;               // EPI_STORE / EPI_RESID / EPI_SILU_MUL output
+    const float* resid;     // EPI_RESID
+    float* q_out;           // EPI_QKV_ROPE: roped Q [d]
+    float* k_cache;         // EPI_QKV_ROPE: this layer's K slot base [ctx][d]
+    float* v_cache;
+    const double2* rope;    // [pos][hd/2] (cos, sin)
+    uint32_t hd;            // head dim (= rope dims)
+    uint32_t d;             // embd
+    const StepParams* sp;   // past
+};
+
+template <int MAP>
+__device__ __forceinline__ const f4* row_ptr(const GemvArgs& a, uint32_t v, uint32_t K4) {
+    if (MAP == MAP_SINGLE) return (const f4*)a.w[0] + (size_t)v * K4;
+    if (MAP == MAP_BLOCK) {
+        const uint32_t m = v / a.rows_per_mat;
+        return (const f4*)a.w[m] + (size_t)(v - m * a.rows_per_mat) * K4;
+    }
+    return (const f4*)a.w[v & 1] + (size_t)(v >> 1) * K4;
+}
+
+// RMSNorm + weight multiply on the thread's own columns (ml.go:1753-1812 then ml.go:1877-1914):
+//   mean = (sum_f64 fl32(x*x)) / K ; scale = fl32(1/sqrt(mean + 1e-5)) ; t = fl32(x*scale) ; h = fl32(gamma*t)
+template <int KI, int TH>
+__device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)[KI], const float* gamma, uint32_t K, double* sred) {
+    constexpr int NW = TH / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        if (act[j]) {
+            s += (double)__fmul_rn(xr[j].x, xr[j].x);
+            s += (double)__fmul_rn(xr[j].y, xr[j].y);
+            s += (double)__fmul_rn(xr[j].z, xr[j].z);
+            s += (double)__fmul_rn(xr[j].w, xr[j].w);
+        }
+    }
+    s = wave_sum_f64(s);
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += sred[w];
+    const double mean = tot / (double)K;
+    const float scale = (float)(1.0 / sqrt(mean + 1e-5));
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        if (act[j]) {
+            const f4 g = ((const f4*)gamma)[tid + j * TH];
+            xr[j].x = __fmul_rn(g.x, __fmul_rn(xr[j].x, scale));
+            xr[j].y = __fmul_rn(g.y, __fmul_rn(xr[j].y, scale));
+            xr[j].z = __fmul_rn(g.z, __fmul_rn(xr[j].z, scale));
+            xr[j].w = __fmul_rn(g.w, __fmul_rn(xr[j].w, scale));
+        }
+    }
+}
+
+template <int KI, int U, int TH, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
+    static_assert(U % 2 == 0, "U must be even (row pairs stay in one batch)");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = TH / 64;
+    double* sred = (double*)smem_raw;                // [NW]
+    float* red = (float*)(smem_raw + NW * 8);        // [2][U][NW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t K4 = a.K >> 2;
+    const uint32_t nwg = gridDim.x;
+    // rows are dealt in pairs so RoPE / SiLU partners share a workgroup and a batch
+    const uint32_t npairs = a.M >> 1;
+    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
+    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+
+    f4 xr[KI];
+    bool act[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        act[j] = (uint32_t)(tid + j * TH) < K4;
+        xr[j] = act[j] ? ((const f4*)a.x)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // first U rows are requested before the prologue so HBM latency overlaps the norm
+    f4 w[U][KI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool rv = r0 + u < r1;
+        const f4* p = row_ptr<MAP>(a, rv ? r0 + u : r0, K4);
+#pragma unroll
+        for (int j = 0; j < KI; ++j) w[u][j] = (rv && act[j]) ? ld_nt(p + tid + j * TH) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, a.gamma, a.K, sred);
+
+    int buf = 0;
+    for (uint32_t r = r0; r < r1; r += U) {
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t nr = r + U + u;
+            const bool nv = nr < r1;
+            const f4* p = row_ptr<MAP>(a, nv ? nr : r0, K4);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const f4 c = w[u][j];
+                s = fmaf(c.x, xr[j].x, s);
+                s = fmaf(c.y, xr[j].y, s);
+                s = fmaf(c.z, xr[j].z, s);
+                s = fmaf(c.w, xr[j].w, s);
+                if (nv && act[j]) w[u][j] = ld_nt(p + tid + j * TH);
+            }
+            acc[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) red[(buf * U + u) * NW + wave] = acc[u];
+        }
+        __syncthreads();
+        if (EPI == EPI_STORE || EPI == EPI_RESID) {
+            if (tid < U && r + tid < r1) {
+                const float* p = red + (buf * U + tid) * NW;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) s += p[k];
+                const uint32_t v = r + tid;
+                if (EPI == EPI_RESID) s = __fadd_rn(s, a.resid[v]);  // Add(cur, inp) ml.go:2515-2584
+                a.y[v] = s;
+            }
+        } else {
+            if (tid < U / 2 && r + 2 * tid < r1) {
+                const float* p0 = red + (buf * U + 2 * tid) * NW;
+                const float* p1 = p0 + NW;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) { s0 += p0[k]; s1 += p1[k]; }
+                const uint32_t v = r + 2 * tid;
+                if (EPI == EPI_SILU_MUL) {
+                    // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+                    a.y[v >> 1] = __fmul_rn(silu_ref(s0), s1);
+                } else {  // EPI_QKV_ROPE
+                    const uint32_t past = a.sp->past;
+                    const uint32_t d = a.d;
+                    if (v < 2 * d) {
+                        const uint32_t e = v < d ? v : v - d;           // element inside the d-vector
+                        const uint32_t i0 = e % a.hd;                   // even offset inside the head
+                        const double2 cs = a.rope[(size_t)past * (a.hd >> 1) + (i0 >> 1)];
+                        float o0, o1;
+                        rope_rotate(s0, s1, cs, &o0, &o1);
+                        float* dst = v < d ? a.q_out + e : a.k_cache + (size_t)past * d + e;
+                        dst[0] = o0;
+                        dst[1] = o1;
+                    } else {
+                        float* dst = a.v_cache + (size_t)past * d + (v - 2 * d);
+                        dst[0] = s0;
+                        dst[1] = s1;
+                    }
+                }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Multi-column variant for small-N prefill (N <= NC per launch): the weight row is still streamed
+// once, NC activation columns live in registers.  Y[c][v] (+ resid) row-major [N][M].
+// ---------------------------------------------------------------------------------------------------
+struct GemmColsArgs {
+    const float* w;     // [M][K]
+    const float* x;     // [ncols][K] (row c at x + c*ldx)
+    float* y;           // [ncols][M] (row c at y + c*ldy)
+    const float* resid; // optional, same layout as y
+    uint32_t M, K, ldx, ldy, ncols;
+};
+
+template <int KI, int U, int TH, int NC>
+__global__ __launch_bounds__(TH) void k_gemv_cols(const GemmColsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = TH / 64;
+    float* red = (float*)smem_raw;  // [2][U*NC][NW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t K4 = a.K >> 2;
+    const uint32_t nwg = gridDim.x;
+    const uint32_t r0 = (uint32_t)(((uint64_t)blockIdx.x * a.M) / nwg);
+    const uint32_t r1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * a.M) / nwg);
+    f4 xr[NC][KI];
+    bool act[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) act[j] = (uint32_t)(tid + j * TH) < K4;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+            xr[c][j] = (act[j] && (uint32_t)c < a.ncols) ? ((const f4*)(a.x + (size_t)c * a.ldx))[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    f4 w[U][KI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool rv = r0 + u < r1;
+        const f4* p = (const f4*)a.w + (size_t)(rv ? r0 + u : r0) * K4;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) w[u][j] = (rv && act[j]) ? ld_nt(p + tid + j * TH) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    int buf = 0;
+    for (uint32_t r = r0; r < r1; r += U) {
+        float acc[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t nr = r + U + u;
+            const bool nv = nr < r1;
+            const f4* p = (const f4*)a.w + (size_t)(nv ? nr : r0) * K4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[u][c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const f4 cw = w[u][j];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float s = acc[u][c];
+                    s = fmaf(cw.x, xr[c][j].x, s);
+                    s = fmaf(cw.y, xr[c][j].y, s);
+                    s = fmaf(cw.z, xr[c][j].z, s);
+                    s = fmaf(cw.w, xr[c][j].w, s);
+                    acc[u][c] = s;
+                }
+                if (nv && act[j]) w[u][j] = ld_nt(p + tid + j * TH);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float s = wave_sum(acc[u][c]);
+                if (lane == 0) red[((buf * U + u) * NC + c) * NW + wave] = s;
+            }
+        __syncthreads();
+        if (tid < U * NC) {
+            const int u = tid / NC, c = tid % NC;
+            if (r + u < r1 && (uint32_t)c < a.ncols) {
+                const float* p = red + ((buf * U + u) * NC + c) * NW;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; ++k) s += p[k];
+                const size_t o = (size_t)c * a.ldy + (r + u);
+                if (a.resid) s = __fadd_rn(s, a.resid[o]);
+                a.y[o] = s;
+            }
+        }
+        buf ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Attention for one (head, query row): scores over the cached keys, scale, causal mask, softmax, PV.
+// Replaces KQ / Scale / DiagMaskInf / SoftMax / VTrans copy / KQV / merge (llama.go:300-333) without
+// materialising the transposed V or the [T x N x H] score tensor.  Keys beyond the causal limit are
+// skipped: in the reference they become exactly 0 after the softmax (ml.go:2476-2477) and add nothing.
+//   grid = (H, N), 256 threads.  K/V rows are strided by d floats in the cache; 8 groups of 32 lanes each
+//   take one key (float4 per lane, 128-float head), reduce with DPP.  T <= TMAX scores live in LDS.
+// ---------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* q;        // [N][d] roped queries
+    const float* k_cache;  // layer slot base [ctx][d] (post-RoPE keys)
+    const float* v_cache;
+    float* out;            // [N][d] merged heads
+    uint32_t d, hd, n;
+    float scale;           // fl32(1/sqrt(hd)) llama.go:306
+    const StepParams* sp;  // past (device) ...
+    uint32_t past_host;    // ... or host value when sp == nullptr
+};
+
+__global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sc = (float*)smem_raw;  // [T] scores / probabilities, then [256] reduction scratch after it
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t h = blockIdx.x, j = blockIdx.y;
+    const uint32_t past = a.sp ? a.sp->past : a.past_host;
+    const uint32_t T = past + j + 1;  // keys 0..past+j are visible to query j (mask: i > past + j, ml.go:2401-2404)
+    float* scratch = sc + ((T + 63) & ~63u);
+    const uint32_t d = a.d, hd = a.hd;
+    const float* q = a.q + (size_t)j * d + h * hd;
+    const float* Kc = a.k_cache + h * hd;
+    const float* Vc = a.v_cache + h * hd;
+    // --- scores: one key per 32-lane group per iteration (hd = 128 -> float4 per lane; general hd handled by loop)
+    const int g = tid >> 5, gl = tid & 31;
+    for (uint32_t t = g; t < T; t += 8) {
+        float s = 0.f;
+        for (uint32_t c = gl * 4; c < hd; c += 128) {
+            const f4 kv = *(const f4*)(Kc + (size_t)t * d + c);
+            const f4 qv = *(const f4*)(q + c);
+            s = fmaf(kv.x, qv.x, s); s = fmaf(kv.y, qv.y, s); s = fmaf(kv.z, qv.z, s); s = fmaf(kv.w, qv.w, s);
+        }
+        s = half_wave_sum(s);
+        if (gl == 0) sc[t] = __fmul_rn(s, a.scale);  // Scale ml.go:2331-2374
+    }
+    __syncthreads();
+    // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum
+    float m = -INFINITY;
+    for (uint32_t t = tid; t < T; t += 256) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    if (lane == 0) scratch[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    __syncthreads();
+    float psum = 0.f;
+    for (uint32_t t = tid; t < T; t += 256) {
+        const float p = (float)exp((double)__fsub_rn(sc[t], m));
+        sc[t] = p;
+        psum += p;
+    }
+    psum = wave_sum(psum);
+    if (lane == 0) scratch[wave] = psum;
+    __syncthreads();
+    const float inv = __fdiv_rn(1.0f, (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
+    __syncthreads();
+    for (uint32_t t = tid; t < T; t += 256) sc[t] = __fmul_rn(sc[t], inv);
+    __syncthreads();
+    // --- PV: thread c accumulates over keys; 256/hd key-phases run in parallel and are combined in LDS
+    const uint32_t phases = 256 / hd ? 256 / hd : 1;  // hd = 128 -> 2
+    const uint32_t c = tid % hd, ph = tid / hd;
+    float acc = 0.f;
+    if (ph < phases) {
+        for (uint32_t t = ph; t < T; t += phases) acc = fmaf(Vc[(size_t)t * d + c], sc[t], acc);
+    }
+    scratch[tid] = acc;
+    __syncthreads();
+    if (tid < hd) {
+        float o = scratch[tid];
+        for (uint32_t p = 1; p < phases; ++p) o += scratch[tid + p * hd];
+        a.out[(size_t)j * d + h * hd + tid] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Small kernels
+// ---------------------------------------------------------------------------------------------------
+// GetRows ml.go:1711-1750 — embedding lookup; token ids from the device step parameters (decode) or a device array.
+__global__ __launch_bounds__(256) void k_embed(const float* __restrict__ emb, const uint32_t* __restrict__ tokens, const StepParams* sp,
+                                                float* __restrict__ x, uint32_t d) {
+    const uint32_t row = blockIdx.x;
+    const uint32_t tok = tokens ? tokens[row] : sp->token;
+    const f4* src = (const f4*)(emb + (size_t)tok * d);
+    f4* dst = (f4*)(x + (size_t)row * d);
+    for (uint32_t i = threadIdx.x; i < d / 4; i += 256) dst[i] = src[i];
+}
+
+// Greedy argmax over the logits (strict >, lowest index on ties: SURVEY §8c) + advance of the resident loop.
+__global__ __launch_bounds__(1024) void k_argmax_advance(const float* __restrict__ logits, uint32_t n, StepParams* sp, uint32_t* __restrict__ out_tokens,
+                                                         uint32_t* __restrict__ argmax_out, int advance) {
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float bv = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        const float v = logits[i];
+        if (v > bv || bi == 0xFFFFFFFFu) { bv = v; bi = i; }  // ascending i: first maximum kept
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const uint32_t oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (argmax_out) *argmax_out = bi;
+        if (advance) {
+            out_tokens[sp->step] = bi;
+            sp->token = bi;
+            sp->past += 1;
+            sp->step += 1;
+        }
+    }
+}
+
+// RMSNorm + weight for N rows (prefill): one workgroup per row.
+__global__ __launch_bounds__(256) void k_rmsnorm_rows(const float* __restrict__ x, const float* __restrict__ gamma, float* __restrict__ y, uint32_t d) {
+    __shared__ double sred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xr = x + (size_t)blockIdx.x * d;
+    float* yr = y + (size_t)blockIdx.x * d;
+    double s = 0.0;
+    for (uint32_t i = tid; i < d; i += 256) s += (double)__fmul_rn(xr[i], xr[i]);
+    s = wave_sum_f64(s);
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    const double mean = (((sred[0] + sred[1]) + sred[2]) + sred[3]) / (double)d;
+    const float scale = (float)(1.0 / sqrt(mean + 1e-5));
+    for (uint32_t i = tid; i < d; i += 256) {
+        const float t = __fmul_rn(xr[i], scale);
+        yr[i] = gamma ? __fmul_rn(gamma[i], t) : t;
+    }
+}
+
+// RoPE on Q (mode 0) and on the new K rows, K/V append into the cache (prefill): qkv rows [N][3][d] -> q [N][d], caches.
+__global__ __launch_bounds__(256) void k_rope_store(const float* __restrict__ qraw, const float* __restrict__ kraw, const float* __restrict__ vraw,
+                                                     float* __restrict__ q, float* __restrict__ k_cache, float* __restrict__ v_cache,
+                                                     const double2* __restrict__ rope, uint32_t d, uint32_t hd, uint32_t past) {
+    const uint32_t row = blockIdx.x, pos = past + row;
+    for (uint32_t e = threadIdx.x * 2; e < d; e += 512) {
+        const double2 cs = rope[(size_t)pos * (hd >> 1) + ((e % hd) >> 1)];
+        float o0, o1;
+        rope_rotate(qraw[(size_t)row * d + e], qraw[(size_t)row * d + e + 1], cs, &o0, &o1);
+        q[(size_t)row * d + e] = o0;
+        q[(size_t)row * d + e + 1] = o1;
+        rope_rotate(kraw[(size_t)row * d + e], kraw[(size_t)row * d + e + 1], cs, &o0, &o1);
+        k_cache[(size_t)pos * d + e] = o0;
+        k_cache[(size_t)pos * d + e + 1] = o1;
+        v_cache[(size_t)pos * d + e] = vraw[(size_t)row * d + e];
+        v_cache[(size_t)pos * d + e + 1] = vraw[(size_t)row * d + e + 1];
+    }
+}
+
+// silu(a) * b elementwise (prefill FFN gate).
+__global__ __launch_bounds__(256) void k_silu_mul(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (; i < n; i += stride) y[i] = __fmul_rn(silu_ref(a[i]), b[i]);
+}
+
+}  // namespace lh

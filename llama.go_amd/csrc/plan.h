@@ -1,0 +1,67 @@
+// csrc/plan.h — fused LLaMA plan: resolved model description + scratch + captured decode graph.
+#pragma once
+#include "common.h"
+#include "kernels_common.h"
+
+namespace lh {
+
+struct LayerW {
+    const float *attn_norm = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+    bool operator==(const LayerW& o) const {
+        return attn_norm == o.attn_norm && wq == o.wq && wk == o.wk && wv == o.wv && wo == o.wo && ffn_norm == o.ffn_norm && w1 == o.w1 && w2 == o.w2 && w3 == o.w3;
+    }
+};
+
+// Device-resolved description of llama.Model + one KV cache (llama.go:181-193, 173-178).
+struct ModelDesc {
+    uint32_t V = 0, d = 0, H = 0, hd = 0, L = 0, F = 0, ctx = 0;
+    uint32_t layer0 = 0, layer1 = 0;  // layers evaluated by this plan
+    uint32_t cache_layer0 = 0;        // layer stored in slot 0 of the caches
+    const float *tok_emb = nullptr, *norm = nullptr, *output = nullptr;
+    std::vector<LayerW> layers;       // indexed by absolute layer id
+    float *kc = nullptr, *vc = nullptr;
+    bool same(const ModelDesc& o) const {
+        return V == o.V && d == o.d && H == o.H && hd == o.hd && L == o.L && F == o.F && ctx == o.ctx && layer0 == o.layer0 && layer1 == o.layer1 &&
+               cache_layer0 == o.cache_layer0 && tok_emb == o.tok_emb && norm == o.norm && output == o.output && kc == o.kc && vc == o.vc && layers == o.layers;
+    }
+    bool first_stage() const { return layer0 == 0; }
+    bool last_stage() const { return layer1 == L; }
+};
+
+struct Plan {
+    lh_ctx* ctx = nullptr;
+    ModelDesc md;
+    // scratch, sized for n_cap rows
+    uint32_t n_cap = 0;
+    float *xa = nullptr, *xb = nullptr, *h = nullptr, *qraw = nullptr, *kraw = nullptr, *vraw = nullptr, *q = nullptr, *attn = nullptr;
+    float *a1 = nullptr, *a3 = nullptr, *g = nullptr, *logits = nullptr;
+    uint32_t* tokens_dev = nullptr;
+    // decode graph state
+    StepParams* sp_dev = nullptr;
+    StepParams* sp_host = nullptr;   // pinned
+    uint32_t* out_tokens_dev = nullptr;
+    uint32_t out_cap = 0;
+    uint32_t* argmax_dev = nullptr;
+    hipGraphExec_t exec_step = nullptr;       // one Eval(N=1): embed .. logits
+    hipGraphExec_t exec_step_adv = nullptr;   // the same + argmax + advance (resident greedy loop)
+    hipGraph_t graph_step = nullptr, graph_step_adv = nullptr;
+    bool use_graph = true;
+};
+
+int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out);
+void plan_destroy(Plan* p);
+Plan* plan_find_or_create(lh_ctx* ctx, const ModelDesc& md, int* rc);
+int plan_ensure_rows(Plan* p, uint32_t n);
+// One llama.Eval on the plan: tokens (host) or x_in (device) -> logits rows in p->logits ([n][V]) or x_out (non-last stage).
+int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past);
+// enqueue the kernels of one decode step (N = 1), parameters from p->sp_dev
+int plan_enqueue_decode(Plan* p, const float* x_in_dev, float* x_out_dev, bool with_argmax_advance, lh_kernel_time* prof, uint32_t prof_cap, uint32_t* prof_n);
+int plan_decode_step(Plan* p, uint32_t token, uint32_t past);  // graph replay of one step; logits in p->logits
+void destroy_plans(lh_ctx* ctx);
+
+}  // namespace lh
+
+struct lh_llama {
+    lh_ctx* ctx;
+    lh::Plan* plan;
+};

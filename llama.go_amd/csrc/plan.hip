@@ -1,0 +1,601 @@
+// csrc/plan.hip — fused LLaMA plan executor: decode step (hipGraph-replayed), small-N prefill, pipeline
+// stages, device-resident greedy loop, per-kernel event profiling.  Entry points: lh_llama_* (llamahip.h).
+// Follows the layer schedule of llama.Eval (pkg/llama/llama.go:246-384).
+#include "plan.h"
+#include "kernels_llama.h"
+#include <math.h>
+#include <algorithm>
+
+namespace lh {
+
+static thread_local bool g_prepare_only = false;  // set kernel attributes without launching (before graph capture)
+
+static constexpr int TH = 1024;
+static constexpr size_t FAT_LDS = 96 * 1024;  // > 80 KiB: one fat workgroup per CU
+
+struct ProfSink {
+    struct Rec { const char* name; uint64_t bytes; hipEvent_t e0, e1; };
+    std::vector<Rec> recs;
+    bool on = false;
+};
+static thread_local ProfSink* g_prof = nullptr;
+
+struct ProfScope {
+    hipStream_t st;
+    ProfSink::Rec rec;
+    bool on;
+    ProfScope(hipStream_t s, const char* name, uint64_t bytes) : st(s), on(g_prof && g_prof->on && !g_prepare_only) {
+        if (on) {
+            rec.name = name; rec.bytes = bytes;
+            hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
+            hipEventRecord(rec.e0, st);
+        }
+    }
+    ~ProfScope() {
+        if (on) { hipEventRecord(rec.e1, st); g_prof->recs.push_back(rec); }
+    }
+};
+
+template <typename KernT>
+static int set_lds_once(lh_ctx* ctx, KernT kern, size_t lds, bool* flags) {
+    if (!flags[ctx->device & 15]) {
+        LH_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        flags[ctx->device & 15] = true;
+    }
+    return 0;
+}
+
+template <int KI, int U, int PRO, int EPI, int MAP>
+static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
+    auto kern = k_gemv<KI, U, TH, PRO, EPI, MAP>;
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, name, bytes);
+    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+template <int PRO, int EPI, int MAP>
+static int gemv(lh_ctx* ctx, const GemvArgs& a, const char* name) {
+    if (a.K % 4 || a.M % 2) LH_FAIL(ctx, LH_ESHAPE, "gemv %s: K=%u must be a multiple of 4 and M=%u even", name, a.K, a.M);
+    const uint32_t K4 = a.K / 4;
+    const int ki = (int)((K4 + TH - 1) / TH);
+    const uint64_t bytes = (uint64_t)a.M * a.K * 4;
+    switch (ki) {
+        case 1: return launch_gemv<1, 4, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 2: return launch_gemv<2, 4, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 3: return launch_gemv<3, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 4: return launch_gemv<4, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 5: return launch_gemv<5, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 6: return launch_gemv<6, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+        default: LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: K=%u exceeds the supported 24576 columns", name, a.K);
+    }
+}
+
+template <int KI, int U, int NC>
+static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
+    auto kern = k_gemv_cols<KI, U, TH, NC>;
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4);
+    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// Y[n][M] = X[n][K] . W[M][K]^T (+ resid), weights streamed once per chunk of NC activation rows.
+int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n,
+                 uint32_t ldx, uint32_t ldy, const char* name) {
+    if (K % 4) LH_FAIL(ctx, LH_ESHAPE, "gemm %s: K=%u must be a multiple of 4", name, K);
+    const uint32_t K4 = K / 4;
+    const int ki = (int)((K4 + TH - 1) / TH);
+    const uint32_t NCmax = ki <= 2 ? 8 : 4;
+    for (uint32_t c0 = 0; c0 < n; c0 += NCmax) {
+        GemmColsArgs a;
+        a.w = w; a.x = x + (size_t)c0 * ldx; a.y = y + (size_t)c0 * ldy; a.resid = resid ? resid + (size_t)c0 * ldy : nullptr;
+        a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy; a.ncols = std::min(NCmax, n - c0);
+        int rc;
+        switch (ki) {
+            case 1: rc = launch_cols<1, 2, 8>(ctx, a, name); break;
+            case 2: rc = launch_cols<2, 2, 8>(ctx, a, name); break;
+            case 3: rc = launch_cols<3, 2, 4>(ctx, a, name); break;
+            case 4: rc = launch_cols<4, 2, 4>(ctx, a, name); break;
+            case 5: rc = launch_cols<5, 1, 4>(ctx, a, name); break;
+            case 6: rc = launch_cols<6, 1, 4>(ctx, a, name); break;
+            default: LH_FAIL(ctx, LH_EUNSUPPORTED, "gemm %s: K=%u exceeds the supported 24576 columns", name, K);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
+    if (a.hd > 256 || 256 % a.hd || a.hd % 4) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: head dim %u unsupported (needs to divide 256)", a.hd);
+    const size_t lds = ((size_t)((max_T + 63) & ~63u) + 256) * 4;
+    static bool flags[16] = {};
+    static size_t cur[16] = {};
+    if (lds > 48 * 1024 && lds > cur[ctx->device & 15]) {
+        flags[ctx->device & 15] = false;
+        int rc = set_lds_once(ctx, k_attention, 160 * 1024, flags);
+        if (rc) return rc;
+        cur[ctx->device & 15] = 160 * 1024;
+    }
+    if (lds > 160 * 1024) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: %u keys exceed the single-pass LDS budget", max_T);
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, "attention", (uint64_t)2 * max_T * a.d * 4);
+    hipLaunchKernelGGL(k_attention, dim3(a.d / a.hd, a.n), dim3(256), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+int plan_ensure_rows(Plan* p, uint32_t n) {
+    if (n <= p->n_cap) return 0;
+    lh_ctx* ctx = p->ctx;
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const ModelDesc& m = p->md;
+    auto re = [&](float** ptr, size_t nfloats) -> int {
+        if (*ptr) LH_HIP(ctx, hipFree(*ptr));
+        *ptr = nullptr;
+        LH_HIP(ctx, hipMalloc((void**)ptr, nfloats * 4));
+        return 0;
+    };
+    const size_t nd = (size_t)n * m.d, nf = (size_t)n * m.F;
+    int rc = 0;
+    rc |= re(&p->xa, nd); rc |= re(&p->xb, nd); rc |= re(&p->h, nd); rc |= re(&p->q, nd); rc |= re(&p->attn, nd); rc |= re(&p->g, nf);
+    if (n > 1) { rc |= re(&p->qraw, nd); rc |= re(&p->kraw, nd); rc |= re(&p->vraw, nd); rc |= re(&p->a1, nf); rc |= re(&p->a3, nf); }
+    if (m.last_stage()) rc |= re(&p->logits, (size_t)n * m.V);
+    if (rc) return LH_EHIP;
+    if (p->tokens_dev) LH_HIP(ctx, hipFree(p->tokens_dev));
+    LH_HIP(ctx, hipMalloc((void**)&p->tokens_dev, (size_t)n * 4));
+    p->n_cap = n;
+    // captured graphs hold the old scratch addresses
+    if (p->exec_step) { hipGraphExecDestroy(p->exec_step); p->exec_step = nullptr; }
+    if (p->exec_step_adv) { hipGraphExecDestroy(p->exec_step_adv); p->exec_step_adv = nullptr; }
+    if (p->graph_step) { hipGraphDestroy(p->graph_step); p->graph_step = nullptr; }
+    if (p->graph_step_adv) { hipGraphDestroy(p->graph_step_adv); p->graph_step_adv = nullptr; }
+    return 0;
+}
+
+static constexpr uint32_t SP_SLOTS = 64;
+
+int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
+    if (md.d % md.H || md.d % 4 || md.F % 4) LH_FAIL(ctx, LH_ESHAPE, "plan: embd %u / heads %u / ff %u not supported", md.d, md.H, md.F);
+    Plan* p = new Plan();
+    p->ctx = ctx;
+    p->md = md;
+    const char* env = getenv("LLAMAHIP_NO_GRAPH");
+    p->use_graph = !(env && env[0] == '1');
+    int rc = ensure_rope_table(ctx, md.ctx, md.hd);
+    if (rc) { delete p; return rc; }
+    hipError_t e = hipMalloc((void**)&p->sp_dev, sizeof(StepParams) * SP_SLOTS);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&p->sp_host, sizeof(StepParams) * SP_SLOTS, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->argmax_dev, 4);
+    if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
+    rc = plan_ensure_rows(p, 1);
+    if (rc) { plan_destroy(p); return rc; }
+    *out = p;
+    return 0;
+}
+
+void plan_destroy(Plan* p) {
+    if (!p) return;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    if (p->exec_step) hipGraphExecDestroy(p->exec_step);
+    if (p->exec_step_adv) hipGraphExecDestroy(p->exec_step_adv);
+    if (p->graph_step) hipGraphDestroy(p->graph_step);
+    if (p->graph_step_adv) hipGraphDestroy(p->graph_step_adv);
+    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits};
+    for (float* b : bufs) if (b) hipFree(b);
+    if (p->tokens_dev) hipFree(p->tokens_dev);
+    if (p->sp_dev) hipFree(p->sp_dev);
+    if (p->sp_host) hipHostFree(p->sp_host);
+    if (p->out_tokens_dev) hipFree(p->out_tokens_dev);
+    if (p->argmax_dev) hipFree(p->argmax_dev);
+    delete p;
+}
+
+Plan* plan_find_or_create(lh_ctx* ctx, const ModelDesc& md, int* rc) {
+    for (Plan* p : ctx->plans) if (p->md.same(md)) { *rc = 0; return p; }
+    Plan* p = nullptr;
+    *rc = plan_create(ctx, md, &p);
+    if (*rc) return nullptr;
+    ctx->plans.push_back(p);
+    return p;
+}
+
+void destroy_plans(lh_ctx* ctx) {
+    for (Plan* p : ctx->plans) plan_destroy(p);
+    ctx->plans.clear();
+}
+
+// ---- decode step (N = 1): 5 kernels per layer --------------------------------------------------------
+static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, bool argmax_advance, uint32_t* argmax_out,
+                          const uint32_t* tokens_dev = nullptr) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    const double2* rope = ctx->ds->rope_table;
+    int rc;
+    const float* x = p->xa;
+    if (m.first_stage()) {
+        if (!g_prepare_only) {
+            ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
+            hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d);
+            LH_HIP(ctx, hipGetLastError());
+        }
+    } else {
+        x = x_in;  // residual stream received from the previous stage
+    }
+    float* xa = p->xa;
+    float* xb = p->xb;
+    const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
+    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+        const LayerW& L = m.layers[il];
+        const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
+        {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K) -> K,V appended to the cache   (llama.go:255-297)
+            GemvArgs a = {};
+            a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.rows_per_mat = m.d; a.M = 3 * m.d; a.K = m.d;
+            a.x = x; a.gamma = L.attn_norm; a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot;
+            a.rope = rope; a.hd = m.hd; a.d = m.d; a.sp = sp;
+            if ((rc = gemv<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "gemv_qkv_rope"))) return rc;
+        }
+        {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
+            AttnArgs a = {};
+            a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = m.d; a.hd = m.hd; a.n = 1; a.scale = scale; a.sp = sp;
+            if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
+        }
+        {   // wo + residual   (llama.go:336-340)
+            GemvArgs a = {};
+            a.w[0] = L.wo; a.M = m.d; a.K = m.d; a.x = p->attn; a.resid = x; a.y = xb;
+            if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_wo_resid"))) return rc;
+        }
+        {   // RMSNorm*gamma -> w1|w3 -> silu(w1 h) * (w3 h)   (llama.go:346-361)
+            GemvArgs a = {};
+            a.w[0] = L.w1; a.w[1] = L.w3; a.M = 2 * m.F; a.K = m.d; a.x = xb; a.gamma = L.ffn_norm; a.y = p->g;
+            if ((rc = gemv<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "gemv_w1w3_silu"))) return rc;
+        }
+        {   // w2 + residual   (llama.go:363-366)
+            const bool last = il + 1 == m.layer1;
+            GemvArgs a = {};
+            a.w[0] = L.w2; a.M = m.d; a.K = m.F; a.x = p->g; a.resid = xb;
+            a.y = (last && !m.last_stage()) ? x_out : xa;
+            if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_w2_resid"))) return rc;
+        }
+        x = xa;
+    }
+    if (m.last_stage()) {   // final RMSNorm*gamma -> lm_head   (llama.go:374-384)
+        GemvArgs a = {};
+        a.w[0] = m.output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits;
+        if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead"))) return rc;
+        if ((argmax_advance || argmax_out) && !g_prepare_only) {
+            ProfScope ps(ctx->stream, "argmax", (uint64_t)m.V * 4);
+            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)p->logits, m.V, (StepParams*)sp, p->out_tokens_dev,
+                               argmax_out, argmax_advance ? 1 : 0);
+            LH_HIP(ctx, hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+static int ensure_out_tokens(Plan* p, uint32_t n) {
+    if (n <= p->out_cap) return 0;
+    lh_ctx* ctx = p->ctx;
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (p->out_tokens_dev) LH_HIP(ctx, hipFree(p->out_tokens_dev));
+    p->out_tokens_dev = nullptr;
+    const uint32_t cap = std::max(n, 4096u);
+    LH_HIP(ctx, hipMalloc((void**)&p->out_tokens_dev, (size_t)cap * 4));
+    p->out_cap = cap;
+    // graphs captured the old pointer
+    if (p->exec_step_adv) { hipGraphExecDestroy(p->exec_step_adv); p->exec_step_adv = nullptr; }
+    if (p->graph_step_adv) { hipGraphDestroy(p->graph_step_adv); p->graph_step_adv = nullptr; }
+    return 0;
+}
+
+static int ensure_decode_graph(Plan* p, bool adv) {
+    lh_ctx* ctx = p->ctx;
+    hipGraphExec_t& exec = adv ? p->exec_step_adv : p->exec_step;
+    hipGraph_t& graph = adv ? p->graph_step_adv : p->graph_step;
+    if (exec) return 0;
+    if (adv) { int rc = ensure_out_tokens(p, 1); if (rc) return rc; }
+    g_prepare_only = true;
+    int rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
+    g_prepare_only = false;
+    if (rc) return rc;
+    LH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc) return rc;
+    if (e != hipSuccess) LH_FAIL(ctx, LH_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    LH_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    return 0;
+}
+
+static int upload_step_params(Plan* p, uint32_t slot, uint32_t token, uint32_t past, uint32_t step) {
+    lh_ctx* ctx = p->ctx;
+    p->sp_host[slot].token = token;
+    p->sp_host[slot].past = past;
+    p->sp_host[slot].step = step;
+    p->sp_host[slot].pad = 0;
+    LH_HIP(ctx, hipMemcpyAsync(p->sp_dev + slot, p->sp_host + slot, sizeof(StepParams), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    if (past >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: position %u outside the context window of %u", past, m.ctx);
+    if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "plan_decode_step needs a whole-model plan");
+    int rc;
+    if (p->use_graph) {
+        if ((rc = ensure_decode_graph(p, false))) return rc;
+        if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
+        LH_HIP(ctx, hipGraphLaunch(p->exec_step, ctx->stream));
+        return 0;
+    }
+    if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
+    return enqueue_decode(p, p->sp_dev, nullptr, nullptr, false, nullptr);
+}
+
+// ---- general Eval on the plan (N >= 1) ----------------------------------------------------------------
+static uint32_t g_slot_counter = 0;
+
+int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    if (n == 0) LH_FAIL(ctx, LH_EINVAL, "Eval: empty token batch");
+    if ((uint64_t)past + n > m.ctx) LH_FAIL(ctx, LH_EINVAL, "Eval: past %u + n %u exceeds the context window of %u", past, n, m.ctx);
+    if (m.first_stage() && !tokens_host) LH_FAIL(ctx, LH_EINVAL, "Eval: first stage needs token ids");
+    if (!m.first_stage() && !x_in_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: later stage needs the residual stream");
+    if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: non-final stage needs an output buffer");
+    int rc;
+    if ((rc = plan_ensure_rows(p, n))) return rc;
+    if (n == 1) {
+        if (m.first_stage() && m.last_stage() && p->use_graph) return plan_decode_step(p, tokens_host[0], past);
+        const uint32_t slot = 1 + (g_slot_counter++ % (SP_SLOTS - 1));
+        if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
+        return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
+    }
+    // ---- prefill, N > 1 rows
+    const double2* rope = ctx->ds->rope_table;
+    const float* x = p->xa;
+    if (m.first_stage()) {
+        if ((rc = ensure_staging(ctx, (uint64_t)n * 4))) return rc;
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
+        memcpy(ctx->staging, tokens_host, (size_t)n * 4);
+        LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d);
+        LH_HIP(ctx, hipGetLastError());
+    } else {
+        x = x_in_dev;
+    }
+    const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
+    const uint32_t d = m.d, F = m.F;
+    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+        const LayerW& L = m.layers[il];
+        const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d);
+        if ((rc = gemm_small_n(ctx, L.wq, p->h, p->qraw, nullptr, d, d, n, d, d, "gemm_wq"))) return rc;
+        if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
+        if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
+        hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
+                           m.vc + slot, rope, d, m.hd, past);
+        AttnArgs a = {};
+        a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
+        if ((rc = launch_attention(ctx, a, past + n))) return rc;
+        if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d);
+        if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
+        if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
+        hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
+                           (const float*)p->a3, p->g, (uint64_t)n * F);
+        const bool last = il + 1 == m.layer1;
+        float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
+        if ((rc = gemm_small_n(ctx, L.w2, p->g, y, p->xb, d, F, n, F, d, "gemm_w2"))) return rc;
+        x = p->xa;
+        LH_HIP(ctx, hipGetLastError());
+    }
+    if (m.last_stage()) {
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, m.norm, p->h, d);
+        // the reference evaluates lm_head for all N rows (llama.go:384) although only row N-1 is read (llama.go:394-401)
+        if ((rc = gemm_small_n(ctx, m.output, p->h, p->logits, nullptr, m.V, d, n, d, m.V, "gemm_lmhead"))) return rc;
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace lh
+
+using namespace lh;
+
+// ======================================================================================================
+// C-ABI
+// ======================================================================================================
+extern "C" {
+
+void lh_ctx_destroy(lh_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    destroy_plans(ctx);
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->staging) hipHostFree(ctx->staging);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out) {
+    if (!ctx || !desc || !out) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: NULL argument");
+    *out = nullptr;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (desc->weight_dtype != 0) LH_FAIL(ctx, LH_EUNSUPPORTED, "lh_llama_create: weight dtype %d not supported yet", desc->weight_dtype);
+    ModelDesc md;
+    md.V = desc->vocab; md.d = desc->embd; md.H = desc->heads; md.L = desc->layers; md.F = desc->ff; md.ctx = desc->ctx;
+    if (!md.H || !md.d || md.d % md.H) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: bad embd/heads");
+    md.hd = md.d / md.H;
+    md.layer0 = desc->layer0; md.layer1 = desc->layer1 ? desc->layer1 : desc->layers;
+    if (md.layer0 >= md.layer1 || md.layer1 > md.L) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: bad layer range [%u,%u)", md.layer0, md.layer1);
+    md.cache_layer0 = md.layer0;
+    auto need = [&](lh_buf b, uint64_t n, const char* what, const float** dst) -> int {
+        Buffer* bf = find_buffer(ctx->ds, b);
+        if (!bf) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: %s is not a registered buffer", what);
+        if (bf->nfloats < n) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: %s has %llu floats, needs %llu", what, (unsigned long long)bf->nfloats, (unsigned long long)n);
+        *dst = bf->dev;
+        return 0;
+    };
+    int rc;
+    const uint64_t d = md.d, F = md.F, V = md.V;
+    if (md.first_stage() && (rc = need(desc->tok_embeddings, V * d, "tok_embeddings", &md.tok_emb))) return rc;
+    if (md.last_stage()) {
+        if ((rc = need(desc->norm, d, "norm", &md.norm))) return rc;
+        if ((rc = need(desc->output, V * d, "output", &md.output))) return rc;
+    }
+    md.layers.resize(md.L);
+    for (uint32_t il = md.layer0; il < md.layer1; ++il) {
+        const lh_llama_layer& s = desc->layer[il];
+        LayerW& L = md.layers[il];
+        if ((rc = need(s.attention_norm, d, "attention_norm", &L.attn_norm))) return rc;
+        if ((rc = need(s.wq, d * d, "wq", &L.wq))) return rc;
+        if ((rc = need(s.wk, d * d, "wk", &L.wk))) return rc;
+        if ((rc = need(s.wv, d * d, "wv", &L.wv))) return rc;
+        if ((rc = need(s.wo, d * d, "wo", &L.wo))) return rc;
+        if ((rc = need(s.ffn_norm, d, "ffn_norm", &L.ffn_norm))) return rc;
+        if ((rc = need(s.w1, d * F, "w1", &L.w1))) return rc;
+        if ((rc = need(s.w2, d * F, "w2", &L.w2))) return rc;
+        if ((rc = need(s.w3, d * F, "w3", &L.w3))) return rc;
+    }
+    const float *kc, *vc;
+    const uint64_t kvn = d * (md.layer1 - md.layer0) * md.ctx;
+    if ((rc = need(desc->k_cache, kvn, "k_cache", &kc))) return rc;
+    if ((rc = need(desc->v_cache, kvn, "v_cache", &vc))) return rc;
+    md.kc = (float*)kc; md.vc = (float*)vc;
+    Plan* p = nullptr;
+    if ((rc = plan_create(ctx, md, &p))) return rc;
+    lh_llama* m = new lh_llama();
+    m->ctx = ctx;
+    m->plan = p;
+    *out = m;
+    return LH_OK;
+}
+
+void lh_llama_destroy(lh_llama* m) {
+    if (!m) return;
+    plan_destroy(m->plan);
+    delete m;
+}
+
+int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past, float* logits_host) {
+    if (!m || !tokens) return LH_EINVAL;
+    lh_ctx* ctx = m->ctx;
+    Plan* p = m->plan;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!p->md.first_stage() || !p->md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_eval needs a whole-model plan; use lh_llama_stage");
+    int rc = plan_eval(p, tokens, nullptr, nullptr, n, past);
+    if (rc) return rc;
+    if (logits_host)
+        LH_HIP(ctx, hipMemcpyAsync(logits_host, p->logits + (size_t)(n - 1) * p->md.V, (size_t)p->md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LH_OK;
+}
+
+int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host) {
+    if (!m || !n_steps) return LH_EINVAL;
+    lh_ctx* ctx = m->ctx;
+    Plan* p = m->plan;
+    const ModelDesc& md = p->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!md.first_stage() || !md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_greedy needs a whole-model plan");
+    if ((uint64_t)past + n_steps > md.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: past %u + %u steps exceed the context window of %u", past, n_steps, md.ctx);
+    int rc;
+    if ((rc = ensure_out_tokens(p, n_steps))) return rc;
+    if (p->use_graph && (rc = ensure_decode_graph(p, true))) return rc;
+    if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
+    for (uint32_t s = 0; s < n_steps; ++s) {
+        if (p->use_graph) LH_HIP(ctx, hipGraphLaunch(p->exec_step_adv, ctx->stream));
+        else if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
+    }
+    if (out_tokens) LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, p->logits, (size_t)md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LH_OK;
+}
+
+int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_dev, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past,
+                   float* logits_dev, uint32_t* argmax_dev) {
+    if (!m) return LH_EINVAL;
+    lh_ctx* ctx = m->ctx;
+    Plan* p = m->plan;
+    const ModelDesc& md = p->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if (n == 1) {
+        if ((rc = plan_ensure_rows(p, 1))) return rc;
+        if ((uint64_t)past + 1 > md.ctx) LH_FAIL(ctx, LH_EINVAL, "stage: position %u outside the context window", past);
+        const uint32_t slot = 1 + (g_slot_counter++ % (SP_SLOTS - 1));
+        if (md.first_stage() && !tokens && !tokens_dev) LH_FAIL(ctx, LH_EINVAL, "stage: first stage needs a token id (host or device)");
+        if ((rc = upload_step_params(p, slot, tokens ? tokens[0] : 0, past, 0))) return rc;
+        if ((rc = enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, md.last_stage() ? argmax_dev : nullptr, tokens ? nullptr : tokens_dev))) return rc;
+    } else {
+        if (md.first_stage() && !tokens) LH_FAIL(ctx, LH_EINVAL, "stage: multi-row first stage needs host token ids");
+        if ((rc = plan_eval(p, tokens, x_in_dev, x_out_dev, n, past))) return rc;
+        if (md.last_stage() && argmax_dev) {
+            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)(p->logits + (size_t)(n - 1) * md.V), md.V, (StepParams*)nullptr,
+                               (uint32_t*)nullptr, argmax_dev, 0);
+            LH_HIP(ctx, hipGetLastError());
+        }
+    }
+    if (md.last_stage() && logits_dev)
+        LH_HIP(ctx, hipMemcpyAsync(logits_dev, p->logits + (size_t)(n - 1) * md.V, (size_t)md.V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return LH_OK;
+}
+
+int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap) {
+    if (!m || !out || !repeats) return LH_EINVAL;
+    lh_ctx* ctx = m->ctx;
+    Plan* p = m->plan;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure_out_tokens(p, 1))) return rc;
+    const float* pin = p->md.first_stage() ? nullptr : p->h;   // stage models: scratch stands in for the received residual
+    float* pout = p->md.last_stage() ? nullptr : p->attn;
+    ProfSink sink;
+    sink.on = true;
+    // warm-up (also sets kernel attributes), then timed eager steps at the same position
+    g_prof = nullptr;
+    if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
+    if ((rc = enqueue_decode(p, p->sp_dev, pin, pout, false, nullptr))) return rc;
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g_prof = &sink;
+    for (uint32_t r = 0; r < repeats && !rc; ++r) rc = enqueue_decode(p, p->sp_dev, pin, pout, false, p->md.last_stage() ? p->argmax_dev : nullptr);
+    g_prof = nullptr;
+    hipStreamSynchronize(ctx->stream);
+    std::vector<lh_kernel_time> acc;
+    for (auto& r : sink.recs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+        size_t i = 0;
+        for (; i < acc.size(); ++i) if (!strcmp(acc[i].name, r.name)) break;
+        if (i == acc.size()) {
+            lh_kernel_time t = {};
+            snprintf(t.name, sizeof t.name, "%s", r.name);
+            t.bytes_per_launch = r.bytes;
+            acc.push_back(t);
+        }
+        acc[i].launches += 1;
+        acc[i].total_ms += ms;
+    }
+    if (rc) return rc;
+    uint32_t n = (uint32_t)std::min<size_t>(acc.size(), cap);
+    for (uint32_t i = 0; i < n; ++i) out[i] = acc[i];
+    return (int)n;
+}
+
+}  // extern "C"

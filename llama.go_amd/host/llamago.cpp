@@ -1,0 +1,731 @@
+// host/llamago.cpp — C++ mirror of the reference's pkg/ml + pkg/llama operator surface (include/llamago.h)
+// on top of the C-ABI boundary (include/llamahip.h).  This file is what the Go side of a llama.go build with
+// the `hip` tag does (INTEGRATION.md / go/ml_hip.go): graphs are BUILT on the host exactly like the reference
+// (shapes, strides, view aliasing, post-order DFS), and ml_GraphCompute crosses the boundary ONCE per Eval.
+// No arithmetic of the hot path happens here and there is no CPU fallback: without a GPU every compute call fails.
+//
+// The reference is Go; the toolchain is absent from this image, hence C++ (prompt rule ②).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include "../../include/llamago.h"
+#include "../../include/llamahip.h"
+
+#define MAX_NODES 4096  // ml.go:20
+
+static thread_local std::string g_err;
+static void* halt(const char* msg) { g_err = msg; return nullptr; }
+static int halt_rc(const std::string& msg) { g_err = msg; return 1; }
+extern "C" const char* ml_LastError(void) { return g_err.c_str(); }
+
+// ---- process-wide device selection -----------------------------------------------------------------
+static void* g_stream_for_new_contexts = nullptr;
+static int device_index() {
+    const char* e = getenv("LLAMAGO_DEVICE");
+    if (e && *e) return atoi(e);
+    e = getenv("LOCAL_RANK");
+    if (e && *e) return atoi(e);
+    return 0;
+}
+static lh_ctx* g_model_ctx = nullptr;  // context used for model-level work (weight registration, fills)
+static lh_ctx* model_ctx() {
+    if (!g_model_ctx) {
+        int rc = lh_ctx_create(device_index(), nullptr, &g_model_ctx);
+        if (rc) { g_err = std::string("no HIP context: ") + lh_last_error(nullptr); return nullptr; }
+    }
+    return g_model_ctx;
+}
+
+struct ml_context {  // ml.Context ml.go:50-57
+    int maxThreads;
+    lh_ctx* hip;
+    uint64_t generation = 0;  // bumped by every GraphCompute (validity of tensor->graph indices)
+};
+
+struct ml_tensor {  // ml.Tensor ml.go:180-203
+    int type = 0;
+    uint32_t dims = 0;
+    uint32_t ne[4] = {1, 1, 1, 1};
+    uint32_t nb[4] = {4, 4, 4, 4};
+    int op = ML_OP_NONE;
+    ml_tensor *src0 = nullptr, *src1 = nullptr;
+    float* data = nullptr;  // host Data (NULL for device-only persistent tensors)
+    bool owns = false;
+    // aliasing made explicit for the C side: the tensor whose allocation these bytes live in + float offset
+    ml_tensor* base = nullptr;
+    uint64_t base_off = 0;
+    // device residency of persistent leafs (weights, KV cache)
+    lh_buf buf = 0;
+    bool persistent = false;
+    // position in the last computed graph
+    ml_context* last_ctx = nullptr;
+    uint64_t last_gen = 0;
+    uint32_t last_index = 0;
+    ml_tensor* gc_next = nullptr;
+};
+
+struct ml_graph {  // ml.Graph ml.go:31-45
+    std::vector<ml_tensor*> nodes, leafs;
+};
+
+static thread_local ml_tensor* g_gc_head = nullptr;
+static thread_local bool g_gc_enabled = true;
+
+static uint64_t nelements(const ml_tensor* t) { return (uint64_t)t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
+static bool same_shape(const ml_tensor* a, const ml_tensor* b) { return a->ne[0] == b->ne[0] && a->ne[1] == b->ne[1] && a->ne[2] == b->ne[2] && a->ne[3] == b->ne[3]; }
+
+// NewTensor ml.go:760-783 — strides always re-derived contiguous; data == alias of `alias_of` when given
+static ml_tensor* new_tensor(int dt, uint32_t dims, uint32_t ne0, uint32_t ne1, uint32_t ne2, uint32_t ne3, ml_tensor* alias_of, uint64_t extra_off,
+                             bool alloc_host = true) {
+    ml_tensor* t = new ml_tensor();
+    t->type = dt;
+    t->dims = dims;
+    t->ne[0] = ne0; t->ne[1] = ne1; t->ne[2] = ne2; t->ne[3] = ne3;
+    t->nb[0] = 4; t->nb[1] = ne0 * 4; t->nb[2] = ne0 * ne1 * 4; t->nb[3] = ne0 * ne1 * ne2 * 4;
+    if (alias_of) {
+        t->base = alias_of->base;
+        t->base_off = alias_of->base_off + extra_off;
+        t->data = alias_of->base->data ? alias_of->base->data + t->base_off : nullptr;
+    } else {
+        t->base = t;
+        if (alloc_host) {
+            const uint64_t n = nelements(t);
+            t->data = (float*)calloc(n ? n : 1, sizeof(float));
+            t->owns = true;
+        }
+    }
+    if (g_gc_enabled) { t->gc_next = g_gc_head; g_gc_head = t; }
+    return t;
+}
+static ml_tensor* new_leaf(int dt, uint32_t dims, uint32_t ne0, uint32_t ne1, uint32_t ne2, bool alloc_host = true) {
+    const bool save = g_gc_enabled;
+    g_gc_enabled = false;
+    ml_tensor* t = new_tensor(dt, dims, ne0, ne1, ne2, 1, nullptr, 0, alloc_host);
+    g_gc_enabled = save;
+    return t;
+}
+static ml_tensor* view_tensor(ml_tensor* s) { return new_tensor(s->type, s->dims, s->ne[0], s->ne[1], s->ne[2], s->ne[3], s, 0); }  // ml.go:231
+static ml_tensor* dup_tensor(ml_tensor* s) { return new_tensor(s->type, s->dims, s->ne[0], s->ne[1], s->ne[2], s->ne[3], nullptr, 0); }  // ml.go:236
+static ml_tensor* node2(ml_tensor* r, int op, ml_tensor* a, ml_tensor* b) { r->op = op; r->src0 = a; r->src1 = b; return r; }
+static void free_tensor(ml_tensor* t) {
+    if (!t) return;
+    if (t->owns) free(t->data);
+    if (t->buf && t->persistent && g_model_ctx) lh_buf_free(g_model_ctx, t->buf);
+    delete t;
+}
+
+extern "C" {
+
+// ---- context ---------------------------------------------------------------------------------------
+ml_context* ml_NewContext(int maxThreads, int useAVX, int useNEON) {  // ml.go:59-74
+    (void)useAVX; (void)useNEON;  // CPU kernel selectors of the reference (ml.go:52-53); this backend always runs HIP
+    lh_ctx* h = nullptr;
+    if (lh_ctx_create(device_index(), g_stream_for_new_contexts, &h)) return (ml_context*)halt(lh_last_error(nullptr));
+    ml_context* c = new ml_context();
+    c->maxThreads = maxThreads;
+    c->hip = h;
+    return c;
+}
+void ml_ReleaseContext(ml_context* ctx) {  // ml.go:77-80
+    if (!ctx) return;
+    lh_ctx_destroy(ctx->hip);
+    delete ctx;
+}
+
+// ---- tensors ---------------------------------------------------------------------------------------
+ml_tensor* ml_NewTensor1D(ml_context*, int dt, uint32_t ne0) { return new_leaf(dt, 1, ne0, 1, 1); }
+ml_tensor* ml_NewTensor2D(ml_context*, int dt, uint32_t ne0, uint32_t ne1) { return new_leaf(dt, 2, ne0, ne1, 1); }
+ml_tensor* ml_NewTensor3D(ml_context*, int dt, uint32_t ne0, uint32_t ne1, uint32_t ne2) { return new_leaf(dt, 3, ne0, ne1, ne2); }
+ml_tensor* ml_NewFP32(ml_context* ctx, float v) { ml_tensor* t = ml_NewTensor1D(ctx, ML_TYPE_F32, 1); t->data[0] = v; return t; }  // ml.go:915-930
+float* ml_TensorData(ml_tensor* t) { return t->data; }
+void ml_TensorShape(const ml_tensor* t, uint32_t ne[4], uint32_t nb[4]) { for (int i = 0; i < 4; i++) { ne[i] = t->ne[i]; nb[i] = t->nb[i]; } }
+int ml_TensorOp(const ml_tensor* t) { return t->op; }
+uint64_t ml_Nelements(const ml_tensor* t) { return nelements(t); }
+void ml_TensorDirty(ml_tensor* t) { (void)t; /* non-persistent leafs are uploaded on every GraphCompute */ }
+void ml_FreeTensor(ml_tensor* t) { free_tensor(t); }
+
+int ml_TensorRead(ml_context* ctx, ml_tensor* t, float* dst, uint64_t n) {
+    if (t->base->persistent && t->base->buf) {  // weights / KV cache: straight from HBM
+        lh_ctx* h = ctx ? ctx->hip : model_ctx();
+        if (!h) return 1;
+        if (lh_buf_read(h, t->base->buf, t->base_off, dst, n)) return halt_rc(lh_last_error(h));
+        return 0;
+    }
+    if (t->op == ML_OP_NONE && t->data) { memcpy(dst, t->data, n * 4); return 0; }  // plain host leaf
+    if (!ctx || t->last_ctx != ctx || t->last_gen != ctx->generation) return halt_rc("ml_TensorRead: tensor is not part of the last computed graph");
+    if (lh_node_read(ctx->hip, t->last_index, 0, dst, n)) return halt_rc(lh_last_error(ctx->hip));
+    return 0;
+}
+
+// ---- operator constructors (shapes/strides/views exactly as the reference builds them) -------------------
+ml_tensor* ml_Mul(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:241-287
+    if (!same_shape(a, b)) return (ml_tensor*)halt("[STOP] MulImpl - tensors of different shapes!");
+    return node2(dup_tensor(a), ML_OP_MUL, a, b);
+}
+ml_tensor* ml_Add(ml_context*, ml_tensor* a, ml_tensor* b) { return node2(dup_tensor(a), ML_OP_ADD, a, b); }  // ml.go:321-360
+ml_tensor* ml_MulMat(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:295-318
+    ml_tensor* r = new_tensor(ML_TYPE_F32, a->dims < b->dims ? a->dims : b->dims, a->ne[1], b->ne[1], a->ne[2], b->ne[3], nullptr, 0);
+    return node2(r, ML_OP_MUL_MAT, a, b);
+}
+ml_tensor* ml_Repeat(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:487-513
+    if (same_shape(a, b)) return a;
+    return node2(new_tensor(a->type, b->dims, b->ne[0], b->ne[1], b->ne[2], b->ne[3], nullptr, 0), ML_OP_REPEAT, a, b);
+}
+ml_tensor* ml_GetRows(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:528-557
+    return node2(new_tensor(ML_TYPE_F32, 2, a->ne[0], b->ne[0], 1, 1, nullptr, 0), ML_OP_GET_ROWS, a, b);
+}
+ml_tensor* ml_RMSNorm(ml_context*, ml_tensor* a) { return node2(dup_tensor(a), ML_OP_RMS_NORM, a, nullptr); }  // ml.go:559-597
+ml_tensor* ml_View1D(ml_context*, ml_tensor* a, uint32_t ne0, uint32_t offset) {  // ml.go:601-617 (offset in floats)
+    if (a->base_off + (uint64_t)offset + ne0 > nelements(a->base)) return (ml_tensor*)halt("[HALT] View1D : slice bounds out of range");
+    return node2(new_tensor(a->type, 1, ne0, 1, 1, 1, a, offset), ML_OP_VIEW, a, nullptr);
+}
+ml_tensor* ml_Copy(ml_context*, ml_tensor* a, ml_tensor* b) { return node2(view_tensor(b), ML_OP_CPY, a, b); }  // ml.go:700-735
+ml_tensor* ml_Permute(ml_context*, ml_tensor* a, uint32_t ax0, uint32_t ax1, uint32_t ax2, uint32_t ax3) {  // ml.go:786-845
+    if (ax0 > 3 || ax1 > 3 || ax2 > 3 || ax3 > 3) return (ml_tensor*)halt("[STOP] Permute error");
+    ml_tensor* r = view_tensor(a);
+    uint32_t ne[4], nb[4];
+    ne[ax0] = a->ne[0]; ne[ax1] = a->ne[1]; ne[ax2] = a->ne[2]; ne[ax3] = a->ne[3];
+    nb[ax0] = a->nb[0]; nb[ax1] = a->nb[1]; nb[ax2] = a->nb[2]; nb[ax3] = a->nb[3];
+    for (int i = 0; i < 4; i++) { r->ne[i] = ne[i]; r->nb[i] = nb[i]; }
+    return node2(r, ML_OP_PERMUTE, a, nullptr);
+}
+ml_tensor* ml_Rope(ml_context*, ml_tensor* a, uint32_t past, uint32_t dims, uint32_t mode) {  // ml.go:848-880
+    ml_tensor* r = view_tensor(a);
+    ml_tensor* b = new_tensor(ML_TYPE_I32, 1, 3, 1, 1, 1, nullptr, 0);
+    b->data[0] = (float)past; b->data[1] = (float)dims; b->data[2] = (float)mode;
+    return node2(r, ML_OP_ROPE, a, b);
+}
+ml_tensor* ml_Reshape3D(ml_context*, ml_tensor* a, uint32_t ne0, uint32_t ne1, uint32_t ne2) {  // ml.go:882-912
+    return node2(new_tensor(a->type, 3, ne0, ne1, ne2, 1, a, 0), ML_OP_RESHAPE, a, nullptr);
+}
+ml_tensor* ml_Scale(ml_context*, ml_tensor* a, ml_tensor* b) { return node2(view_tensor(a), ML_OP_SCALE, a, b); }  // ml.go:933-961
+ml_tensor* ml_DiagMaskInf(ml_context*, ml_tensor* a, uint32_t past) {  // ml.go:968-990
+    ml_tensor* b = new_tensor(ML_TYPE_F32, 1, 1, 1, 1, 1, nullptr, 0);
+    b->data[0] = (float)past;
+    return node2(view_tensor(a), ML_OP_DIAG_MASK_INF, a, b);
+}
+ml_tensor* ml_SoftMax(ml_context*, ml_tensor* a) { return node2(view_tensor(a), ML_OP_SOFT_MAX, a, nullptr); }  // ml.go:993-1014
+ml_tensor* ml_Silu(ml_context*, ml_tensor* a) { return node2(dup_tensor(a), ML_OP_SILU, a, nullptr); }         // ml.go:1018-1043
+
+// ---- graph  ml.go:619-697 ------------------------------------------------------------------------------
+ml_graph* ml_NewGraph(void) { return new ml_graph(); }
+void ml_FreeGraph(ml_graph* g) {
+    ml_tensor* t = g_gc_head;
+    while (t) { ml_tensor* n = t->gc_next; free_tensor(t); t = n; }
+    g_gc_head = nullptr;
+    delete g;
+}
+static int visit_parents(ml_graph* g, ml_tensor* node) {  // ml.go:647-697
+    for (ml_tensor* t : g->nodes) if (t == node) return 0;
+    for (ml_tensor* t : g->leafs) if (t == node) return 0;
+    if (node->src0 && visit_parents(g, node->src0)) return 1;
+    if (node->src1 && visit_parents(g, node->src1)) return 1;
+    if (node->op == ML_OP_NONE) {
+        if (g->leafs.size() >= MAX_NODES) return halt_rc("[HALT] graph: too many leafs");
+        g->leafs.push_back(node);
+    } else {
+        if (g->nodes.size() >= MAX_NODES) return halt_rc("[HALT] graph: too many nodes");
+        g->nodes.push_back(node);
+    }
+    return 0;
+}
+int ml_BuildForwardExpand(ml_graph* g, ml_tensor* t) {  // ml.go:620-644
+    const size_t n0 = g->nodes.size();
+    if (visit_parents(g, t)) return 1;
+    if (g->nodes.size() > n0 && g->nodes.back() != t) return halt_rc("[STOP] BuildForwardImpl : the last added node should always be starting point!");
+    return 0;
+}
+uint32_t ml_GraphNodesCount(const ml_graph* g) { return (uint32_t)g->nodes.size(); }
+ml_tensor* ml_GraphNode(const ml_graph* g, uint32_t i) { return i < g->nodes.size() ? g->nodes[i] : nullptr; }
+
+// ml.GraphCompute ml.go:1411-1528 -> ONE call across the C-ABI.
+static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
+    g_err.clear();
+    if (!ctx || !ctx->hip) return halt_rc("ml_GraphCompute: no HIP context");
+    // every storage owner must be part of the array the C side sees
+    std::vector<ml_tensor*> leafs = g->leafs;
+    std::unordered_map<const ml_tensor*, int> index;
+    auto collect = [&](const std::vector<ml_tensor*>& v, int base) { for (size_t i = 0; i < v.size(); ++i) index[v[i]] = base + (int)i; };
+    collect(leafs, 0);
+    for (ml_tensor* t : g->nodes) index[t] = -2;
+    auto add_owner = [&](ml_tensor* t) {
+        if (!index.count(t->base)) { index[t->base] = (int)leafs.size(); leafs.push_back(t->base); }
+    };
+    for (ml_tensor* t : g->leafs) add_owner(t);
+    for (ml_tensor* t : g->nodes) add_owner(t);
+    const uint32_t nl = (uint32_t)leafs.size(), nn = (uint32_t)g->nodes.size();
+    collect(leafs, 0);
+    collect(g->nodes, (int)nl);
+    std::vector<lh_tensor> T(nl + nn);
+    ctx->generation++;
+    for (uint32_t i = 0; i < nl + nn; ++i) {
+        ml_tensor* t = i < nl ? leafs[i] : g->nodes[i - nl];
+        lh_tensor& o = T[i];
+        memset(&o, 0, sizeof o);
+        o.op = (uint8_t)t->op;
+        o.dtype = (uint8_t)(t->type == ML_TYPE_I32 ? ML_TYPE_F32 : t->type);  // "I32" parameter tensors hold fp32 (ml.go:864-867)
+        for (int k = 0; k < 4; ++k) { o.ne[k] = t->ne[k]; o.nb[k] = t->nb[k]; }
+        o.src0 = t->src0 ? index[t->src0] : -1;
+        o.src1 = t->src1 ? index[t->src1] : -1;
+        o.storage = index[t->base];
+        o.view_off = t->base_off;
+        if (t->base == t) {
+            o.buf = t->persistent ? t->buf : 0;
+            o.host = (t->op == ML_OP_NONE && !t->persistent) ? t->data : nullptr;
+        }
+        t->last_ctx = ctx;
+        t->last_gen = ctx->generation;
+        t->last_index = i;
+    }
+    if (lh_graph_compute(ctx->hip, T.data(), nl, nn, flags)) return halt_rc(lh_last_error(ctx->hip));
+    return 0;
+}
+int ml_GraphCompute(ml_context* ctx, ml_graph* g) {
+    const char* e = getenv("LLAMAGO_NO_FUSION");  // debugging aid: force the node-by-node path
+    return graph_compute(ctx, g, (e && e[0] == '1') ? LH_GRAPH_NO_FUSION : 0);
+}
+// product extensions (not in the reference): node-by-node execution, and which path the last graph took
+int llamago_GraphComputeNoFusion(ml_context* ctx, ml_graph* g) { return graph_compute(ctx, g, LH_GRAPH_NO_FUSION); }
+int llamago_LastGraphFused(ml_context* ctx) { return ctx && ctx->hip ? lh_last_graph_fused(ctx->hip) : 0; }
+void llamago_SetStream(void* hip_stream) { g_stream_for_new_contexts = hip_stream; }
+int llamago_DeviceCount(void) { return lh_device_count(); }
+
+}  // extern "C"
+
+// ======================================================================================================
+// pkg/llama
+// ======================================================================================================
+struct llama_layer { ml_tensor *attentionNorm, *wq, *wk, *wv, *wo, *ffn_norm, *w1, *w2, *w3; };  // llama.go:128-146
+struct llama_model {  // llama.go:181-193
+    llama_hparams hp;
+    uint32_t ffSize;
+    ml_tensor *tokEmbeddings = nullptr, *norm = nullptr, *output = nullptr;
+    std::vector<llama_layer> layers;
+    uint32_t layer0, layer1;
+};
+struct llama_context {  // llama.go:83-88
+    ml_tensor *K, *V;
+    std::vector<float> logits;
+    ml_context* mlctx;
+    llama_model* model;
+    uint32_t ctxSize;
+    lh_llama* resident = nullptr;  // plan handle for the device-resident loop / stages (created on demand)
+};
+
+static uint32_t ff_size(uint32_t embd, uint32_t mult) { return ((2 * (4 * embd) / 3 + mult - 1) / mult) * mult; }  // llama.go:761
+
+// persistent device tensor without a host copy
+static ml_tensor* new_weight(uint32_t dims, uint32_t ne0, uint32_t ne1) {
+    lh_ctx* h = model_ctx();
+    if (!h) return nullptr;
+    ml_tensor* t = new_leaf(ML_TYPE_F32, dims, ne0, ne1, 1, /*alloc_host=*/false);
+    t->persistent = true;
+    const uint32_t ne[4] = {ne0, ne1, 1, 1};
+    if (lh_tensor_register(h, 0, 0, ne, 1, nullptr, &t->buf)) { g_err = lh_last_error(h); delete t; return nullptr; }
+    return t;
+}
+
+static llama_model* alloc_model(const llama_hparams* hp, uint32_t layer0, uint32_t layer1) {  // llama.go:819-863
+    llama_model* m = new llama_model();
+    m->hp = *hp;
+    m->ffSize = ff_size(hp->embdSize, hp->multSize);
+    if (layer1 == 0 || layer1 > hp->layersCount) layer1 = hp->layersCount;
+    m->layer0 = layer0; m->layer1 = layer1;
+    const uint32_t d = hp->embdSize, V = hp->vocabSize, F = m->ffSize;
+    bool ok = true;
+    if (layer0 == 0) ok &= (m->tokEmbeddings = new_weight(2, d, V)) != nullptr;
+    if (layer1 == hp->layersCount) {
+        ok &= (m->norm = new_weight(1, d, 1)) != nullptr;
+        ok &= (m->output = new_weight(2, d, V)) != nullptr;
+    }
+    m->layers.assign(hp->layersCount, llama_layer{});
+    for (uint32_t i = layer0; i < layer1 && ok; i++) {
+        llama_layer& l = m->layers[i];
+        ok &= (l.attentionNorm = new_weight(1, d, 1)) != nullptr;
+        ok &= (l.wq = new_weight(2, d, d)) != nullptr;
+        ok &= (l.wk = new_weight(2, d, d)) != nullptr;
+        ok &= (l.wv = new_weight(2, d, d)) != nullptr;
+        ok &= (l.wo = new_weight(2, d, d)) != nullptr;
+        ok &= (l.ffn_norm = new_weight(1, d, 1)) != nullptr;
+        ok &= (l.w1 = new_weight(2, d, F)) != nullptr;
+        ok &= (l.w2 = new_weight(2, F, d)) != nullptr;
+        ok &= (l.w3 = new_weight(2, d, F)) != nullptr;
+    }
+    if (!ok) { llama_FreeModel(m); return nullptr; }
+    return m;
+}
+
+enum { TID_TOK = 0, TID_NORM = 1, TID_OUT = 2, TID_LAYER0 = 16, TID_PER_LAYER = 16 };
+
+static int fill(ml_tensor* t, uint64_t seed, uint32_t tid, float scale, float offset) {
+    if (!t) return 0;
+    lh_ctx* h = model_ctx();
+    if (lh_buf_fill_synth(h, t->buf, 0, nelements(t), seed, tid, scale, offset)) return halt_rc(lh_last_error(h));
+    return 0;
+}
+
+extern "C" {
+
+ml_tensor* llama_ModelTensor(llama_model* m, const char* name) {  // model.tensors llama.go:826-861
+    if (!strcmp(name, "tok_embeddings.weight")) return m->tokEmbeddings;
+    if (!strcmp(name, "norm.weight")) return m->norm;
+    if (!strcmp(name, "output.weight")) return m->output;
+    unsigned i;
+    char rest[64];
+    if (sscanf(name, "layers.%u.%63s", &i, rest) == 2 && i < m->hp.layersCount) {
+        llama_layer& l = m->layers[i];
+        if (!strcmp(rest, "attention_norm.weight")) return l.attentionNorm;
+        if (!strcmp(rest, "attention.wq.weight")) return l.wq;
+        if (!strcmp(rest, "attention.wk.weight")) return l.wk;
+        if (!strcmp(rest, "attention.wv.weight")) return l.wv;
+        if (!strcmp(rest, "attention.wo.weight")) return l.wo;
+        if (!strcmp(rest, "ffn_norm.weight")) return l.ffn_norm;
+        if (!strcmp(rest, "feed_forward.w1.weight")) return l.w1;
+        if (!strcmp(rest, "feed_forward.w2.weight")) return l.w2;
+        if (!strcmp(rest, "feed_forward.w3.weight")) return l.w3;
+    }
+    return nullptr;
+}
+
+llama_model* llama_NewSyntheticModel(const llama_hparams* hp, uint64_t seed, uint32_t layer0, uint32_t layer1) {
+    llama_model* m = alloc_model(hp, layer0, layer1);
+    if (!m) return nullptr;
+    const uint32_t d = hp->embdSize, F = m->ffSize;
+    const float a_d = (float)sqrt(3.0 / (double)d), a_f = (float)sqrt(3.0 / (double)F);
+    int rc = 0;
+    rc |= fill(m->tokEmbeddings, seed, TID_TOK, (float)sqrt(3.0), 0.0f);
+    rc |= fill(m->norm, seed, TID_NORM, 0.1f, 1.0f);
+    rc |= fill(m->output, seed, TID_OUT, a_d, 0.0f);
+    for (uint32_t i = m->layer0; i < m->layer1; i++) {
+        llama_layer& l = m->layers[i];
+        const uint32_t t = TID_LAYER0 + i * TID_PER_LAYER;
+        rc |= fill(l.attentionNorm, seed, t + 0, 0.1f, 1.0f);
+        rc |= fill(l.wq, seed, t + 1, a_d, 0.0f);
+        rc |= fill(l.wk, seed, t + 2, a_d, 0.0f);
+        rc |= fill(l.wv, seed, t + 3, a_d, 0.0f);
+        rc |= fill(l.wo, seed, t + 4, a_d, 0.0f);
+        rc |= fill(l.ffn_norm, seed, t + 5, 0.1f, 1.0f);
+        rc |= fill(l.w1, seed, t + 6, a_d, 0.0f);
+        rc |= fill(l.w2, seed, t + 7, a_f, 0.0f);
+        rc |= fill(l.w3, seed, t + 8, a_d, 0.0f);
+    }
+    if (rc || lh_ctx_sync(model_ctx())) { llama_FreeModel(m); return nullptr; }
+    return m;
+}
+
+void llama_FreeModel(llama_model* m) {
+    if (!m) return;
+    free_tensor(m->tokEmbeddings); free_tensor(m->norm); free_tensor(m->output);
+    for (llama_layer& l : m->layers) {
+        free_tensor(l.attentionNorm); free_tensor(l.wq); free_tensor(l.wk); free_tensor(l.wv); free_tensor(l.wo);
+        free_tensor(l.ffn_norm); free_tensor(l.w1); free_tensor(l.w2); free_tensor(l.w3);
+    }
+    delete m;
+}
+void llama_ModelHParams(const llama_model* m, llama_hparams* out) { *out = m->hp; }
+uint32_t llama_ModelFFSize(const llama_model* m) { return m->ffSize; }
+
+// ---- ggjt v1 loader (llama.go:712-976): every tensor goes file -> bounce buffer -> HBM, no Go-heap-style copy kept
+static float f16_to_f32(uint16_t h) {  // x448/float16 Float32() (llama.go:1005-1013): exact widening
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 0x1F;
+    uint32_t man = h & 0x3FF, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else { int e = -1; do { e++; man <<= 1; } while (!(man & 0x400)); bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FF) << 13); }
+    } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+static uint16_t f32_to_f16(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000;
+    const int32_t exp = (int32_t)((x >> 23) & 0xFF) - 127 + 15;
+    uint32_t man = x & 0x7FFFFF;
+    if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00 | (man ? 0x200 : 0));
+    if (exp >= 31) return (uint16_t)(sign | 0x7C00);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000;
+        const uint32_t shift = (uint32_t)(14 - exp);
+        uint32_t hm = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    const uint32_t hm = man >> 13, rem = man & 0x1FFF;
+    uint16_t out = (uint16_t)(sign | ((uint32_t)exp << 10) | hm);
+    if (rem > 0x1000 || (rem == 0x1000 && (hm & 1))) out++;
+    return out;
+}
+static uint32_t rd_u32(FILE* f) { unsigned char b[4]; if (fread(b, 1, 4, f) != 4) return 0; return (uint32_t)b[3] << 24 | (uint32_t)b[2] << 16 | (uint32_t)b[1] << 8 | b[0]; }
+static const uint32_t LLAMA_FILE_MAGIC = 0x67676a74u;
+
+llama_model* llama_LoadModel(const char* fileName, uint32_t ctxSize) {
+    FILE* f = fopen(fileName, "rb");
+    if (!f) return (llama_model*)halt("[ERROR] cannot open model file");
+    if (rd_u32(f) != LLAMA_FILE_MAGIC) { fclose(f); return (llama_model*)halt("[ERROR] Invalid model file! Wrong MAGIC in header"); }  // llama.go:722-732
+    if (rd_u32(f) != 1) { fclose(f); return (llama_model*)halt("[ERROR] Invalid model file! Unsupported version"); }                     // llama.go:734-739
+    llama_hparams hp;
+    memset(&hp, 0, sizeof hp);
+    hp.ctxSize = ctxSize;
+    hp.vocabSize = rd_u32(f); hp.embdSize = rd_u32(f); hp.multSize = rd_u32(f); hp.headsCount = rd_u32(f);
+    hp.layersCount = rd_u32(f); hp.rotCount = rd_u32(f); hp.f16 = rd_u32(f);  // llama.go:743-749
+    if (!hp.vocabSize || !hp.embdSize || !hp.headsCount || !hp.layersCount || !hp.multSize) { fclose(f); return (llama_model*)halt("[ERROR] Invalid model file! Bad hyper-parameters"); }
+    for (uint32_t i = 0; i < hp.vocabSize; i++) { const uint32_t len = rd_u32(f); fseek(f, (long)len + 4, SEEK_CUR); }  // vocab llama.go:799-811 (not on the hot path)
+    llama_model* m = alloc_model(&hp, 0, 0);
+    if (!m) { fclose(f); return nullptr; }
+    lh_ctx* h = model_ctx();
+    std::vector<float> bounce;
+    std::vector<uint16_t> half;
+    for (;;) {  // llama.go:889-969
+        const uint32_t dims = rd_u32(f);
+        if (dims < 1 || dims > 2) break;
+        const uint32_t nameLen = rd_u32(f), dtype = rd_u32(f);
+        uint32_t ne[2] = {1, 1};
+        for (uint32_t i = 0; i < dims; i++) ne[i] = rd_u32(f);
+        (void)ne;
+        char name[256];
+        if (nameLen >= sizeof name || fread(name, 1, nameLen, f) != nameLen) { fclose(f); llama_FreeModel(m); return (llama_model*)halt("[ERROR] bad tensor name in model file"); }
+        name[nameLen] = 0;
+        ml_tensor* t = llama_ModelTensor(m, name);
+        if (!t) { fclose(f); llama_FreeModel(m); return (llama_model*)halt("[ERROR] Unknown tensor in model file"); }
+        long off = ftell(f);
+        off = (off + 31) & ~31L;  // 32-byte alignment llama.go:926-933
+        fseek(f, off, SEEK_SET);
+        const uint64_t n = nelements(t);
+        bounce.resize(n);
+        if (dtype == ML_TYPE_F16) {  // widened to f32 at load, llama.go:938-941
+            half.resize(n);
+            if (fread(half.data(), 2, n, f) != n) { fclose(f); llama_FreeModel(m); return (llama_model*)halt("[ERROR] Failed to read FP16 tensor from model!"); }
+            for (uint64_t i = 0; i < n; i++) bounce[i] = f16_to_f32(half[i]);
+        } else if (dtype == ML_TYPE_F32) {
+            if (fread(bounce.data(), 4, n, f) != n) { fclose(f); llama_FreeModel(m); return (llama_model*)halt("[ERROR] Failed to read BIG FP32 chunk from model!"); }
+        } else { fclose(f); llama_FreeModel(m); return (llama_model*)halt("[ERROR] Tensor data type is not supported yet!"); }  // llama.go:956-959
+        if (lh_buf_upload(h, t->buf, 0, bounce.data(), n)) { g_err = lh_last_error(h); fclose(f); llama_FreeModel(m); return nullptr; }
+    }
+    fclose(f);
+    return m;
+}
+
+static void wr_u32(FILE* f, uint32_t v) { unsigned char b[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)}; fwrite(b, 1, 4, f); }
+static int wr_tensor(FILE* f, const char* name, ml_tensor* t, int ftype) {  // scripts/convert-pth-to-ggml.py:196-232
+    const uint32_t dims = t->dims;
+    const bool as16 = ftype == 1 && dims == 2;
+    wr_u32(f, dims); wr_u32(f, (uint32_t)strlen(name)); wr_u32(f, as16 ? 1u : 0u);
+    for (uint32_t i = 0; i < dims; i++) wr_u32(f, t->ne[i]);
+    fwrite(name, 1, strlen(name), f);
+    long off = ftell(f);
+    while (off % 32) { fputc(0, f); off++; }
+    const uint64_t n = nelements(t);
+    std::vector<float> host(n);
+    if (ml_TensorRead(nullptr, t, host.data(), n)) return 1;
+    if (as16) { std::vector<uint16_t> hh(n); for (uint64_t i = 0; i < n; i++) hh[i] = f32_to_f16(host[i]); fwrite(hh.data(), 2, n, f); }
+    else fwrite(host.data(), 4, n, f);
+    return 0;
+}
+int llama_SaveModel(const llama_model* mc, const char* fileName, int ftype) {
+    llama_model* m = (llama_model*)mc;
+    if (m->layer0 != 0 || m->layer1 != m->hp.layersCount) return halt_rc("llama_SaveModel: partial (layer-sharded) model");
+    FILE* f = fopen(fileName, "wb");
+    if (!f) return halt_rc("llama_SaveModel: cannot open file");
+    wr_u32(f, LLAMA_FILE_MAGIC); wr_u32(f, 1);
+    wr_u32(f, m->hp.vocabSize); wr_u32(f, m->hp.embdSize); wr_u32(f, m->hp.multSize); wr_u32(f, m->hp.headsCount);
+    wr_u32(f, m->hp.layersCount); wr_u32(f, m->hp.embdSize / m->hp.headsCount); wr_u32(f, (uint32_t)ftype);
+    for (uint32_t i = 0; i < m->hp.vocabSize; i++) { char tok[16]; const int len = snprintf(tok, sizeof tok, "<%u>", i); wr_u32(f, (uint32_t)len); fwrite(tok, 1, (size_t)len, f); const float s = -(float)i; fwrite(&s, 4, 1, f); }
+    int rc = 0;
+    rc |= wr_tensor(f, "tok_embeddings.weight", m->tokEmbeddings, ftype);
+    rc |= wr_tensor(f, "norm.weight", m->norm, ftype);
+    rc |= wr_tensor(f, "output.weight", m->output, ftype);
+    static const char* names[9] = {"attention_norm.weight", "attention.wq.weight", "attention.wk.weight", "attention.wv.weight", "attention.wo.weight",
+                                   "ffn_norm.weight", "feed_forward.w1.weight", "feed_forward.w2.weight", "feed_forward.w3.weight"};
+    for (uint32_t i = 0; i < m->hp.layersCount && !rc; i++) {
+        llama_layer& l = m->layers[i];
+        ml_tensor* ts[9] = {l.attentionNorm, l.wq, l.wk, l.wv, l.wo, l.ffn_norm, l.w1, l.w2, l.w3};
+        for (int k = 0; k < 9 && !rc; k++) { char nm[96]; snprintf(nm, sizeof nm, "layers.%u.%s", i, names[k]); rc |= wr_tensor(f, nm, ts[k], ftype); }
+    }
+    fclose(f);
+    return rc;
+}
+
+// ---- context + Eval -----------------------------------------------------------------------------------
+llama_context* llama_NewContext(llama_model* m, uint32_t ctxSize, int maxThreads, int useAVX, int useNEON) {  // llama.go:91-103
+    g_err.clear();
+    const uint64_t nlayers = m->layer1 - m->layer0;
+    const uint64_t size = (uint64_t)m->hp.embdSize * nlayers * ctxSize;
+    if (size > 0xFFFFFFFFull) return (llama_context*)halt("[HALT] KV cache exceeds uint32 element count (ml.Tensor.NE is uint32)");
+    ml_context* mc = ml_NewContext(maxThreads, useAVX, useNEON);
+    if (!mc) return nullptr;
+    llama_context* c = new llama_context();
+    c->model = m;
+    c->ctxSize = ctxSize;
+    m->hp.ctxSize = ctxSize;
+    c->mlctx = mc;
+    c->K = new_weight(1, (uint32_t)size, 1);  // zero-filled like Go's make([]float32)
+    c->V = new_weight(1, (uint32_t)size, 1);
+    if (!c->K || !c->V) { llama_ReleaseContext(c); return nullptr; }
+    c->logits.assign(m->hp.vocabSize, 0.f);
+    return c;
+}
+void llama_ReleaseContext(llama_context* c) {  // llama.go:105-113
+    if (!c) return;
+    if (c->resident) lh_llama_destroy(c->resident);
+    if (c->mlctx) lh_ctx_sync(c->mlctx->hip);
+    free_tensor(c->K); free_tensor(c->V);
+    ml_ReleaseContext(c->mlctx);
+    delete c;
+}
+const float* llama_Logits(const llama_context* c) { return c->logits.data(); }
+ml_context* llama_MLContext(llama_context* c) { return c->mlctx; }
+
+int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, uint32_t N, uint32_t pastCount) {  // llama.go:211-426
+    if (model->layer0 != 0 || model->layer1 != model->hp.layersCount) return halt_rc("llama_Eval: layer-sharded model, use llamago_Stage");
+    const uint32_t embdSize = model->hp.embdSize, layersCount = model->hp.layersCount, ctxSize = lctx->ctxSize;
+    const uint32_t headsCount = model->hp.headsCount, vocabSize = model->hp.vocabSize, rotCount = embdSize / headsCount;
+    if (N == 0 || (uint64_t)pastCount + N > ctxSize) return halt_rc("llama_Eval: token window outside the context (the reference would index past the KV slice, llama.go:274)");
+    ml_context* ctx0 = lctx->mlctx;
+    ml_graph* graph = ml_NewGraph();
+    int rc = 1;
+    const bool save = g_gc_enabled;
+    g_gc_enabled = true;
+    ml_tensor* inpL = nullptr;
+    do {
+        ml_tensor* embd = new_tensor(ML_TYPE_F32, 1, N, 1, 1, 1, nullptr, 0);  // :239-242 token ids as fp32
+        for (uint32_t i = 0; i < N; i++) embd->data[i] = (float)tokens[i];
+        inpL = ml_GetRows(ctx0, model->tokEmbeddings, embd);                     // :244
+        bool fail = false;
+        for (uint32_t il = 0; il < layersCount && !fail; il++) {
+            llama_layer& L = model->layers[il];
+            ml_tensor* inpSA = inpL;
+            ml_tensor* cur = ml_RMSNorm(ctx0, inpL);                              // :255
+            cur = ml_Mul(ctx0, ml_Repeat(ctx0, L.attentionNorm, cur), cur);       // :258-259
+            ml_tensor* Qcur = ml_MulMat(ctx0, L.wq, cur);                         // :263-265
+            ml_tensor* Kcur = ml_MulMat(ctx0, L.wk, cur);
+            ml_tensor* Vcur = ml_MulMat(ctx0, L.wv, cur);
+            {                                                                     // :268-279
+                ml_tensor* k = ml_View1D(ctx0, lctx->K, N * embdSize, embdSize * (il * ctxSize + pastCount));
+                ml_tensor* v = ml_View1D(ctx0, lctx->V, N * embdSize, embdSize * (il * ctxSize + pastCount));
+                if (!k || !v) { fail = true; break; }
+                if (ml_BuildForwardExpand(graph, ml_Copy(ctx0, Kcur, k)) || ml_BuildForwardExpand(graph, ml_Copy(ctx0, Vcur, v))) { fail = true; break; }
+            }
+            ml_tensor* Q = ml_Permute(ctx0,                                       // :281-288
+                ml_Rope(ctx0, ml_Copy(ctx0, Qcur, new_tensor(ML_TYPE_F32, 3, embdSize / headsCount, headsCount, N, 1, nullptr, 0)), pastCount, rotCount, 0),
+                0, 2, 1, 3);
+            ml_tensor* K = ml_Permute(ctx0,                                       // :290-297
+                ml_Rope(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, lctx->K, (pastCount + N) * embdSize, il * ctxSize * embdSize),
+                                           embdSize / headsCount, headsCount, pastCount + N), pastCount, rotCount, 1),
+                0, 2, 1, 3);
+            ml_tensor* KQ = ml_MulMat(ctx0, K, Q);                                // :300
+            ml_tensor* sc = new_tensor(ML_TYPE_F32, 1, 1, 1, 1, 1, nullptr, 0);   // :303-307
+            sc->data[0] = (float)(1.0 / sqrt((double)embdSize / (double)headsCount));
+            ml_tensor* KQScaled = ml_Scale(ctx0, KQ, sc);
+            ml_tensor* KQMasked = ml_DiagMaskInf(ctx0, KQScaled, pastCount);      // :310
+            ml_tensor* KQSoftMax = ml_SoftMax(ctx0, KQMasked);                    // :313
+            ml_tensor* VTrans = ml_Copy(ctx0,                                     // :315-322
+                ml_Permute(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, lctx->V, (pastCount + N) * embdSize, il * ctxSize * embdSize),
+                                              embdSize / headsCount, headsCount, pastCount + N), 1, 2, 0, 3),
+                new_tensor(ML_TYPE_F32, 3, pastCount + N, embdSize / headsCount, headsCount, 1, nullptr, 0));
+            ml_tensor* KQV = ml_MulMat(ctx0, VTrans, KQSoftMax);                  // :325
+            ml_tensor* KQVMerged = ml_Permute(ctx0, KQV, 0, 2, 1, 3);             // :328
+            cur = ml_Copy(ctx0, KQVMerged, new_tensor(ML_TYPE_F32, 2, embdSize, N, 1, 1, nullptr, 0));  // :331-333
+            cur = ml_MulMat(ctx0, L.wo, cur);                                     // :336
+            ml_tensor* inpFF = ml_Add(ctx0, cur, inpSA);                          // :340
+            cur = ml_RMSNorm(ctx0, inpFF);                                        // :346
+            cur = ml_Mul(ctx0, ml_Repeat(ctx0, L.ffn_norm, cur), cur);            // :349-351
+            ml_tensor* tmp = ml_MulMat(ctx0, L.w3, cur);                          // :354
+            cur = ml_MulMat(ctx0, L.w1, cur);                                     // :356
+            cur = ml_Silu(ctx0, cur);                                             // :359
+            cur = ml_Mul(ctx0, cur, tmp);                                         // :361
+            cur = ml_MulMat(ctx0, L.w2, cur);                                     // :363
+            cur = ml_Add(ctx0, cur, inpFF);                                       // :366
+            inpL = cur;
+        }
+        if (fail) break;
+        inpL = ml_RMSNorm(ctx0, inpL);                                            // :374
+        inpL = ml_Mul(ctx0, ml_Repeat(ctx0, model->norm, inpL), inpL);            // :377-379
+        inpL = ml_MulMat(ctx0, model->output, inpL);                              // :384
+        if (ml_BuildForwardExpand(graph, inpL)) break;                            // :387
+        if (ml_GraphCompute(ctx0, graph)) break;                                  // :389
+        // :394-401 — only the last token's logits are copied out
+        if (lh_node_read(ctx0->hip, inpL->last_index, (uint64_t)vocabSize * (N - 1), lctx->logits.data(), vocabSize)) { g_err = lh_last_error(ctx0->hip); break; }
+        rc = 0;
+    } while (0);
+    ml_FreeGraph(graph);
+    g_gc_enabled = save;
+    return rc;
+}
+
+static uint32_t argmax_f32(const float* x, uint32_t n) {  // strict >, lowest index wins ties
+    uint32_t best = 0;
+    for (uint32_t i = 1; i < n; i++) if (x[i] > x[best]) best = i;
+    return best;
+}
+int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t* out_tokens,
+                       float* step_logits) {  // loop shape of server.Do, server.go:153-217
+    uint32_t past = 0;
+    const uint32_t V = m->hp.vocabSize;
+    if (llama_Eval(lctx, m, prompt, n_prompt, past)) return 1;
+    past += n_prompt;
+    for (uint32_t s = 0; s < n_predict; s++) {
+        const uint32_t id = argmax_f32(lctx->logits.data(), V);
+        out_tokens[s] = id;
+        if (step_logits) memcpy(step_logits + (uint64_t)s * V, lctx->logits.data(), (size_t)V * 4);
+        if (s + 1 == n_predict) break;
+        if (llama_Eval(lctx, m, &id, 1, past)) return 1;
+        past += 1;
+    }
+    return 0;
+}
+
+// ---- product extensions: device-resident decode loop, kernel timing, pipeline stage -----------------------
+static lh_llama* resident(llama_context* c) {
+    if (c->resident) return c->resident;
+    llama_model* m = c->model;
+    std::vector<lh_llama_layer> ls(m->hp.layersCount);
+    for (uint32_t i = m->layer0; i < m->layer1; i++) {
+        llama_layer& l = m->layers[i];
+        ls[i] = lh_llama_layer{l.attentionNorm->buf, l.wq->buf, l.wk->buf, l.wv->buf, l.wo->buf, l.ffn_norm->buf, l.w1->buf, l.w2->buf, l.w3->buf};
+    }
+    lh_llama_desc d;
+    memset(&d, 0, sizeof d);
+    d.vocab = m->hp.vocabSize; d.embd = m->hp.embdSize; d.heads = m->hp.headsCount; d.layers = m->hp.layersCount; d.ff = m->ffSize; d.ctx = c->ctxSize;
+    d.layer0 = m->layer0; d.layer1 = m->layer1;
+    d.tok_embeddings = m->tokEmbeddings ? m->tokEmbeddings->buf : 0;
+    d.norm = m->norm ? m->norm->buf : 0;
+    d.output = m->output ? m->output->buf : 0;
+    d.layer = ls.data();
+    d.k_cache = c->K->buf; d.v_cache = c->V->buf;
+    if (lh_llama_create(c->mlctx->hip, &d, &c->resident)) { g_err = lh_last_error(c->mlctx->hip); return nullptr; }
+    return c->resident;
+}
+int llamago_DecodeGreedyResident(llama_context* c, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last) {
+    lh_llama* r = resident(c);
+    if (!r) return 1;
+    if (lh_llama_decode_greedy(r, first_token, past, n_steps, out_tokens, logits_last)) return halt_rc(lh_last_error(c->mlctx->hip));
+    return 0;
+}
+int llamago_ProfileDecode(llama_context* c, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap) {
+    lh_llama* r = resident(c);
+    if (!r) return -1;
+    const int n = lh_llama_profile_decode(r, token, past, repeats, out, cap);
+    if (n < 0) g_err = lh_last_error(c->mlctx->hip);
+    return n;
+}
+int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_dev, const void* x_in_dev, void* x_out_dev, uint32_t n, uint32_t past,
+                  void* logits_dev, void* argmax_dev) {
+    lh_llama* r = resident(c);
+    if (!r) return 1;
+    if (lh_llama_stage(r, tokens, (const uint32_t*)tokens_dev, (const float*)x_in_dev, (float*)x_out_dev, n, past, (float*)logits_dev, (uint32_t*)argmax_dev))
+        return halt_rc(lh_last_error(c->mlctx->hip));
+    return 0;
+}
+int llamago_Sync(llama_context* c) { return lh_ctx_sync(c->mlctx->hip) ? halt_rc(lh_last_error(c->mlctx->hip)) : 0; }
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+"""ctypes binding of include/llamago.h — the host-side mirror of the reference's pkg/ml + pkg/llama API.
+
+`MLLib(path)` wraps any shared library exporting that API.  The product instance comes from
+`load_product()` (libllamago.so -> libllamahip.so -> MI355X) and raises if the HIP library is absent;
+the test-suite wraps its CPU checker library with the same class.  Method names are the Go
+names (ml.MulMat -> MLLib.MulMat, llama.Eval -> Model/Context.Eval).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+c_u32 = C.c_uint32
+c_u64 = C.c_uint64
+c_f32p = C.POINTER(C.c_float)
+c_u32p = C.POINTER(c_u32)
+VP = C.c_void_p
+
+
+class HParams(C.Structure):
+    """llama.HParams (llama.go:149-158)."""
+    _fields_ = [(n, c_u32) for n in ("ctxSize", "vocabSize", "embdSize", "multSize", "headsCount", "layersCount", "rotCount", "f16")]
+
+
+# dtype / op numeric values (ml.go:85-94, 133-174)
+TYPE_F32, TYPE_F16, TYPE_I32 = 0, 1, 6
+OP_NAMES = ["NONE", "DUP", "ADD", "SUB", "MUL", "DIV", "SQR", "SQRT", "SUM", "MEAN", "REPEAT", "ABS", "SGN", "NEG", "STEP",
+            "RELU", "GELU", "SILU", "NORM", "RMS_NORM", "MUL_MAT", "SCALE", "CPY", "RESHAPE", "VIEW", "PERMUTE", "TRANSPOSE",
+            "GET_ROWS", "DIAG_MASK_INF", "SOFT_MAX", "ROPE", "CONV_1D_1S", "CONV_1D_2S", "FLASH_ATTN", "FLASH_FF"]
+
+
+class MLError(RuntimeError):
+    pass
+
+
+class MLLib:
+    def __init__(self, path, mode=C.RTLD_LOCAL):
+        if not os.path.exists(path):
+            raise MLError(f"shared library not found: {path} (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        self.path = path
+        self.lib = L = C.CDLL(path, mode=mode)
+
+        def sig(name, res, *args):
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = list(args)
+            return fn
+
+        sig("ml_NewContext", VP, C.c_int, C.c_int, C.c_int)
+        sig("ml_ReleaseContext", None, VP)
+        sig("ml_LastError", C.c_char_p)
+        sig("ml_NewTensor1D", VP, VP, C.c_int, c_u32)
+        sig("ml_NewTensor2D", VP, VP, C.c_int, c_u32, c_u32)
+        sig("ml_NewTensor3D", VP, VP, C.c_int, c_u32, c_u32, c_u32)
+        sig("ml_NewFP32", VP, VP, C.c_float)
+        sig("ml_TensorData", c_f32p, VP)
+        sig("ml_TensorShape", None, VP, c_u32p, c_u32p)
+        sig("ml_TensorOp", C.c_int, VP)
+        sig("ml_Nelements", c_u64, VP)
+        sig("ml_TensorRead", C.c_int, VP, VP, c_f32p, c_u64)
+        sig("ml_TensorDirty", None, VP)
+        sig("ml_FreeTensor", None, VP)
+        for name in ("ml_Add", "ml_Mul", "ml_MulMat", "ml_Repeat", "ml_GetRows", "ml_Copy", "ml_Scale"):
+            sig(name, VP, VP, VP, VP)
+        for name in ("ml_RMSNorm", "ml_SoftMax", "ml_Silu"):
+            sig(name, VP, VP, VP)
+        sig("ml_View1D", VP, VP, VP, c_u32, c_u32)
+        sig("ml_Permute", VP, VP, VP, c_u32, c_u32, c_u32, c_u32)
+        sig("ml_Rope", VP, VP, VP, c_u32, c_u32, c_u32)
+        sig("ml_Reshape3D", VP, VP, VP, c_u32, c_u32, c_u32)
+        sig("ml_DiagMaskInf", VP, VP, VP, c_u32)
+        sig("ml_NewGraph", VP)
+        sig("ml_FreeGraph", None, VP)
+        sig("ml_BuildForwardExpand", C.c_int, VP, VP)
+        sig("ml_GraphNodesCount", c_u32, VP)
+        sig("ml_GraphNode", VP, VP, c_u32)
+        sig("ml_GraphCompute", C.c_int, VP, VP)
+        sig("llama_LoadModel", VP, C.c_char_p, c_u32)
+        sig("llama_NewSyntheticModel", VP, C.POINTER(HParams), c_u64, c_u32, c_u32)
+        sig("llama_SaveModel", C.c_int, VP, C.c_char_p, C.c_int)
+        sig("llama_FreeModel", None, VP)
+        sig("llama_ModelHParams", None, VP, C.POINTER(HParams))
+        sig("llama_ModelFFSize", c_u32, VP)
+        sig("llama_ModelTensor", VP, VP, C.c_char_p)
+        sig("llama_NewContext", VP, VP, c_u32, C.c_int, C.c_int, C.c_int)
+        sig("llama_ReleaseContext", None, VP)
+        sig("llama_Eval", C.c_int, VP, VP, c_u32p, c_u32, c_u32)
+        sig("llama_Logits", c_f32p, VP)
+        sig("llama_MLContext", VP, VP)
+        sig("llama_GreedyDecode", C.c_int, VP, VP, c_u32p, c_u32, c_u32, c_u32p, c_f32p)
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def last_error(self):
+        return (self.lib.ml_LastError() or b"").decode()
+
+    def _chk(self, handle, what):
+        if not handle:
+            raise MLError(f"{what}: {self.last_error()}")
+        return handle
+
+    # ---- ml.* ------------------------------------------------------------------------------------
+    def NewContext(self, maxThreads=1, useAVX=False, useNEON=False):
+        return self._chk(self.lib.ml_NewContext(maxThreads, int(useAVX), int(useNEON)), "ml_NewContext")
+
+    def ReleaseContext(self, ctx):
+        self.lib.ml_ReleaseContext(ctx)
+
+    def NewTensor(self, ctx, ne, dt=TYPE_F32, data=None):
+        ne = tuple(int(x) for x in ne)
+        if len(ne) == 1:
+            t = self.lib.ml_NewTensor1D(ctx, dt, ne[0])
+        elif len(ne) == 2:
+            t = self.lib.ml_NewTensor2D(ctx, dt, ne[0], ne[1])
+        elif len(ne) == 3:
+            t = self.lib.ml_NewTensor3D(ctx, dt, ne[0], ne[1], ne[2])
+        else:
+            raise ValueError("1..3 dims")
+        self._chk(t, "ml_NewTensor")
+        if data is not None:
+            self.set_data(t, data)
+        return t
+
+    def NewFP32(self, ctx, v):
+        return self._chk(self.lib.ml_NewFP32(ctx, float(v)), "ml_NewFP32")
+
+    def data(self, t):
+        """Host view of Tensor.Data as a flat numpy array (no copy)."""
+        n = self.lib.ml_Nelements(t)
+        return np.ctypeslib.as_array(self.lib.ml_TensorData(t), shape=(n,))
+
+    def set_data(self, t, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+        d = self.data(t)
+        assert a.size == d.size, (a.size, d.size)
+        d[:] = a
+        self.lib.ml_TensorDirty(t)
+
+    def shape(self, t):
+        ne = (c_u32 * 4)()
+        nb = (c_u32 * 4)()
+        self.lib.ml_TensorShape(t, ne, nb)
+        return tuple(ne), tuple(nb)
+
+    def read(self, ctx, t):
+        """Computed values of a (contiguous) tensor, shaped numpy-style [ne3,ne2,ne1,ne0] squeezed of leading 1s."""
+        n = self.lib.ml_Nelements(t)
+        out = np.empty(n, dtype=np.float32)
+        if self.lib.ml_TensorRead(ctx, t, out.ctypes.data_as(c_f32p), n):
+            raise MLError(f"ml_TensorRead: {self.last_error()}")
+        ne, _ = self.shape(t)
+        return out.reshape(ne[3], ne[2], ne[1], ne[0])
+
+    def op2(self, name, ctx, a, b):
+        return self._chk(getattr(self.lib, "ml_" + name)(ctx, a, b), "ml_" + name)
+
+    def op1(self, name, ctx, a):
+        return self._chk(getattr(self.lib, "ml_" + name)(ctx, a), "ml_" + name)
+
+    def Add(self, ctx, a, b): return self.op2("Add", ctx, a, b)
+    def Mul(self, ctx, a, b): return self.op2("Mul", ctx, a, b)
+    def MulMat(self, ctx, a, b): return self.op2("MulMat", ctx, a, b)
+    def Repeat(self, ctx, a, b): return self.op2("Repeat", ctx, a, b)
+    def GetRows(self, ctx, a, b): return self.op2("GetRows", ctx, a, b)
+    def Copy(self, ctx, a, b): return self.op2("Copy", ctx, a, b)
+    def Scale(self, ctx, a, b): return self.op2("Scale", ctx, a, b)
+    def RMSNorm(self, ctx, a): return self.op1("RMSNorm", ctx, a)
+    def SoftMax(self, ctx, a): return self.op1("SoftMax", ctx, a)
+    def Silu(self, ctx, a): return self.op1("Silu", ctx, a)
+    def View1D(self, ctx, a, ne0, off): return self._chk(self.lib.ml_View1D(ctx, a, ne0, off), "ml_View1D")
+    def Permute(self, ctx, a, a0, a1, a2, a3): return self._chk(self.lib.ml_Permute(ctx, a, a0, a1, a2, a3), "ml_Permute")
+    def Rope(self, ctx, a, past, dims, mode): return self._chk(self.lib.ml_Rope(ctx, a, past, dims, mode), "ml_Rope")
+    def Reshape3D(self, ctx, a, n0, n1, n2): return self._chk(self.lib.ml_Reshape3D(ctx, a, n0, n1, n2), "ml_Reshape3D")
+    def DiagMaskInf(self, ctx, a, past): return self._chk(self.lib.ml_DiagMaskInf(ctx, a, past), "ml_DiagMaskInf")
+
+    def NewGraph(self):
+        return self._chk(self.lib.ml_NewGraph(), "ml_NewGraph")
+
+    def FreeGraph(self, g):
+        self.lib.ml_FreeGraph(g)
+
+    def BuildForwardExpand(self, g, t):
+        if self.lib.ml_BuildForwardExpand(g, t):
+            raise MLError(f"ml_BuildForwardExpand: {self.last_error()}")
+
+    def GraphCompute(self, ctx, g):
+        if self.lib.ml_GraphCompute(ctx, g):
+            raise MLError(f"ml_GraphCompute: {self.last_error()}")
+
+    def graph_ops(self, g):
+        return [OP_NAMES[self.lib.ml_TensorOp(self.lib.ml_GraphNode(g, i))] for i in range(self.lib.ml_GraphNodesCount(g))]
+
+    # ---- llama.* -----------------------------------------------------------------------------------
+    def NewSyntheticModel(self, hp, seed=1234, layer0=0, layer1=0):
+        return Model(self, self._chk(self.lib.llama_NewSyntheticModel(C.byref(hp), seed, layer0, layer1), "llama_NewSyntheticModel"))
+
+    def LoadModel(self, path, ctxSize):
+        return Model(self, self._chk(self.lib.llama_LoadModel(os.fsencode(path), ctxSize), "llama_LoadModel"))
+
+
+def make_hparams(vocab, embd, mult, heads, layers, ctx=128):
+    hp = HParams()
+    hp.ctxSize, hp.vocabSize, hp.embdSize, hp.multSize, hp.headsCount, hp.layersCount = ctx, vocab, embd, mult, heads, layers
+    hp.rotCount, hp.f16 = embd // heads, 0
+    return hp
+
+
+# Named shapes (SURVEY §8 / BASELINE.json configs).  "tiny" is the unit-test twin.
+SHAPES = {
+    "tiny": dict(vocab=512, embd=256, mult=256, heads=4, layers=2),
+    "small": dict(vocab=2048, embd=1024, mult=256, heads=8, layers=4),
+    "7B": dict(vocab=32000, embd=4096, mult=256, heads=32, layers=32),
+    "13B": dict(vocab=32000, embd=5120, mult=256, heads=40, layers=40),
+    "65B": dict(vocab=32000, embd=8192, mult=256, heads=64, layers=80),
+}
+PROMPT = [1, 306, 4658, 278, 6593, 310, 2834, 338]  # fixed 8-token prompt
+
+
+class Model:
+    """llama.Model (llama.go:181-193)."""
+
+    def __init__(self, ml, handle):
+        self.ml, self.h = ml, handle
+        self.hp = HParams()
+        ml.lib.llama_ModelHParams(handle, C.byref(self.hp))
+        self.ffSize = ml.lib.llama_ModelFFSize(handle)
+
+    def tensor(self, name):
+        return self.ml.lib.llama_ModelTensor(self.h, name.encode())
+
+    def Save(self, path, ftype=0):
+        if self.ml.lib.llama_SaveModel(self.h, os.fsencode(path), ftype):
+            raise MLError("llama_SaveModel failed")
+
+    def NewContext(self, ctxSize=128, maxThreads=1, useAVX=False, useNEON=False):
+        h = self.ml._chk(self.ml.lib.llama_NewContext(self.h, ctxSize, maxThreads, int(useAVX), int(useNEON)), "llama_NewContext")
+        return Context(self, h)
+
+    def free(self):
+        if self.h:
+            self.ml.lib.llama_FreeModel(self.h)
+            self.h = None
+
+
+class Context:
+    """llama.Context (llama.go:83-88)."""
+
+    def __init__(self, model, handle):
+        self.model, self.ml, self.h = model, model.ml, handle
+
+    def Eval(self, tokens, pastCount):
+        toks = (c_u32 * len(tokens))(*[int(t) for t in tokens])
+        if self.ml.lib.llama_Eval(self.h, self.model.h, toks, len(tokens), pastCount):
+            raise MLError(f"llama_Eval: {self.ml.last_error()}")
+        return self.logits()
+
+    def logits(self):
+        V = self.model.hp.vocabSize
+        return np.ctypeslib.as_array(self.ml.lib.llama_Logits(self.h), shape=(V,)).copy()
+
+    def GreedyDecode(self, prompt, n_predict, want_logits=True):
+        V = self.model.hp.vocabSize
+        toks = (c_u32 * len(prompt))(*[int(t) for t in prompt])
+        out = (c_u32 * n_predict)()
+        lg = np.empty((n_predict, V), dtype=np.float32) if want_logits else None
+        rc = self.ml.lib.llama_GreedyDecode(self.h, self.model.h, toks, len(prompt), n_predict, out,
+                                            lg.ctypes.data_as(c_f32p) if want_logits else None)
+        if rc:
+            raise MLError(f"llama_GreedyDecode: {self.ml.last_error()}")
+        return list(out), lg
+
+    def free(self):
+        if self.h:
+            self.ml.lib.llama_ReleaseContext(self.h)
+            self.h = None
+
+
+class KernelTime(C.Structure):
+    """lh_kernel_time (include/llamahip.h)."""
+    _fields_ = [("name", C.c_char * 48), ("launches", c_u32), ("total_ms", C.c_float), ("bytes_per_launch", c_u64)]
+
+
+def _bind_extensions(ml):
+    """Product-only entry points (no counterpart in the reference): resident decode loop, kernel timing, pipeline stage."""
+    L = ml.lib
+    L.llamago_DecodeGreedyResident.restype = C.c_int
+    L.llamago_DecodeGreedyResident.argtypes = [VP, c_u32, c_u32, c_u32, c_u32p, c_f32p]
+    L.llamago_ProfileDecode.restype = C.c_int
+    L.llamago_ProfileDecode.argtypes = [VP, c_u32, c_u32, c_u32, C.POINTER(KernelTime), c_u32]
+    L.llamago_Stage.restype = C.c_int
+    L.llamago_Stage.argtypes = [VP, c_u32p, VP, VP, VP, c_u32, c_u32, VP, VP]
+    L.llamago_Sync.restype = C.c_int
+    L.llamago_Sync.argtypes = [VP]
+    L.llamago_SetStream.restype = None
+    L.llamago_SetStream.argtypes = [VP]
+    L.llamago_DeviceCount.restype = C.c_int
+    L.llamago_LastGraphFused.restype = C.c_int
+    L.llamago_LastGraphFused.argtypes = [VP]
+    L.llamago_GraphComputeNoFusion.restype = C.c_int
+    L.llamago_GraphComputeNoFusion.argtypes = [VP, VP]
+    ml.has_extensions = True
+
+
+def decode_greedy_resident(ctx, first_token, past, n_steps, want_logits=False):
+    """llamago_DecodeGreedyResident: n_steps decode steps without host round trips (argmax on the GPU)."""
+    ml = ctx.ml
+    out = (c_u32 * n_steps)()
+    lg = np.empty(ctx.model.hp.vocabSize, dtype=np.float32) if want_logits else None
+    if ml.lib.llamago_DecodeGreedyResident(ctx.h, first_token, past, n_steps, out, lg.ctypes.data_as(c_f32p) if want_logits else None):
+        raise MLError(f"llamago_DecodeGreedyResident: {ml.last_error()}")
+    return list(out), lg
+
+
+def profile_decode(ctx, token, past, repeats=3):
+    """Per-kernel-class HIP-event timing of eager decode steps: list of dicts(name, launches, avg_us, bytes_per_launch, gbps)."""
+    ml = ctx.ml
+    arr = (KernelTime * 32)()
+    n = ml.lib.llamago_ProfileDecode(ctx.h, token, past, repeats, arr, 32)
+    if n < 0:
+        raise MLError(f"llamago_ProfileDecode: {ml.last_error()}")
+    res = []
+    for i in range(n):
+        k = arr[i]
+        avg_us = k.total_ms * 1e3 / max(k.launches, 1)
+        res.append(dict(name=k.name.decode(), launches=int(k.launches), avg_us=avg_us, bytes_per_launch=int(k.bytes_per_launch),
+                        gbps=(k.bytes_per_launch / avg_us / 1e3) if avg_us > 0 else 0.0))
+    return res
+
+
+_product = None
+
+
+def load_product():
+    """The product library (HIP path).  Fails loudly when the extension is missing: there is no CPU fallback."""
+    global _product
+    if _product is None:
+        from . import LIBLLAMAGO, LIBLLAMAHIP
+        if not os.path.exists(LIBLLAMAHIP):
+            raise MLError(f"HIP extension missing: {LIBLLAMAHIP} — build it with __graft_entry__.build(); no CPU fallback exists")
+        C.CDLL(LIBLLAMAHIP, mode=C.RTLD_GLOBAL)
+        _product = MLLib(LIBLLAMAGO)
+        _bind_extensions(_product)
+    return _product
