@@ -41,6 +41,25 @@ def bytes_per_token(hp_d, L, F, V, T):
     return weights, kv
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box reports 256
+    logical CPUs but runs the job under a 16-CPU quota; oversubscribing OpenMP there is catastrophic)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +141,8 @@ def main():
         # ---- CPU baseline + parity on the same inputs (oracle = test infrastructure; only used here as the checker / baseline)
         if not args.no_cpu_baseline:
             orc = MLLib(os.path.join(ROOT, "oracle", "liboracle.so"))
-            ncpu = os.cpu_count() or 1
+            ncpu = usable_cores()
+            os.environ.setdefault("OMP_WAIT_POLICY", "passive")
             t_gen = time.perf_counter()
             om = orc.NewSyntheticModel(hp, SEED)
             t_gen = time.perf_counter() - t_gen
@@ -154,7 +174,7 @@ def main():
                           f"{nsteps} decode steps at P={P0}.. after an {P0}-token prefill; rows split over {ncpu} host threads",
                 "ms_per_token": round(avx_dt * 1e3, 1),
                 "pure_go_scalar_1thread_ms_per_token": round(scalar1_dt * 1e3, 1),
-                "weights_gen_s": round(t_gen, 1),
+                "weights_gen_s": round(t_gen, 1), "host_logical_cpus": os.cpu_count(),
             }
             # parity: GPU ids/logits vs the scalar-order oracle on the overlapping steps
             gl = [logits0]

@@ -51,7 +51,7 @@ __device__ __forceinline__ const f4* row_ptr(const GemvArgs& a, uint32_t v, uint
 // RMSNorm + weight multiply on the thread's own columns (ml.go:1753-1812 then ml.go:1877-1914):
 //   mean = (sum_f64 fl32(x*x)) / K ; scale = fl32(1/sqrt(mean + 1e-5)) ; t = fl32(x*scale) ; h = fl32(gamma*t)
 template <int KI, int TH>
-__device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)[KI], const float* gamma, uint32_t K, double* sred) {
+__device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)[KI], const f4 (&gr)[KI], uint32_t K, double* sred) {
     constexpr int NW = TH / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double s = 0.0;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
         if (act[j]) {
-            const f4 g = ((const f4*)gamma)[tid + j * TH];
+            const f4 g = gr[j];
             xr[j].x = __fmul_rn(g.x, __fmul_rn(xr[j].x, scale));
             xr[j].y = __fmul_rn(g.y, __fmul_rn(xr[j].y, scale));
             xr[j].z = __fmul_rn(g.z, __fmul_rn(xr[j].z, scale));
@@ -86,25 +86,42 @@ __device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)
 
 template <int KI, int U, int TH, int PRO, int EPI, int MAP>
 __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
-    static_assert(U % 2 == 0, "U must be even (row pairs stay in one batch)");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = TH / 64;
     double* sred = (double*)smem_raw;                // [NW]
-    float* red = (float*)(smem_raw + NW * 8);        // [2][U][NW]
+    float* red = (float*)(smem_raw + NW * 8);        // [rows of this workgroup][NW] per-wave partial dot products
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t K4 = a.K >> 2;
     const uint32_t nwg = gridDim.x;
-    // rows are dealt in pairs so RoPE / SiLU partners share a workgroup and a batch
+    // rows are dealt in pairs so RoPE / SiLU partners share a workgroup
     const uint32_t npairs = a.M >> 1;
     const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
     const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
 
     f4 xr[KI];
+    f4 gr[KI];
     bool act[KI];
 #pragma unroll
     for (int j = 0; j < KI; ++j) {
         act[j] = (uint32_t)(tid + j * TH) < K4;
         xr[j] = act[j] ? ((const f4*)a.x)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+        if (PRO == PRO_RMSNORM) gr[j] = act[j] ? ((const f4*)a.gamma)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // Epilogue operands of this workgroup's rows are fetched now (one finishing thread per row or row pair), so their
+    // latency hides under the weight stream.
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;  // row offset this thread finishes
+    float resid_pre = 0.f;
+    double2 cs_pre = {1.0, 0.0};
+    uint32_t past_pre = 0;
+    if (EPI == EPI_RESID) {
+        if (r0 + fin < r1) resid_pre = a.resid[r0 + fin];
+    } else if (EPI == EPI_QKV_ROPE) {
+        past_pre = a.sp->past;
+        const uint32_t v = r0 + fin;
+        if (v < r1 && v < 2 * a.d) {
+            const uint32_t e = v < a.d ? v : v - a.d;
+            cs_pre = a.rope[(size_t)past_pre * (a.hd >> 1) + ((e % a.hd) >> 1)];
+        }
     }
     // first U rows are requested before the prologue so HBM latency overlaps the norm
     f4 w[U][KI];
@@ -115,9 +132,11 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < KI; ++j) w[u][j] = (rv && act[j]) ? ld_nt(p + tid + j * TH) : f4{0.f, 0.f, 0.f, 0.f};
     }
-    if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, a.gamma, a.K, sred);
+    if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, gr, a.K, sred);
 
-    int buf = 0;
+    // Main stream: no workgroup barrier inside.  At the latency/bandwidth knee (U x 16 KiB in flight per CU) every stall
+    // that delays the next load request costs throughput (tools/kernel_ablate: a per-batch barrier + epilogue = 3-4 %),
+    // so waves run free and park their per-row partial sums in LDS.
     for (uint32_t r = r0; r < r1; r += U) {
         float acc[U];
 #pragma unroll
@@ -141,51 +160,46 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
         for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
         if (lane == 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) red[(buf * U + u) * NW + wave] = acc[u];
+            for (int u = 0; u < U; ++u)
+                if (r + u < r1) red[(r - r0 + u) * NW + wave] = acc[u];
         }
-        __syncthreads();
-        if (EPI == EPI_STORE || EPI == EPI_RESID) {
-            if (tid < U && r + tid < r1) {
-                const float* p = red + (buf * U + tid) * NW;
-                float s = 0.f;
+    }
+    __syncthreads();
+    // Epilogue, once, all rows of the workgroup in parallel; cross-wave sums in fixed order -> bit-reproducible.
+    if (r0 + fin < r1) {
+        const float* p0 = red + fin * NW;
+        float s0 = 0.f;
 #pragma unroll
-                for (int k = 0; k < NW; ++k) s += p[k];
-                const uint32_t v = r + tid;
-                if (EPI == EPI_RESID) s = __fadd_rn(s, a.resid[v]);  // Add(cur, inp) ml.go:2515-2584
-                a.y[v] = s;
-            }
+        for (int k = 0; k < NW; ++k) s0 += p0[k];
+        const uint32_t v = r0 + fin;
+        if (EPI == EPI_STORE) {
+            a.y[v] = s0;
+        } else if (EPI == EPI_RESID) {
+            a.y[v] = __fadd_rn(s0, resid_pre);  // Add(cur, inp) ml.go:2515-2584
         } else {
-            if (tid < U / 2 && r + 2 * tid < r1) {
-                const float* p0 = red + (buf * U + 2 * tid) * NW;
-                const float* p1 = p0 + NW;
-                float s0 = 0.f, s1 = 0.f;
+            const float* p1 = p0 + NW;
+            float s1 = 0.f;
 #pragma unroll
-                for (int k = 0; k < NW; ++k) { s0 += p0[k]; s1 += p1[k]; }
-                const uint32_t v = r + 2 * tid;
-                if (EPI == EPI_SILU_MUL) {
-                    // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
-                    a.y[v >> 1] = __fmul_rn(silu_ref(s0), s1);
-                } else {  // EPI_QKV_ROPE
-                    const uint32_t past = a.sp->past;
-                    const uint32_t d = a.d;
-                    if (v < 2 * d) {
-                        const uint32_t e = v < d ? v : v - d;           // element inside the d-vector
-                        const uint32_t i0 = e % a.hd;                   // even offset inside the head
-                        const double2 cs = a.rope[(size_t)past * (a.hd >> 1) + (i0 >> 1)];
-                        float o0, o1;
-                        rope_rotate(s0, s1, cs, &o0, &o1);
-                        float* dst = v < d ? a.q_out + e : a.k_cache + (size_t)past * d + e;
-                        dst[0] = o0;
-                        dst[1] = o1;
-                    } else {
-                        float* dst = a.v_cache + (size_t)past * d + (v - 2 * d);
-                        dst[0] = s0;
-                        dst[1] = s1;
-                    }
+            for (int k = 0; k < NW; ++k) s1 += p1[k];
+            if (EPI == EPI_SILU_MUL) {
+                // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+                a.y[v >> 1] = __fmul_rn(silu_ref(s0), s1);
+            } else {  // EPI_QKV_ROPE: Rope mode 0 on Q / mode 1 on the new K row (ml.go:2253-2328), K,V appended to the cache (llama.go:274-278)
+                const uint32_t d = a.d;
+                if (v < 2 * d) {
+                    const uint32_t e = v < d ? v : v - d;
+                    float o0, o1;
+                    rope_rotate(s0, s1, cs_pre, &o0, &o1);
+                    float* dst = v < d ? a.q_out + e : a.k_cache + (size_t)past_pre * d + e;
+                    dst[0] = o0;
+                    dst[1] = o1;
+                } else {
+                    float* dst = a.v_cache + (size_t)past_pre * d + (v - 2 * d);
+                    dst[0] = s0;
+                    dst[1] = s1;
                 }
             }
         }
-        buf ^= 1;
     }
 }
 
@@ -298,62 +312,69 @@ struct AttnArgs {
 
 __global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sc = (float*)smem_raw;  // [T] scores / probabilities, then [256] reduction scratch after it
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t h = blockIdx.x, j = blockIdx.y;
     const uint32_t past = a.sp ? a.sp->past : a.past_host;
     const uint32_t T = past + j + 1;  // keys 0..past+j are visible to query j (mask: i > past + j, ml.go:2401-2404)
-    float* scratch = sc + ((T + 63) & ~63u);
+    const uint32_t Tp = (T + 63) & ~63u;
+    float* sc = (float*)smem_raw;     // [Tp] scaled scores
+    float* pr = sc + Tp;              // [Tp] un-normalised probabilities (every wave writes identical values)
+    float* scratch = pr + Tp;         // [256] PV partials
     const uint32_t d = a.d, hd = a.hd;
     const float* q = a.q + (size_t)j * d + h * hd;
     const float* Kc = a.k_cache + h * hd;
     const float* Vc = a.v_cache + h * hd;
-    // --- scores: one key per 32-lane group per iteration (hd = 128 -> float4 per lane; general hd handled by loop)
+    // --- V prefetch for the PV phase: issued first so its latency hides under scores + softmax
+    const uint32_t phases = 256 / hd;  // hd = 128 -> 2 key phases
+    const uint32_t c = tid % hd, ph = tid / hd;
+    constexpr int VP = 16;
+    float vpre[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const uint32_t t = ph + (uint32_t)i * phases;
+        vpre[i] = t < T ? Vc[(size_t)t * d + c] : 0.f;
+    }
+    // --- scores: one key per 32-lane group per iteration (hd = 128 -> float4 per lane)
     const int g = tid >> 5, gl = tid & 31;
     for (uint32_t t = g; t < T; t += 8) {
         float s = 0.f;
-        for (uint32_t c = gl * 4; c < hd; c += 128) {
-            const f4 kv = *(const f4*)(Kc + (size_t)t * d + c);
-            const f4 qv = *(const f4*)(q + c);
+        for (uint32_t cc = gl * 4; cc < hd; cc += 128) {
+            const f4 kv = *(const f4*)(Kc + (size_t)t * d + cc);
+            const f4 qv = *(const f4*)(q + cc);
             s = fmaf(kv.x, qv.x, s); s = fmaf(kv.y, qv.y, s); s = fmaf(kv.z, qv.z, s); s = fmaf(kv.w, qv.w, s);
         }
         s = half_wave_sum(s);
         if (gl == 0) sc[t] = __fmul_rn(s, a.scale);  // Scale ml.go:2331-2374
     }
     __syncthreads();
-    // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum
+    // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum.
+    // Each wave evaluates the whole row redundantly with wave-level reductions (same code -> same bits), which removes
+    // every block barrier of this phase; waves only read sc[] and write identical values to pr[].
     float m = -INFINITY;
-    for (uint32_t t = tid; t < T; t += 256) m = fmaxf(m, sc[t]);
+    for (uint32_t t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
     m = wave_max(m);
-    if (lane == 0) scratch[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
-    __syncthreads();
     float psum = 0.f;
-    for (uint32_t t = tid; t < T; t += 256) {
+    for (uint32_t t = lane; t < T; t += 64) {
         const float p = (float)exp((double)__fsub_rn(sc[t], m));
-        sc[t] = p;
+        pr[t] = p;
         psum += p;
     }
     psum = wave_sum(psum);
-    if (lane == 0) scratch[wave] = psum;
-    __syncthreads();
-    const float inv = __fdiv_rn(1.0f, (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]));
-    __syncthreads();
-    for (uint32_t t = tid; t < T; t += 256) sc[t] = __fmul_rn(sc[t], inv);
-    __syncthreads();
-    // --- PV: thread c accumulates over keys; 256/hd key-phases run in parallel and are combined in LDS
-    const uint32_t phases = 256 / hd ? 256 / hd : 1;  // hd = 128 -> 2
-    const uint32_t c = tid % hd, ph = tid / hd;
+    const float inv = __fdiv_rn(1.0f, psum);
+    // --- PV: thread (c, ph) accumulates its key phase; DS operations of a wave execute in order, so pr[] written above by
+    // this wave is visible to its own reads below
     float acc = 0.f;
-    if (ph < phases) {
-        for (uint32_t t = ph; t < T; t += phases) acc = fmaf(Vc[(size_t)t * d + c], sc[t], acc);
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const uint32_t t = ph + (uint32_t)i * phases;
+        if (t < T) acc = fmaf(vpre[i], __fmul_rn(pr[t], inv), acc);
     }
+    for (uint32_t t = ph + VP * phases; t < T; t += phases) acc = fmaf(Vc[(size_t)t * d + c], __fmul_rn(pr[t], inv), acc);
     scratch[tid] = acc;
     __syncthreads();
-    if (tid < hd) {
+    if (tid < (int)hd) {
         float o = scratch[tid];
-        for (uint32_t p = 1; p < phases; ++p) o += scratch[tid + p * hd];
+        for (uint32_t p2 = 1; p2 < phases; ++p2) o += scratch[tid + p2 * hd];
         a.out[(size_t)j * d + h * hd + tid] = o;
     }
 }
@@ -379,10 +400,24 @@ __global__ __launch_bounds__(1024) void k_argmax_advance(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float bv = -INFINITY;
     uint32_t bi = 0xFFFFFFFFu;
-    for (uint32_t i = tid; i < n; i += 1024) {
-        const float v = logits[i];
-        if (v > bv || bi == 0xFFFFFFFFu) { bv = v; bi = i; }  // ascending i: first maximum kept
+    auto take = [&](float v, uint32_t i) {  // ascending i inside a thread: the first maximum is kept
+        if (v > bv || bi == 0xFFFFFFFFu) { bv = v; bi = i; }
+    };
+    const uint32_t n4 = (n % 4 == 0 && ((uintptr_t)logits & 15) == 0) ? n / 4 : 0;
+    for (uint32_t i0 = tid; i0 < n4; i0 += 1024 * 4) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * 1024;
+            v[u] = i < n4 ? ((const f4*)logits)[i] : f4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * 1024;
+            if (i < n4) { take(v[u].x, 4 * i); take(v[u].y, 4 * i + 1); take(v[u].z, 4 * i + 2); take(v[u].w, 4 * i + 3); }
+        }
     }
+    for (uint32_t i = 4 * n4 + tid; i < n; i += 1024) take(logits[i], i);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const float ov = __shfl_xor(bv, o, 64);

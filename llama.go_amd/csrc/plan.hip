@@ -61,6 +61,8 @@ static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_
 template <int PRO, int EPI, int MAP>
 static int gemv(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     if (a.K % 4 || a.M % 2) LH_FAIL(ctx, LH_ESHAPE, "gemv %s: K=%u must be a multiple of 4 and M=%u even", name, a.K, a.M);
+    // one finishing thread per row and rows*16 partial sums in LDS per workgroup
+    if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
     const uint32_t K4 = a.K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
@@ -116,7 +118,7 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
 
 static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
     if (a.hd > 256 || 256 % a.hd || a.hd % 4) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: head dim %u unsupported (needs to divide 256)", a.hd);
-    const size_t lds = ((size_t)((max_T + 63) & ~63u) + 256) * 4;
+    const size_t lds = (2 * (size_t)((max_T + 63) & ~63u) + 256) * 4;
     static bool flags[16] = {};
     static size_t cur[16] = {};
     if (lds > 48 * 1024 && lds > cur[ctx->device & 15]) {

@@ -1,0 +1,86 @@
+// tools/kernel_ablate.hip — ablation of the PRODUCT GEMV kernel (csrc/kernels_llama.h) on 7B shapes: bare stream vs
+// + row mapping vs + RMSNorm prologue vs + fused epilogue.  Not product code.  Cycles through a 6 GiB weight pool.
+#include "../llama.go_amd/csrc/kernels_llama.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+using namespace lh;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static float* pool; static const size_t POOL = (size_t)6 << 30;
+static hipStream_t st; static hipEvent_t e0, e1; static int nCU;
+
+template <typename K> static void run(const char* label, K kern, GemvArgs a, size_t bytes, int nmat_stride_rows) {
+    const size_t lds = 96 * 1024;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    size_t nmat = POOL / bytes; int iters = (int)(3e9 / bytes) + 8;
+    auto launch = [&](int i) {
+        GemvArgs b = a; float* base = pool + (size_t)(i % nmat) * (bytes / 4);
+        const size_t per = bytes / 4 / (a.w[2] ? 3 : a.w[1] ? 2 : 1);
+        b.w[0] = base; if (a.w[1]) b.w[1] = base + per; if (a.w[2]) b.w[2] = base + 2 * per;
+        hipLaunchKernelGGL(kern, dim3(nCU), dim3(1024), lds, st, b);
+    };
+    for (int i = 0; i < 3; ++i) launch(i);
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch(i);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / iters;
+    printf("  %-58s %8.2f us  %7.1f GB/s\n", label, us, bytes / us / 1e3);
+    CK(hipGetLastError());
+}
+
+int main() {
+    CK(hipSetDevice(0)); hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); nCU = p.multiProcessorCount;
+    CK(hipMalloc(&pool, POOL));
+    { size_t pat = (size_t)16 << 20; std::vector<float> h(pat); unsigned s = 12345;
+      for (size_t i = 0; i < pat; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)) * 0.02f; }
+      for (size_t off = 0; off < POOL; off += pat * 4) CK(hipMemcpy((char*)pool + off, h.data(), pat * 4, hipMemcpyHostToDevice)); }
+    float *x, *g, *y, *q, *kc, *vc, *res; StepParams* sp; double2* rope;
+    CK(hipMalloc(&x, 65536 * 4)); CK(hipMalloc(&g, 65536 * 4)); CK(hipMalloc(&y, 65536 * 4)); CK(hipMalloc(&q, 65536 * 4)); CK(hipMalloc(&res, 65536 * 4));
+    CK(hipMalloc(&kc, 128 * 4096 * 4)); CK(hipMalloc(&vc, 128 * 4096 * 4)); CK(hipMalloc(&sp, sizeof(StepParams))); CK(hipMalloc(&rope, 256 * 64 * sizeof(double2)));
+    std::vector<float> hx(65536); { unsigned s = 7; for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); } }
+    CK(hipMemcpy(x, hx.data(), 65536 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(g, hx.data(), 65536 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(res, hx.data(), 65536 * 4, hipMemcpyHostToDevice));
+    StepParams hsp = {1, 9, 0, 0}; CK(hipMemcpy(sp, &hsp, sizeof hsp, hipMemcpyHostToDevice));
+    std::vector<double2> hr(256 * 64); for (auto& v : hr) { v.x = 0.8; v.y = 0.6; } CK(hipMemcpy(rope, hr.data(), hr.size() * sizeof(double2), hipMemcpyHostToDevice));
+    CK(hipStreamCreate(&st)); CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const uint32_t d = 4096, F = 11008, V = 32000;
+    auto base = [&](uint32_t M, uint32_t K) { GemvArgs a = {}; a.w[0] = pool; a.M = M; a.K = K; a.x = x; a.gamma = g; a.y = y; a.resid = res; a.q_out = q; a.k_cache = kc; a.v_cache = vc; a.rope = rope; a.hd = 128; a.d = d; a.sp = sp; a.rows_per_mat = d; return a; };
+
+    printf("[w1w3 2x11008x4096]\n");
+    { GemvArgs a = base(2 * F, d); size_t B = (size_t)2 * F * d * 4;
+      run("U4 plain/store/single (bare stream)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);
+      GemvArgs b = a; b.w[1] = pool + 1;
+      run("U4 plain/store/pair", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_PAIR>, b, B, 0);
+      run("U4 rmsnorm/store/pair", k_gemv<1, 4, 1024, PRO_RMSNORM, EPI_STORE, MAP_PAIR>, b, B, 0);
+      run("U4 plain/silu/pair", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_SILU_MUL, MAP_PAIR>, b, B, 0);
+      run("U4 rmsnorm/silu/pair (product)", k_gemv<1, 4, 1024, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, b, B, 0);
+      run("U2 rmsnorm/silu/pair", k_gemv<1, 2, 1024, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, b, B, 0);
+      run("U6 rmsnorm/silu/pair", k_gemv<1, 6, 1024, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, b, B, 0);
+      run("U8 rmsnorm/silu/pair", k_gemv<1, 8, 1024, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, b, B, 0); }
+    printf("[qkv 3x4096x4096]\n");
+    { GemvArgs a = base(3 * d, d); size_t B = (size_t)3 * d * d * 4; GemvArgs b = a; b.w[1] = pool + 1; b.w[2] = pool + 2;
+      run("U4 plain/store/single (bare stream)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);
+      run("U4 plain/store/block", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_BLOCK>, b, B, 0);
+      run("U4 rmsnorm/store/block", k_gemv<1, 4, 1024, PRO_RMSNORM, EPI_STORE, MAP_BLOCK>, b, B, 0);
+      run("U4 plain/rope/block", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_QKV_ROPE, MAP_BLOCK>, b, B, 0);
+      run("U4 rmsnorm/rope/block (product)", k_gemv<1, 4, 1024, PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>, b, B, 0); }
+    printf("[wo 4096x4096]\n");
+    { GemvArgs a = base(d, d); size_t B = (size_t)d * d * 4;
+      run("U4 plain/store/single (bare stream)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);
+      run("U4 plain/resid/single (product)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, a, B, 0);
+      run("U2 plain/resid/single", k_gemv<1, 2, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, a, B, 0); }
+    printf("[w2 4096x11008]\n");
+    { GemvArgs a = base(d, F); size_t B = (size_t)d * F * 4;
+      run("KI3 U2 plain/store/single (bare stream)", k_gemv<3, 2, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);
+      run("KI3 U2 plain/resid/single (product)", k_gemv<3, 2, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, a, B, 0);
+      run("KI3 U4 plain/resid/single", k_gemv<3, 4, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, a, B, 0); }
+    printf("[lmhead 32000x4096]\n");
+    { GemvArgs a = base(V, d); size_t B = (size_t)V * d * 4;
+      run("U4 plain/store/single (bare stream)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);
+      run("U4 rmsnorm/store/single (product)", k_gemv<1, 4, 1024, PRO_RMSNORM, EPI_STORE, MAP_SINGLE>, a, B, 0); }
+    printf("done\n");
+    return 0;
+}
