@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--pods", type=int, default=0, help="streams in flight for N > 1 (default N)")
     args = ap.parse_args()
 
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before any OpenMP runtime loads (CPU baseline threads)
     import numpy as np
     import torch  # first: the process then uses ONE HIP runtime (torch's), libllamahip binds to it by SONAME
     import torch.distributed as dist
