@@ -58,6 +58,12 @@ int lh_buf_read(lh_ctx* ctx, lh_buf buf, uint64_t off_floats, float* dst, uint64
 /* Fill with the synthetic-model generator: w[i] = offset + scale * u(seed, tensor_id, i), in HBM. */
 int lh_buf_fill_synth(lh_ctx* ctx, lh_buf buf, uint64_t off_floats, uint64_t n, uint64_t seed, uint32_t tensor_id,
                       float scale, float offset);
+/* Block-int8 (dtype 7; our format — the reference has none, ml.go:85-94, llama.go:956-959): quantise a registered fp32
+ * matrix [rows][cols] on the device into a new buffer (d = max|w|/127 per 32 columns, q = rint(w/d)).  A dtype-7 buffer
+ * can also be registered directly from 36-byte interchange blocks {float d; int8 q[32]} with lh_tensor_register. */
+int lh_buf_quantize_q8(lh_ctx* ctx, lh_buf src_f32, uint32_t rows, uint32_t cols, lh_buf* out);
+/* Dequantised fp32 values of a dtype-7 buffer (w = fl32(d*q)), for checks. */
+int lh_buf_read_q8(lh_ctx* ctx, lh_buf buf, uint64_t off, float* dst, uint64_t n);
 int lh_buf_free(lh_ctx* ctx, lh_buf buf);
 void* lh_buf_devptr(lh_ctx* ctx, lh_buf buf);   /* raw device address (interop with a framework's collectives) */
 uint64_t lh_buf_nfloats(lh_ctx* ctx, lh_buf buf);

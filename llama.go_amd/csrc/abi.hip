@@ -1,8 +1,10 @@
 // csrc/abi.hip — contexts, persistent buffers, synthetic-weight generator, RoPE table.
 // C-ABI entry points declared in include/llamahip.h.
 #include "common.h"
+#include "kernels_q8_pack.h"
 #include <stdarg.h>
 #include <math.h>
+#include <algorithm>
 
 namespace lh {
 
@@ -162,8 +164,31 @@ void* lh_ctx_stream(lh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4], int persistent, const void* host, lh_buf* out) {
     if (!ctx || !ne || !out) LH_FAIL(ctx, LH_EINVAL, "lh_tensor_register: NULL argument");
     (void)persistent;
-    if (dtype != 0) LH_FAIL(ctx, LH_EUNSUPPORTED, "lh_tensor_register: dtype %d not supported (f32 only; the reference loader rejects others too, llama.go:956-959)", dtype);
+    if (dtype != 0 && dtype != 7) LH_FAIL(ctx, LH_EUNSUPPORTED, "lh_tensor_register: dtype %d not supported (f32 and block-int8 only; the reference loader accepts f32/f16, llama.go:956-959)", dtype);
     LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (dtype == 7) {
+        if (ne[0] % 32 || ne[2] != 1 || ne[3] != 1 || !host) LH_FAIL(ctx, LH_ESHAPE, "lh_tensor_register: block-int8 needs a 2-D matrix with columns %% 32 == 0 and host blocks");
+        const uint64_t nblocks = (uint64_t)ne[0] * ne[1] / 32;
+        auto b = std::make_unique<Buffer>();
+        b->nfloats = (uint64_t)ne[0] * ne[1]; b->dtype = 7; b->rows = ne[1]; b->cols = ne[0]; b->key = key; b->device = ctx->device;
+        const uint64_t qbytes = (b->nfloats + 255) & ~(uint64_t)255;
+        b->bytes = qbytes + nblocks * 4;
+        unsigned int* raw = nullptr;
+        LH_HIP(ctx, hipMalloc((void**)&b->dev, b->bytes));
+        b->scales = (float*)((char*)b->dev + qbytes);
+        LH_HIP(ctx, hipMalloc((void**)&raw, nblocks * 36));
+        LH_HIP(ctx, hipMemcpy(raw, host, nblocks * 36, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_q8_deinterleave, dim3((unsigned)std::min<uint64_t>((nblocks + 255) / 256, 65535)), dim3(256), 0, ctx->stream, (const unsigned int*)raw,
+                           (signed char*)b->dev, b->scales, nblocks);
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LH_HIP(ctx, hipFree(raw));
+        std::lock_guard<std::mutex> lk(ctx->ds->mu);
+        lh_buf id = ctx->ds->next_id++;
+        if (key) ctx->ds->by_key[key] = id;
+        ctx->ds->bufs[id] = std::move(b);
+        *out = id;
+        return LH_OK;
+    }
     DeviceState* ds = ctx->ds;
     if (key) {
         std::lock_guard<std::mutex> lk(ds->mu);
@@ -204,6 +229,7 @@ int lh_buf_upload(lh_ctx* ctx, lh_buf buf, uint64_t off, const float* host, uint
     int rc = get_buf(ctx, buf, off, n, &b, "lh_buf_upload");
     if (rc) return rc;
     if (!host) LH_FAIL(ctx, LH_EINVAL, "lh_buf_upload: host is NULL");
+    if (b->dtype != 0) LH_FAIL(ctx, LH_EINVAL, "lh_buf_upload: not an f32 buffer");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     LH_HIP(ctx, hipMemcpy(b->dev + off, host, n * 4, hipMemcpyHostToDevice));
@@ -215,6 +241,7 @@ int lh_buf_read(lh_ctx* ctx, lh_buf buf, uint64_t off, float* dst, uint64_t n) {
     int rc = get_buf(ctx, buf, off, n, &b, "lh_buf_read");
     if (rc) return rc;
     if (!dst) LH_FAIL(ctx, LH_EINVAL, "lh_buf_read: dst is NULL");
+    if (b->dtype == 7) return lh_buf_read_q8(ctx, buf, off, dst, n);
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     LH_HIP(ctx, hipMemcpy(dst, b->dev + off, n * 4, hipMemcpyDeviceToHost));
@@ -231,6 +258,47 @@ int lh_buf_fill_synth(lh_ctx* ctx, lh_buf buf, uint64_t off, uint64_t n, uint64_
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_fill_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b->dev + off, n, key, scale, offset);
     LH_HIP(ctx, hipGetLastError());
+    return LH_OK;
+}
+
+int lh_buf_quantize_q8(lh_ctx* ctx, lh_buf src, uint32_t rows, uint32_t cols, lh_buf* out) {
+    Buffer* sb;
+    if (!out) return LH_EINVAL;
+    int rc = get_buf(ctx, src, 0, (uint64_t)rows * cols, &sb, "lh_buf_quantize_q8");
+    if (rc) return rc;
+    if (sb->dtype != 0 || cols % 32) LH_FAIL(ctx, LH_ESHAPE, "lh_buf_quantize_q8: needs an f32 matrix with columns %% 32 == 0");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = (uint64_t)rows * cols, nblocks = n / 32;
+    auto b = std::make_unique<Buffer>();
+    b->nfloats = n; b->dtype = 7; b->rows = rows; b->cols = cols; b->device = ctx->device;
+    const uint64_t qbytes = (n + 255) & ~(uint64_t)255;
+    b->bytes = qbytes + nblocks * 4;
+    LH_HIP(ctx, hipMalloc((void**)&b->dev, b->bytes));
+    b->scales = (float*)((char*)b->dev + qbytes);
+    hipLaunchKernelGGL(k_quantize_q8, dim3((unsigned)std::min<uint64_t>((nblocks + 255) / 256, 65535)), dim3(256), 0, ctx->stream, (const float*)sb->dev,
+                       (signed char*)b->dev, b->scales, nblocks);
+    LH_HIP(ctx, hipGetLastError());
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->ds->mu);
+    lh_buf id = ctx->ds->next_id++;
+    ctx->ds->bufs[id] = std::move(b);
+    *out = id;
+    return LH_OK;
+}
+
+int lh_buf_read_q8(lh_ctx* ctx, lh_buf buf, uint64_t off, float* dst, uint64_t n) {
+    Buffer* b;
+    int rc = get_buf(ctx, buf, off, n, &b, "lh_buf_read_q8");
+    if (rc) return rc;
+    if (b->dtype != 7 || !dst) LH_FAIL(ctx, LH_EINVAL, "lh_buf_read_q8: not a block-int8 buffer");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<signed char> q(n);
+    const uint64_t b0 = off / 32, b1 = (off + n + 31) / 32;
+    std::vector<float> sc(b1 - b0);
+    LH_HIP(ctx, hipMemcpy(q.data(), (signed char*)b->dev + off, n, hipMemcpyDeviceToHost));
+    LH_HIP(ctx, hipMemcpy(sc.data(), b->scales + b0, (b1 - b0) * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) dst[i] = sc[(off + i) / 32 - b0] * (float)q[i];
     return LH_OK;
 }
 

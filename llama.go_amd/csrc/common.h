@@ -36,7 +36,9 @@ struct Buffer {
     float* dev = nullptr;
     uint64_t nfloats = 0;  // f32 elements (for block-int8: logical elements)
     uint64_t bytes = 0;
-    int dtype = 0;
+    int dtype = 0;              // ml.DType: 0 = f32, 7 = block-int8 (planes: int8 quants at dev, fp32 scales at `scales`)
+    float* scales = nullptr;    // block-int8: [rows][cols/32]
+    uint32_t rows = 0, cols = 0;
     uint64_t key = 0;
     int device = 0;
 };

@@ -45,18 +45,27 @@ struct Matcher {
     bool is(int i, int op) const { return i >= 0 && (uint32_t)i < total && T[i].op == op; }
     int s0(int i) const { return T[i].src0; }
     int s1(int i) const { return T[i].src1; }
-    // persistent f32 weight leaf with the expected shape -> device pointer
-    const float* weight(int i, uint32_t ne0, uint32_t ne1) const {
+    // persistent weight leaf with the expected shape -> device pointer.  Matrices may be f32 or block-int8 (all the same
+    // dtype within a model: `want`); norm vectors are always f32.
+    const float* weight(int i, uint32_t ne0, uint32_t ne1, const float** scales = nullptr, bool matrix = false) {
         if (i < 0 || (uint32_t)i >= n_leafs) return nullptr;
         const lh_tensor& t = T[i];
-        if (t.op != OP_NONE || t.storage != i || !t.buf || t.dtype != 0) return nullptr;
-        if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.ne[2] != 1 || t.ne[3] != 1 || !contiguous(t)) return nullptr;
+        if (t.op != OP_NONE || t.storage != i || !t.buf) return nullptr;
+        if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.ne[2] != 1 || t.ne[3] != 1) return nullptr;
         Buffer* b = find_buffer(ctx->ds, t.buf);
-        if (!b || b->nfloats < (uint64_t)ne0 * ne1) return nullptr;
+        if (!b || b->nfloats < (uint64_t)ne0 * ne1 || b->dtype != (int)t.dtype) return nullptr;
+        if (!matrix) return b->dtype == 0 && contiguous(t) ? b->dev : nullptr;
+        if (b->dtype != 0 && b->dtype != 7) return nullptr;
+        if (b->dtype == 0 && !contiguous(t)) return nullptr;
+        if (b->dtype == 7 && (b->rows != ne1 || b->cols != ne0)) return nullptr;
+        if (wtype_seen < 0) wtype_seen = b->dtype;
+        else if (wtype_seen != b->dtype) return nullptr;
+        if (scales) *scales = b->scales;
         return b->dev;
     }
+    int wtype_seen = -1;
     // h = Mul(gamma or Repeat(gamma, .), RMSNorm(x))  ->  returns x index, gamma pointer
-    bool norm_mul(int h, int* x, const float** gamma) const {
+    bool norm_mul(int h, int* x, const float** gamma) {
         if (!is(h, OP_MUL)) return false;
         int g = s0(h), r = s1(h);
         if (!is(r, OP_RMS_NORM)) return false;
@@ -92,14 +101,14 @@ struct Matcher {
         if (!is(x_out, OP_ADD)) return false;
         const int mm2 = s0(x_out), inpFF = s1(x_out);
         if (!is(mm2, OP_MUL_MAT)) return false;
-        if (!(L.w2 = weight(s0(mm2), F, d))) return false;
+        if (!(L.w2 = weight(s0(mm2), F, d, &L.s_w2, true))) return false;
         const int gm = s1(mm2);
         if (!is(gm, OP_MUL)) return false;
         const int sl = s0(gm), mm3 = s1(gm);
         if (!is(sl, OP_SILU) || !is(mm3, OP_MUL_MAT)) return false;
         const int mm1 = s0(sl);
         if (!is(mm1, OP_MUL_MAT)) return false;
-        if (!(L.w1 = weight(s0(mm1), d, F)) || !(L.w3 = weight(s0(mm3), d, F))) return false;
+        if (!(L.w1 = weight(s0(mm1), d, F, &L.s_w1, true)) || !(L.w3 = weight(s0(mm3), d, F, &L.s_w3, true))) return false;
         const int h2 = s1(mm1);
         if (s1(mm3) != h2) return false;
         int xff;
@@ -107,7 +116,7 @@ struct Matcher {
         // inpFF = Add(MulMat(wo, A), inpSA)                                             llama.go:336-340
         if (!is(inpFF, OP_ADD)) return false;
         const int mmo = s0(inpFF), inpSA = s1(inpFF);
-        if (!is(mmo, OP_MUL_MAT) || !(L.wo = weight(s0(mmo), d, d))) return false;
+        if (!is(mmo, OP_MUL_MAT) || !(L.wo = weight(s0(mmo), d, d, &L.s_wo, true))) return false;
         // A = Cpy(Permute(KQV), new2D)                                                  llama.go:328-333
         const int A = s1(mmo);
         if (!is(A, OP_CPY) || !is(s0(A), OP_PERMUTE)) return false;
@@ -139,7 +148,7 @@ struct Matcher {
         const int qc = s0(qr);
         if (!is(qc, OP_CPY) || !is(s0(qc), OP_MUL_MAT)) return false;
         const int mmq = s0(qc);
-        if (!(L.wq = weight(s0(mmq), d, d))) return false;
+        if (!(L.wq = weight(s0(mmq), d, d, &L.s_wq, true))) return false;
         const int h1 = s1(mmq);
         int xsa;
         if (!norm_mul(h1, &xsa, &L.attn_norm) || xsa != inpSA) return false;
@@ -164,10 +173,11 @@ struct Matcher {
             if (!is(dstv, OP_VIEW)) continue;
             const int own = T[dstv].storage;
             if (T[dstv].view_off != (uint64_t)d * ((uint64_t)il * md.ctx + p) || T[dstv].ne[0] != n * d) continue;
-            const float* w = weight(s0(src), d, d);
+            const float* wsc = nullptr;
+            const float* w = weight(s0(src), d, d, &wsc, true);
             if (!w) continue;
-            if (own == ko && !gotk) { L.wk = w; gotk = true; }
-            else if (own == vo && !gotv) { L.wv = w; gotv = true; }
+            if (own == ko && !gotk) { L.wk = w; L.s_wk = wsc; gotk = true; }
+            else if (own == vo && !gotv) { L.wv = w; L.s_wv = wsc; gotv = true; }
         }
         if (!gotk || !gotv) return false;
         *x_in = inpSA;
@@ -183,7 +193,7 @@ struct Matcher {
         md.d = T[wout].ne[0];
         md.V = T[wout].ne[1];
         if (!md.d || !md.V || ft.ne[0] != md.V) return false;
-        if (!(md.output = weight(wout, md.d, md.V))) return false;
+        if (!(md.output = weight(wout, md.d, md.V, &md.s_output, true))) return false;
         int x;
         if (!norm_mul(s1(fin), &x, &md.norm)) return false;
         // count layers by walking the residual chain down to GetRows
@@ -252,6 +262,7 @@ struct Matcher {
         if (!kb || !vb || kb == vb || vb->nfloats != kb->nfloats) return false;
         md.kc = kb->dev;
         md.vc = vb->dev;
+        md.wtype = wtype_seen < 0 ? 0 : wtype_seen;
         if ((uint64_t)past + N > md.ctx) return false;
         return true;
     }
@@ -340,6 +351,7 @@ static int run_node(lh_ctx* ctx, const lh_tensor* T, const std::vector<float*>& 
             const lh_tensor &a = T[t.src0], &b = T[t.src1];
             if (a.ne[0] != b.ne[0] || a.ne[2] != b.ne[2] || a.ne[3] != b.ne[3]) LH_FAIL(ctx, LH_ESHAPE, "MulMat: incompatible shapes (ml.go:290-292)");
             if (a.nb[0] != 4 || b.nb[0] != 4) LH_FAIL(ctx, LH_ESHAPE, "MulMat: operands must be contiguous along K (ml.go:1950, 1967)");
+            if (a.dtype != 0) LH_FAIL(ctx, LH_EUNSUPPORTED, "MulMat: block-int8 weights are only supported inside the fused LLaMA plan");
             const bool plain2d = contiguous(a) && contiguous(b) && contiguous(t) && a.ne[2] == 1 && a.ne[3] == 1 && b.ne[2] == 1 && b.ne[3] == 1 &&
                                  a.ne[0] % 4 == 0 && a.ne[0] <= 24576 && a.ne[1] >= 256;
             if (plain2d) return gemm_small_n(ctx, P[t.src0], P[t.src1], P[i], nullptr, a.ne[1], a.ne[0], b.ne[1], a.ne[0], a.ne[1], "mul_mat");

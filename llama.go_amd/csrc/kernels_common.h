@@ -6,6 +6,7 @@
 namespace lh {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 // Device-resident per-step parameters of a decode graph: kernels read `past`/`token` from here so a
 // captured hipGraph can be replayed for every position without node updates.

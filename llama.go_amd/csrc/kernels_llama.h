@@ -21,7 +21,8 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_QKV_ROPE = 2, EPI_SILU_MUL = 3 };
 enum { MAP_SINGLE = 0, MAP_BLOCK = 1, MAP_PAIR = 2 };
 
 struct GemvArgs {
-    const float* w[3];      // matrix bases (MAP_BLOCK: [wq,wk,wv]; MAP_PAIR: [w1,w3])
+    const float* w[3];      // matrix bases (MAP_BLOCK: [wq,wk,wv]; MAP_PAIR: [w1,w3]); block-int8: the int8 planes
+    const float* ws[3];     // block-int8 only: per-32-column scales [rows][K/32]
     uint32_t rows_per_mat;  // MAP_BLOCK
     uint32_t M;             // virtual rows
     uint32_t K;             // columns
@@ -84,6 +85,67 @@ __device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)
     }
 }
 
+// Epilogue, once per workgroup, all rows in parallel; cross-wave sums in fixed order -> bit-reproducible.
+// NP = partial sums per row (waves that shared the row).
+template <int EPI, int NP>
+__device__ __forceinline__ void gemv_finish(const GemvArgs& a, const float* red, uint32_t r0, uint32_t r1, uint32_t fin, float resid_pre,
+                                            double2 cs_pre, uint32_t past_pre) {
+    if (r0 + fin >= r1) return;
+    const float* p0 = red + fin * NP;
+    float s0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) s0 += p0[k];
+    const uint32_t v = r0 + fin;
+    if (EPI == EPI_STORE) {
+        a.y[v] = s0;
+    } else if (EPI == EPI_RESID) {
+        a.y[v] = __fadd_rn(s0, resid_pre);  // Add(cur, inp) ml.go:2515-2584
+    } else {
+        const float* p1 = p0 + NP;
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) s1 += p1[k];
+        if (EPI == EPI_SILU_MUL) {
+            // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+            a.y[v >> 1] = __fmul_rn(silu_ref(s0), s1);
+        } else {  // EPI_QKV_ROPE: Rope mode 0 on Q / mode 1 on the new K row (ml.go:2253-2328), K,V appended to the cache (llama.go:274-278)
+            const uint32_t d = a.d;
+            if (v < 2 * d) {
+                const uint32_t e = v < d ? v : v - d;
+                float o0, o1;
+                rope_rotate(s0, s1, cs_pre, &o0, &o1);
+                float* dst = v < d ? a.q_out + e : a.k_cache + (size_t)past_pre * d + e;
+                dst[0] = o0;
+                dst[1] = o1;
+            } else {
+                float* dst = a.v_cache + (size_t)past_pre * d + (v - 2 * d);
+                dst[0] = s0;
+                dst[1] = s1;
+            }
+        }
+    }
+}
+
+// Epilogue operands of the row (pair) this thread will finish, fetched at kernel start so their latency hides under the
+// weight stream.
+template <int EPI>
+__device__ __forceinline__ void gemv_prefetch_fin(const GemvArgs& a, uint32_t r0, uint32_t r1, uint32_t fin, float* resid_pre, double2* cs_pre,
+                                                  uint32_t* past_pre) {
+    *resid_pre = 0.f;
+    *cs_pre = double2{1.0, 0.0};
+    *past_pre = 0;
+    if (EPI == EPI_RESID) {
+        if (r0 + fin < r1) *resid_pre = a.resid[r0 + fin];
+    } else if (EPI == EPI_QKV_ROPE) {
+        *past_pre = a.sp->past;
+        const uint32_t v = r0 + fin;
+        if (v < r1 && v < 2 * a.d) {
+            const uint32_t e = v < a.d ? v : v - a.d;
+            *cs_pre = a.rope[(size_t)*past_pre * (a.hd >> 1) + ((e % a.hd) >> 1)];
+        }
+    }
+}
+
 template <int KI, int U, int TH, int PRO, int EPI, int MAP>
 __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -110,19 +172,10 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
     // Epilogue operands of this workgroup's rows are fetched now (one finishing thread per row or row pair), so their
     // latency hides under the weight stream.
     const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;  // row offset this thread finishes
-    float resid_pre = 0.f;
-    double2 cs_pre = {1.0, 0.0};
-    uint32_t past_pre = 0;
-    if (EPI == EPI_RESID) {
-        if (r0 + fin < r1) resid_pre = a.resid[r0 + fin];
-    } else if (EPI == EPI_QKV_ROPE) {
-        past_pre = a.sp->past;
-        const uint32_t v = r0 + fin;
-        if (v < r1 && v < 2 * a.d) {
-            const uint32_t e = v < a.d ? v : v - a.d;
-            cs_pre = a.rope[(size_t)past_pre * (a.hd >> 1) + ((e % a.hd) >> 1)];
-        }
-    }
+    float resid_pre;
+    double2 cs_pre;
+    uint32_t past_pre;
+    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
     // first U rows are requested before the prologue so HBM latency overlaps the norm
     f4 w[U][KI];
 #pragma unroll
@@ -165,42 +218,7 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
         }
     }
     __syncthreads();
-    // Epilogue, once, all rows of the workgroup in parallel; cross-wave sums in fixed order -> bit-reproducible.
-    if (r0 + fin < r1) {
-        const float* p0 = red + fin * NW;
-        float s0 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) s0 += p0[k];
-        const uint32_t v = r0 + fin;
-        if (EPI == EPI_STORE) {
-            a.y[v] = s0;
-        } else if (EPI == EPI_RESID) {
-            a.y[v] = __fadd_rn(s0, resid_pre);  // Add(cur, inp) ml.go:2515-2584
-        } else {
-            const float* p1 = p0 + NW;
-            float s1 = 0.f;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) s1 += p1[k];
-            if (EPI == EPI_SILU_MUL) {
-                // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
-                a.y[v >> 1] = __fmul_rn(silu_ref(s0), s1);
-            } else {  // EPI_QKV_ROPE: Rope mode 0 on Q / mode 1 on the new K row (ml.go:2253-2328), K,V appended to the cache (llama.go:274-278)
-                const uint32_t d = a.d;
-                if (v < 2 * d) {
-                    const uint32_t e = v < d ? v : v - d;
-                    float o0, o1;
-                    rope_rotate(s0, s1, cs_pre, &o0, &o1);
-                    float* dst = v < d ? a.q_out + e : a.k_cache + (size_t)past_pre * d + e;
-                    dst[0] = o0;
-                    dst[1] = o1;
-                } else {
-                    float* dst = a.v_cache + (size_t)past_pre * d + (v - 2 * d);
-                    dst[0] = s0;
-                    dst[1] = s1;
-                }
-            }
-        }
-    }
+    gemv_finish<EPI, NW>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------

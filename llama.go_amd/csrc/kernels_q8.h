@@ -1,0 +1,160 @@
+// csrc/kernels_q8.h — block-int8 weights (BASELINE.json configs[3]).
+//
+// The reference has NO quantised storage or kernels: ml.go only carries enum/size-table entries (ml.go:85-94, 123-124,
+// QK = 32 at ml.go:24) and the loader rejects every non-f32/f16 dtype (llama.go:956-959).  The format is therefore ours,
+// in the style of that ggml vintage's Q4_0 ({scale; QK quants} per block):
+//     interchange / registration format: blocks of QK = 32 weights { float d; int8 q[32] } = 36 bytes,  w = d * q
+//     quantiser (ours):                  d = max|w| / 127 (fp32 divide), q = clamp(rint(w / d), -127, 127)   (d = 0 -> q = 0)
+// Semantics the checker uses: dequantise to fp32 (one rounding: fl32(d*q)), then the fp32 MulMat of ml.go:1976-2098.
+//
+// HBM layout (memory laid out for the GPU, not for the file): two planes per matrix — int8 quants [rows][K] and fp32
+// scales [rows][K/32] — so a lane's 16-byte load is 16 consecutive weights, naturally aligned (36-byte blocks are not).
+// Algorithmic bytes per weight stay 36/32.
+//
+// GEMV: same fat-workgroup weight stream as the fp32 kernel, but a row is 4x fewer bytes, so the 1024 threads form
+// G = 1024/TPR row groups that stream G rows at once (same bytes in flight per CU).  Thread t of a group owns columns
+// 16t..16t+15 (+16*TPR*j); its 16 activations per chunk stay in registers.  Per chunk: 16 cvt + 16 fma in fp32, then
+// one fma with the block scale (the scale is factored out of the block sum; vs dequantise-first this moves one rounding,
+// ~1e-7 relative).
+#pragma once
+#include "kernels_llama.h"
+
+namespace lh {
+
+__device__ __forceinline__ u4 ld_nt_u4(const u4* p) { return __builtin_nontemporal_load(p); }
+
+__device__ __forceinline__ float dot16_q8(const u4 q, const f4 (&x)[4]) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = (int)q[k];
+        s = fmaf((float)(int)(signed char)(d), x[k].x, s);
+        s = fmaf((float)(int)(signed char)(d >> 8), x[k].y, s);
+        s = fmaf((float)(int)(signed char)(d >> 16), x[k].z, s);
+        s = fmaf((float)(d >> 24), x[k].w, s);
+    }
+    return s;
+}
+
+template <int MAP>
+__device__ __forceinline__ void row_ptr_q8(const GemvArgs& a, uint32_t v, uint32_t K, const u4** q, const float** sc) {
+    uint32_t m = 0, r = v;
+    if (MAP == MAP_BLOCK) { m = v / a.rows_per_mat; r = v - m * a.rows_per_mat; }
+    if (MAP == MAP_PAIR) { m = v & 1; r = v >> 1; }
+    *q = (const u4*)((const signed char*)a.w[m] + (size_t)r * K);
+    *sc = a.ws[m] + (size_t)r * (K >> 5);
+}
+
+// TPR threads share a row (TPR in {256, 1024}); G = 1024 / TPR rows are streamed side by side.
+template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(1024) void k_gemv_q8(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TH = 1024, G = TH / TPR, NWR = TPR / 64;
+    double* sred = (double*)smem_raw;            // [16]
+    float* red = (float*)(smem_raw + 16 * 8);    // [rows of this workgroup][NWR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid / TPR, tr = tid % TPR, wr = wave % NWR;
+    const uint32_t K = a.K, K16 = K >> 4;
+    const uint32_t nwg = gridDim.x;
+    const uint32_t npairs = a.M >> 1;
+    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
+    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+
+    f4 xr[KI][4];
+    bool act[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const uint32_t c = tr + j * TPR;
+        act[j] = c < K16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xr[j][k] = act[j] ? ((const f4*)a.x)[c * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    float resid_pre;
+    double2 cs_pre;
+    uint32_t past_pre;
+    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
+
+    // slot u of this group holds row r0 + grp + G*(m + u)
+    u4 w[U][KI];
+    float sc[U][KI];
+    auto issue = [&](int u, uint32_t row) {
+        const bool rv = row < r1;
+        const u4* qp;
+        const float* sp;
+        row_ptr_q8<MAP>(a, rv ? row : r0, K, &qp, &sp);
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const uint32_t c = tr + j * TPR;
+            if (rv && act[j]) {
+                w[u][j] = ld_nt_u4(qp + c);
+                sc[u][j] = sp[c >> 1];
+            } else {
+                w[u][j] = u4{0u, 0u, 0u, 0u};
+                sc[u][j] = 0.f;
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue(u, r0 + grp + G * u);
+
+    if (PRO == PRO_RMSNORM) {
+        // RMSNorm * gamma on the thread's own 16*KI columns; every row group holds the same x and reduces it identically
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (act[j]) {
+                    s += (double)__fmul_rn(xr[j][k].x, xr[j][k].x);
+                    s += (double)__fmul_rn(xr[j][k].y, xr[j][k].y);
+                    s += (double)__fmul_rn(xr[j][k].z, xr[j][k].z);
+                    s += (double)__fmul_rn(xr[j][k].w, xr[j][k].w);
+                }
+            }
+        s = wave_sum_f64(s);
+        if (lane == 0) sred[wave] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) tot += sred[grp * NWR + k];
+        const float scale = (float)(1.0 / sqrt(tot / (double)K + 1e-5));
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (act[j]) {
+                    const f4 g = ((const f4*)a.gamma)[(tr + j * TPR) * 4 + k];
+                    xr[j][k].x = __fmul_rn(g.x, __fmul_rn(xr[j][k].x, scale));
+                    xr[j][k].y = __fmul_rn(g.y, __fmul_rn(xr[j][k].y, scale));
+                    xr[j][k].z = __fmul_rn(g.z, __fmul_rn(xr[j][k].z, scale));
+                    xr[j][k].w = __fmul_rn(g.w, __fmul_rn(xr[j][k].w, scale));
+                }
+            }
+    }
+
+    for (uint32_t rb = r0 + grp; rb < r1; rb += G * U) {
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) s = fmaf(sc[u][j], dot16_q8(w[u][j], xr[j]), s);
+            acc[u] = s;
+            issue(u, rb + G * (U + u));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t row = rb + G * u;
+                if (row < r1) red[(row - r0) * NWR + wr] = acc[u];
+            }
+        }
+    }
+    __syncthreads();
+    gemv_finish<EPI, NWR>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
+}
+
+}  // namespace lh

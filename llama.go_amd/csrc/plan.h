@@ -7,6 +7,8 @@ namespace lh {
 
 struct LayerW {
     const float *attn_norm = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+    // block-int8 models: scale planes of the seven matrices (the pointers above are then the int8 planes)
+    const float *s_wq = nullptr, *s_wk = nullptr, *s_wv = nullptr, *s_wo = nullptr, *s_w1 = nullptr, *s_w2 = nullptr, *s_w3 = nullptr;
     bool operator==(const LayerW& o) const {
         return attn_norm == o.attn_norm && wq == o.wq && wk == o.wk && wv == o.wv && wo == o.wo && ffn_norm == o.ffn_norm && w1 == o.w1 && w2 == o.w2 && w3 == o.w3;
     }
@@ -18,11 +20,13 @@ struct ModelDesc {
     uint32_t layer0 = 0, layer1 = 0;  // layers evaluated by this plan
     uint32_t cache_layer0 = 0;        // layer stored in slot 0 of the caches
     const float *tok_emb = nullptr, *norm = nullptr, *output = nullptr;
+    const float* s_output = nullptr;  // block-int8: scales of the output matrix
+    int wtype = 0;                    // dtype of the weight matrices: 0 = f32, 7 = block-int8 (norms and embeddings stay f32)
     std::vector<LayerW> layers;       // indexed by absolute layer id
     float *kc = nullptr, *vc = nullptr;
     bool same(const ModelDesc& o) const {
         return V == o.V && d == o.d && H == o.H && hd == o.hd && L == o.L && F == o.F && ctx == o.ctx && layer0 == o.layer0 && layer1 == o.layer1 &&
-               cache_layer0 == o.cache_layer0 && tok_emb == o.tok_emb && norm == o.norm && output == o.output && kc == o.kc && vc == o.vc && layers == o.layers;
+               cache_layer0 == o.cache_layer0 && wtype == o.wtype && tok_emb == o.tok_emb && norm == o.norm && output == o.output && kc == o.kc && vc == o.vc && layers == o.layers;
     }
     bool first_stage() const { return layer0 == 0; }
     bool last_stage() const { return layer1 == L; }

@@ -3,6 +3,8 @@
 // Follows the layer schedule of llama.Eval (pkg/llama/llama.go:246-384).
 #include "plan.h"
 #include "kernels_llama.h"
+#include "kernels_gemm.h"
+#include "kernels_q8.h"
 #include <math.h>
 #include <algorithm>
 
@@ -58,8 +60,43 @@ static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_
     return 0;
 }
 
+template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
+static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
+    auto kern = k_gemv_q8<KI, U, TPR, PRO, EPI, MAP>;
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, name, bytes);
+    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// block-int8 GEMV: pick threads-per-row so the 16-byte chunks of a row fill the lanes (K = 4096 -> 256 threads x 4 rows side by side)
 template <int PRO, int EPI, int MAP>
-static int gemv(lh_ctx* ctx, const GemvArgs& a, const char* name) {
+static int gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name) {
+    if (a.K % 32 || a.M % 2) LH_FAIL(ctx, LH_ESHAPE, "gemv_q8 %s: K=%u must be a multiple of 32 and M=%u even", name, a.K, a.M);
+    if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv_q8 %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
+    const uint32_t K16 = a.K / 16;
+    const uint64_t bytes = (uint64_t)a.M * a.K / 32 * 36;
+    if (K16 <= 256) return launch_gemv_q8<1, 4, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
+    if (K16 <= 512) return launch_gemv_q8<2, 2, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
+    if (K16 <= 1024) return launch_gemv_q8<1, 6, 1024, PRO, EPI, MAP>(ctx, a, name, bytes);
+    if (K16 <= 2048) return launch_gemv_q8<2, 4, 1024, PRO, EPI, MAP>(ctx, a, name, bytes);
+    LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv_q8 %s: K=%u exceeds the supported 32768 columns", name, a.K);
+}
+
+template <int PRO, int EPI, int MAP>
+static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name);
+
+template <int PRO, int EPI, int MAP>
+static int gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, int wtype = 0) {
+    return wtype == 7 ? gemv_q8<PRO, EPI, MAP>(ctx, a, name) : gemv_f32<PRO, EPI, MAP>(ctx, a, name);
+}
+
+template <int PRO, int EPI, int MAP>
+static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     if (a.K % 4 || a.M % 2) LH_FAIL(ctx, LH_ESHAPE, "gemv %s: K=%u must be a multiple of 4 and M=%u even", name, a.K, a.M);
     // one finishing thread per row and rows*16 partial sums in LDS per workgroup
     if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
@@ -90,10 +127,28 @@ static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
     return 0;
 }
 
-// Y[n][M] = X[n][K] . W[M][K]^T (+ resid), weights streamed once per chunk of NC activation rows.
+static int gemm_mfma(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n, uint32_t ldx,
+                     uint32_t ldy, const char* name) {
+    static bool flags[16] = {};
+    const size_t lds = (size_t)4 * GBK * GLD * sizeof(float);
+    int rc = set_lds_once(ctx, k_gemm_mfma, lds, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    GemmArgs a;
+    a.x = x; a.w = w; a.y = y; a.r = resid; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
+    const uint32_t tiles = ((n + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
+    ProfScope ps(ctx->stream, name, (uint64_t)M * K * 4);
+    hipLaunchKernelGGL(k_gemm_mfma, dim3(tiles), dim3(256), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// Y[n][M] = X[n][K] . W[M][K]^T (+ resid).  N >= 32: fp32 MFMA GEMM (compute-bound side); smaller N: the weight-streaming
+// kernel with NC activation rows in registers (HBM-bound side, weights read once per NC rows).
 int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n,
                  uint32_t ldx, uint32_t ldy, const char* name) {
     if (K % 4) LH_FAIL(ctx, LH_ESHAPE, "gemm %s: K=%u must be a multiple of 4", name, K);
+    if (n >= 32 && K % GBK == 0 && ldx % 4 == 0) return gemm_mfma(ctx, w, x, y, resid, M, K, n, ldx, ldy, name);
     const uint32_t K4 = K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
     const uint32_t NCmax = ki <= 2 ? 8 : 4;
@@ -219,7 +274,7 @@ void destroy_plans(lh_ctx* ctx) {
 
 // ---- decode step (N = 1): 5 kernels per layer --------------------------------------------------------
 static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, bool argmax_advance, uint32_t* argmax_out,
-                          const uint32_t* tokens_dev = nullptr) {
+                          const uint32_t* tokens_dev = nullptr, uint32_t logits_row = 0) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     const double2* rope = ctx->ds->rope_table;
@@ -242,10 +297,10 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
         {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K) -> K,V appended to the cache   (llama.go:255-297)
             GemvArgs a = {};
-            a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.rows_per_mat = m.d; a.M = 3 * m.d; a.K = m.d;
+            a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.ws[0] = L.s_wq; a.ws[1] = L.s_wk; a.ws[2] = L.s_wv; a.rows_per_mat = m.d; a.M = 3 * m.d; a.K = m.d;
             a.x = x; a.gamma = L.attn_norm; a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot;
             a.rope = rope; a.hd = m.hd; a.d = m.d; a.sp = sp;
-            if ((rc = gemv<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "gemv_qkv_rope"))) return rc;
+            if ((rc = gemv<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "gemv_qkv_rope", m.wtype))) return rc;
         }
         {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
             AttnArgs a = {};
@@ -254,27 +309,27 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         }
         {   // wo + residual   (llama.go:336-340)
             GemvArgs a = {};
-            a.w[0] = L.wo; a.M = m.d; a.K = m.d; a.x = p->attn; a.resid = x; a.y = xb;
-            if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_wo_resid"))) return rc;
+            a.w[0] = L.wo; a.ws[0] = L.s_wo; a.M = m.d; a.K = m.d; a.x = p->attn; a.resid = x; a.y = xb;
+            if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_wo_resid", m.wtype))) return rc;
         }
         {   // RMSNorm*gamma -> w1|w3 -> silu(w1 h) * (w3 h)   (llama.go:346-361)
             GemvArgs a = {};
-            a.w[0] = L.w1; a.w[1] = L.w3; a.M = 2 * m.F; a.K = m.d; a.x = xb; a.gamma = L.ffn_norm; a.y = p->g;
-            if ((rc = gemv<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "gemv_w1w3_silu"))) return rc;
+            a.w[0] = L.w1; a.w[1] = L.w3; a.ws[0] = L.s_w1; a.ws[1] = L.s_w3; a.M = 2 * m.F; a.K = m.d; a.x = xb; a.gamma = L.ffn_norm; a.y = p->g;
+            if ((rc = gemv<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "gemv_w1w3_silu", m.wtype))) return rc;
         }
         {   // w2 + residual   (llama.go:363-366)
             const bool last = il + 1 == m.layer1;
             GemvArgs a = {};
-            a.w[0] = L.w2; a.M = m.d; a.K = m.F; a.x = p->g; a.resid = xb;
+            a.w[0] = L.w2; a.ws[0] = L.s_w2; a.M = m.d; a.K = m.F; a.x = p->g; a.resid = xb;
             a.y = (last && !m.last_stage()) ? x_out : xa;
-            if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_w2_resid"))) return rc;
+            if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_w2_resid", m.wtype))) return rc;
         }
         x = xa;
     }
     if (m.last_stage()) {   // final RMSNorm*gamma -> lm_head   (llama.go:374-384)
         GemvArgs a = {};
-        a.w[0] = m.output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits;
-        if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead"))) return rc;
+        a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
+        if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
         if ((argmax_advance || argmax_out) && !g_prepare_only) {
             ProfScope ps(ctx->stream, "argmax", (uint64_t)m.V * 4);
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)p->logits, m.V, (StepParams*)sp, p->out_tokens_dev,
@@ -364,6 +419,18 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
+    if (m.wtype == 7) {
+        // block-int8 prefill: the dequantising GEMM is not built yet; evaluate the n tokens as n causal single-token steps
+        // (bit-identical to what the decode path produces for them), logits row i from step i like llama.go:384.
+        if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EUNSUPPORTED, "block-int8 prefill on a pipeline stage is not supported yet");
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t slot = 1 + (g_slot_counter++ % (SP_SLOTS - 1));
+            if ((rc = upload_step_params(p, slot, tokens_host[i], past + i, 0))) return rc;
+            if ((rc = enqueue_decode(p, p->sp_dev + slot, nullptr, nullptr, false, nullptr, nullptr, i))) return rc;
+            if ((i + 1) % (SP_SLOTS - 2) == 0) LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned parameter slots are recycled
+        }
+        return 0;
+    }
     // ---- prefill, N > 1 rows
     const double2* rope = ctx->ds->rope_table;
     const float* x = p->xa;
@@ -436,7 +503,7 @@ int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out) {
     if (!ctx || !desc || !out) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: NULL argument");
     *out = nullptr;
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    if (desc->weight_dtype != 0) LH_FAIL(ctx, LH_EUNSUPPORTED, "lh_llama_create: weight dtype %d not supported yet", desc->weight_dtype);
+    if (desc->weight_dtype != 0 && desc->weight_dtype != 7) LH_FAIL(ctx, LH_EUNSUPPORTED, "lh_llama_create: weight dtype %d not supported", desc->weight_dtype);
     ModelDesc md;
     md.V = desc->vocab; md.d = desc->embd; md.H = desc->heads; md.L = desc->layers; md.F = desc->ff; md.ctx = desc->ctx;
     if (!md.H || !md.d || md.d % md.H) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: bad embd/heads");
@@ -444,11 +511,23 @@ int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out) {
     md.layer0 = desc->layer0; md.layer1 = desc->layer1 ? desc->layer1 : desc->layers;
     if (md.layer0 >= md.layer1 || md.layer1 > md.L) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: bad layer range [%u,%u)", md.layer0, md.layer1);
     md.cache_layer0 = md.layer0;
+    md.wtype = desc->weight_dtype;
     auto need = [&](lh_buf b, uint64_t n, const char* what, const float** dst) -> int {
         Buffer* bf = find_buffer(ctx->ds, b);
         if (!bf) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: %s is not a registered buffer", what);
         if (bf->nfloats < n) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: %s has %llu floats, needs %llu", what, (unsigned long long)bf->nfloats, (unsigned long long)n);
+        if (bf->dtype != 0) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: %s must be f32", what);
         *dst = bf->dev;
+        return 0;
+    };
+    // weight matrix: f32, or block-int8 planes when the model is quantised
+    auto needw = [&](lh_buf b, uint64_t rows, uint64_t cols, const char* what, const float** dst, const float** sc) -> int {
+        Buffer* bf = find_buffer(ctx->ds, b);
+        if (!bf) LH_FAIL(ctx, LH_EINVAL, "lh_llama_create: %s is not a registered buffer", what);
+        if (bf->nfloats < rows * cols || bf->dtype != md.wtype) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: %s has the wrong size or dtype", what);
+        if (md.wtype == 7 && (bf->rows != rows || bf->cols != cols)) LH_FAIL(ctx, LH_ESHAPE, "lh_llama_create: %s block-int8 shape mismatch", what);
+        *dst = bf->dev;
+        *sc = bf->scales;
         return 0;
     };
     int rc;
@@ -456,21 +535,21 @@ int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out) {
     if (md.first_stage() && (rc = need(desc->tok_embeddings, V * d, "tok_embeddings", &md.tok_emb))) return rc;
     if (md.last_stage()) {
         if ((rc = need(desc->norm, d, "norm", &md.norm))) return rc;
-        if ((rc = need(desc->output, V * d, "output", &md.output))) return rc;
+        if ((rc = needw(desc->output, V, d, "output", &md.output, &md.s_output))) return rc;
     }
     md.layers.resize(md.L);
     for (uint32_t il = md.layer0; il < md.layer1; ++il) {
         const lh_llama_layer& s = desc->layer[il];
         LayerW& L = md.layers[il];
         if ((rc = need(s.attention_norm, d, "attention_norm", &L.attn_norm))) return rc;
-        if ((rc = need(s.wq, d * d, "wq", &L.wq))) return rc;
-        if ((rc = need(s.wk, d * d, "wk", &L.wk))) return rc;
-        if ((rc = need(s.wv, d * d, "wv", &L.wv))) return rc;
-        if ((rc = need(s.wo, d * d, "wo", &L.wo))) return rc;
+        if ((rc = needw(s.wq, d, d, "wq", &L.wq, &L.s_wq))) return rc;
+        if ((rc = needw(s.wk, d, d, "wk", &L.wk, &L.s_wk))) return rc;
+        if ((rc = needw(s.wv, d, d, "wv", &L.wv, &L.s_wv))) return rc;
+        if ((rc = needw(s.wo, d, d, "wo", &L.wo, &L.s_wo))) return rc;
         if ((rc = need(s.ffn_norm, d, "ffn_norm", &L.ffn_norm))) return rc;
-        if ((rc = need(s.w1, d * F, "w1", &L.w1))) return rc;
-        if ((rc = need(s.w2, d * F, "w2", &L.w2))) return rc;
-        if ((rc = need(s.w3, d * F, "w3", &L.w3))) return rc;
+        if ((rc = needw(s.w1, F, d, "w1", &L.w1, &L.s_w1))) return rc;
+        if ((rc = needw(s.w2, d, F, "w2", &L.w2, &L.s_w2))) return rc;
+        if ((rc = needw(s.w3, F, d, "w3", &L.w3, &L.s_w3))) return rc;
     }
     const float *kc, *vc;
     const uint64_t kvn = d * (md.layer1 - md.layer0) * md.ctx;

@@ -304,6 +304,7 @@ struct llama_layer { ml_tensor *attentionNorm, *wq, *wk, *wv, *wo, *ffn_norm, *w
 struct llama_model {  // llama.go:181-193
     llama_hparams hp;
     uint32_t ffSize;
+    int wtype = ML_TYPE_F32;  // dtype of the weight matrices (ML_TYPE_Q8_0 after llamago_QuantizeModelQ8)
     ml_tensor *tokEmbeddings = nullptr, *norm = nullptr, *output = nullptr;
     std::vector<llama_layer> layers;
     uint32_t layer0, layer1;
@@ -702,6 +703,7 @@ static lh_llama* resident(llama_context* c) {
     d.output = m->output ? m->output->buf : 0;
     d.layer = ls.data();
     d.k_cache = c->K->buf; d.v_cache = c->V->buf;
+    d.weight_dtype = m->wtype;
     if (lh_llama_create(c->mlctx->hip, &d, &c->resident)) { g_err = lh_last_error(c->mlctx->hip); return nullptr; }
     return c->resident;
 }
@@ -725,6 +727,29 @@ int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_d
     if (lh_llama_stage(r, tokens, (const uint32_t*)tokens_dev, (const float*)x_in_dev, (float*)x_out_dev, n, past, (float*)logits_dev, (uint32_t*)argmax_dev))
         return halt_rc(lh_last_error(c->mlctx->hip));
     return 0;
+}
+// Block-int8 (format in csrc/kernels_q8.h): quantise every weight MATRIX of the model in HBM
+// (norm vectors and the embedding table, which is only gathered from, stay f32) and release the f32 copies.
+int llamago_QuantizeModelQ8(llama_model* m) {
+    if (m->wtype == ML_TYPE_Q8_0) return 0;
+    lh_ctx* h = model_ctx();
+    if (!h) return 1;
+    auto q = [&](ml_tensor* t) -> int {
+        if (!t) return 0;
+        lh_buf nb = 0;
+        if (lh_buf_quantize_q8(h, t->buf, t->ne[1], t->ne[0], &nb)) return halt_rc(lh_last_error(h));
+        lh_buf_free(h, t->buf);
+        t->buf = nb;
+        t->type = ML_TYPE_Q8_0;
+        return 0;
+    };
+    int rc = q(m->output);
+    for (uint32_t i = m->layer0; i < m->layer1 && !rc; i++) {
+        llama_layer& l = m->layers[i];
+        rc |= q(l.wq); rc |= q(l.wk); rc |= q(l.wv); rc |= q(l.wo); rc |= q(l.w1); rc |= q(l.w2); rc |= q(l.w3);
+    }
+    if (!rc) m->wtype = ML_TYPE_Q8_0;
+    return rc;
 }
 int llamago_Sync(llama_context* c) { return lh_ctx_sync(c->mlctx->hip) ? halt_rc(lh_last_error(c->mlctx->hip)) : 0; }
 

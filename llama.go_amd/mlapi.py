@@ -231,6 +231,15 @@ class Model:
         if self.ml.lib.llama_SaveModel(self.h, os.fsencode(path), ftype):
             raise MLError("llama_SaveModel failed")
 
+    def QuantizeQ8(self):
+        """Block-int8 weight matrices (our format): product quantises in HBM; a checker library replaces
+        its weights by the dequantised values."""
+        f = self.ml.lib.llamago_QuantizeModelQ8
+        f.restype, f.argtypes = C.c_int, [VP]
+        if f(self.h):
+            raise MLError(f"llamago_QuantizeModelQ8: {self.ml.last_error()}")
+        return self
+
     def NewContext(self, ctxSize=128, maxThreads=1, useAVX=False, useNEON=False):
         h = self.ml._chk(self.ml.lib.llama_NewContext(self.h, ctxSize, maxThreads, int(useAVX), int(useNEON)), "llama_NewContext")
         return Context(self, h)

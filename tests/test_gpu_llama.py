@@ -58,6 +58,20 @@ def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     assert greedy_margin(lg_o) > 10 * TOL, "test seed has a near-tie; pick another"
 
 
+@pytest.mark.parametrize("n_prompt", [33, 64, 100])
+def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
+    """N >= 32 tokens in one Eval run the fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) + blocked attention; the next decode steps
+    read the KV cache that prefill wrote."""
+    rng = np.random.default_rng(n_prompt)
+    prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n_prompt)]
+    out = decode_both(product, oracle, "small", 128, prompt, 4)
+    toks_h, lg_h = out["hip"]
+    toks_o, lg_o = out["orc"]
+    assert out["fused"] == 1
+    assert rel(lg_h, lg_o) <= TOL
+    assert toks_h == toks_o
+
+
 def test_generic_path_matches_fused_and_oracle(product, oracle):
     """Node-by-node execution of the very same graph (what an arbitrary ml graph gets) agrees with both."""
     hp = make_hparams(**SHAPES["tiny"], ctx=32)
@@ -170,3 +184,29 @@ def test_7b_shape_slice_matches_oracle(product, oracle, layers):
     assert out["fused"] == 1
     assert rel(lg_h, lg_o) <= TOL
     assert toks_h == toks_o
+
+
+@pytest.mark.parametrize("shape,layers,ctx", [("tiny", None, 32), ("small", None, 64), ("7B", 2, 32)])
+def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, layers, ctx):
+    """BASELINE config 4: block-int8 weight matrices (format ours: the reference has none).  The checker runs the fp32 path on
+    the dequantised weights; the GPU streams int8 planes + scales and must agree (token ids exact, 1e-4 on logits)."""
+    kw = dict(SHAPES[shape])
+    if layers:
+        kw["layers"] = layers
+    hp = make_hparams(**kw, ctx=ctx)
+    prompt = [1, 5, 9, 200, 17, 3, 44, 100] if shape != "7B" else PROMPT
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 321).QuantizeQ8()
+        if name == "hip":
+            wq_h = product.read(None, m.tensor("layers.1.attention.wq.weight"))
+        else:
+            wq_o = oracle.read(None, m.tensor("layers.1.attention.wq.weight"))
+        c = m.NewContext(ctx, 64, False)
+        res[name] = c.GreedyDecode(prompt, 6)
+        c.free()
+        m.free()
+    assert np.array_equal(wq_h, wq_o), "GPU and CPU quantisers disagree"  # value equality: int8 0 has no sign, rint() may give -0.0
+    (th, lh_), (to, lo) = res["hip"], res["orc"]
+    assert rel(lh_, lo) <= TOL
+    assert th == to

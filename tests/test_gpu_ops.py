@@ -80,7 +80,8 @@ def assert_close(out, tol):
         assert close(a, b, tol), f"rel err {np.abs(a - b).max() / max(np.abs(b).max(), 1e-30):.3e} > {tol}"
 
 
-@pytest.mark.parametrize("K,M,N", [(4096, 512, 1), (11008, 256, 1), (4096, 300, 3), (128, 7, 5), (24, 128, 1), (100, 33, 2), (4, 2, 1)])
+@pytest.mark.parametrize("K,M,N", [(4096, 512, 1), (11008, 256, 1), (4096, 300, 3), (128, 7, 5), (24, 128, 1), (100, 33, 2), (4, 2, 1),
+                                   (4096, 512, 64), (1024, 384, 130), (11008, 256, 33)])
 def test_mul_mat_weights(pair, K, M, N):
     r = rng(K + M + N)
     w = r.standard_normal((M, K)).astype(np.float32) / np.sqrt(K)
