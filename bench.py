@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the bounded CPU-baseline sample")
     ap.add_argument("--pods", type=int, default=0, help="streams in flight for N > 1 (default N)")
+    ap.add_argument("--int8", action="store_true", help="BASELINE config 4: block-int8 weight matrices (36 B per 32 weights); not the headline metric")
     args = ap.parse_args()
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before any OpenMP runtime loads (CPU baseline threads)
@@ -114,6 +115,8 @@ def main():
     result = {}
     if world == 1:
         model = prod.NewSyntheticModel(hp, SEED)
+        if args.int8:
+            model.QuantizeQ8()
         F = model.ffSize
         ctx = model.NewContext(ctx_size, 1)
         logits0 = ctx.Eval(PROMPT, 0)  # prefill through ml.GraphCompute (fused plan)
@@ -146,6 +149,8 @@ def main():
             os.environ.setdefault("OMP_WAIT_POLICY", "passive")
             t_gen = time.perf_counter()
             om = orc.NewSyntheticModel(hp, SEED)
+            if args.int8:
+                om.QuantizeQ8()
             t_gen = time.perf_counter() - t_gen
             nsteps = max(1, min(args.cpu_steps, K))
             # (B) "--avx-equivalent": the reference's own vdot (oracle/_ref), rows over all host cores
@@ -285,12 +290,15 @@ def main():
 
     Tbar = P0 + (K + 1) / 2.0
     wbytes, kvbytes = bytes_per_token(d, L, F, V, Tbar)
+    if args.int8:  # matrices at 36/32 B per weight, norms + one embedding row stay f32
+        mat = 4 * (L * (4 * d * d + 3 * d * F) + V * d)
+        wbytes = (wbytes - mat) + mat * 36 // 128
     tok_s = tokens_total / dt
     line = {
-        "metric": "decode tokens/s LLaMA-7B fp32; % HBM-read roofline",
+        "metric": "decode tokens/s LLaMA-7B fp32; % HBM-read roofline" if not args.int8 else "decode tokens/s LLaMA-7B block-int8 weights (config 4); % HBM-read roofline",
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random-init weights, counter-based generator seed 1234; fixed 8-token prompt)",
+        "dtype": "f32" if not args.int8 else "f32 activations/accumulation, int8 block-quantised weights", "data": "synthetic (random-init weights, counter-based generator seed 1234; fixed 8-token prompt)",
         "config": {"workload": f"LLaMA-{args.shape} fp32 greedy decode, context {ctx_size}, positions {P0}..{P0 + K - 1}, batch 1 per stream",
                    "layers": L, "embd": d, "ff": F, "vocab": V, "streams": pods, "parallelism": parallelism},
         "roofline_token": {

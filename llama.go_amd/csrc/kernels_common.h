@@ -38,6 +38,13 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
     return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
+// Full 64-lane sum in 6 DPP adds; the total is valid in LANE 63 only (row_bcast15 / row_bcast31 are gfx9 DPP controls).
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = row16_sum(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2,3
+    return v;
+}
 // Sum over aligned groups of 32 lanes (two DPP rows); result valid in every lane of the group.
 __device__ __forceinline__ float half_wave_sum(float v) {
     v = row16_sum(v);

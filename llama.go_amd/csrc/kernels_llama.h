@@ -177,13 +177,17 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
     uint32_t past_pre;
     gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
     // first U rows are requested before the prologue so HBM latency overlaps the norm
+    // Every load is UNCONDITIONAL: out-of-range rows / inactive lanes read a cache-resident dummy address instead of
+    // branching.  Loads inside exec-masked branches make hipcc fall back to s_waitcnt vmcnt(0) right after the refills
+    // (it cannot count them), which serialises the stream with the arithmetic.
+    const f4* dummy = (const f4*)a.x;
     f4 w[U][KI];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const bool rv = r0 + u < r1;
         const f4* p = row_ptr<MAP>(a, rv ? r0 + u : r0, K4);
 #pragma unroll
-        for (int j = 0; j < KI; ++j) w[u][j] = (rv && act[j]) ? ld_nt(p + tid + j * TH) : f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((rv && act[j]) ? p + tid + j * TH : dummy);
     }
     if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, gr, a.K, sred);
 
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
                 s = fmaf(c.y, xr[j].y, s);
                 s = fmaf(c.z, xr[j].z, s);
                 s = fmaf(c.w, xr[j].w, s);
-                if (nv && act[j]) w[u][j] = ld_nt(p + tid + j * TH);
+                w[u][j] = ld_nt((nv && act[j]) ? p + tid + j * TH : dummy);
             }
             acc[u] = s;
         }
@@ -252,13 +256,14 @@ __global__ __launch_bounds__(TH) void k_gemv_cols(const GemmColsArgs a) {
 #pragma unroll
         for (int j = 0; j < KI; ++j)
             xr[c][j] = (act[j] && (uint32_t)c < a.ncols) ? ((const f4*)(a.x + (size_t)c * a.ldx))[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    const f4* dummy = (const f4*)a.x;  // unconditional loads (see k_gemv)
     f4 w[U][KI];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const bool rv = r0 + u < r1;
         const f4* p = (const f4*)a.w + (size_t)(rv ? r0 + u : r0) * K4;
 #pragma unroll
-        for (int j = 0; j < KI; ++j) w[u][j] = (rv && act[j]) ? ld_nt(p + tid + j * TH) : f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((rv && act[j]) ? p + tid + j * TH : dummy);
     }
     int buf = 0;
     for (uint32_t r = r0; r < r1; r += U) {
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(TH) void k_gemv_cols(const GemmColsArgs a) {
                     s = fmaf(cw.w, xr[c][j].w, s);
                     acc[u][c] = s;
                 }
-                if (nv && act[j]) w[u][j] = ld_nt(p + tid + j * TH);
+                w[u][j] = ld_nt((nv && act[j]) ? p + tid + j * TH : dummy);
             }
         }
 #pragma unroll

@@ -23,17 +23,20 @@ namespace lh {
 
 __device__ __forceinline__ u4 ld_nt_u4(const u4* p) { return __builtin_nontemporal_load(p); }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// 16 int8 x 16 fp32: two independent accumulator PAIRS so the FMAs can issue as v_pk_fma_f32 (2 FMAs per instruction)
 __device__ __forceinline__ float dot16_q8(const u4 q, const f4 (&x)[4]) {
-    float s = 0.f;
+    f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int d = (int)q[k];
-        s = fmaf((float)(int)(signed char)(d), x[k].x, s);
-        s = fmaf((float)(int)(signed char)(d >> 8), x[k].y, s);
-        s = fmaf((float)(int)(signed char)(d >> 16), x[k].z, s);
-        s = fmaf((float)(d >> 24), x[k].w, s);
+        const f2 w0 = {(float)(int)(signed char)(d), (float)(int)(signed char)(d >> 8)};
+        const f2 w1 = {(float)(int)(signed char)(d >> 16), (float)(d >> 24)};
+        a0 = __builtin_elementwise_fma(w0, f2{x[k].x, x[k].y}, a0);
+        a1 = __builtin_elementwise_fma(w1, f2{x[k].z, x[k].w}, a1);
     }
-    return s;
+    return (a0.x + a0.y) + (a1.x + a1.y);
 }
 
 template <int MAP>
@@ -75,28 +78,27 @@ __global__ __launch_bounds__(1024) void k_gemv_q8(const GemvArgs a) {
     uint32_t past_pre;
     gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
 
-    // slot u of this group holds row r0 + grp + G*(m + u)
+    // slot u of this group holds row r0 + grp + G*(m + u).  Every load is unconditional (see k_gemv).
     u4 w[U][KI];
     float sc[U][KI];
-    auto issue = [&](int u, uint32_t row) {
-        const bool rv = row < r1;
-        const u4* qp;
-        const float* sp;
-        row_ptr_q8<MAP>(a, rv ? row : r0, K, &qp, &sp);
+    auto fetch = [&](u4 (&wd)[U][KI], float (&sd)[U][KI], uint32_t row_base) {
 #pragma unroll
-        for (int j = 0; j < KI; ++j) {
-            const uint32_t c = tr + j * TPR;
-            if (rv && act[j]) {
-                w[u][j] = ld_nt_u4(qp + c);
-                sc[u][j] = sp[c >> 1];
-            } else {
-                w[u][j] = u4{0u, 0u, 0u, 0u};
-                sc[u][j] = 0.f;
+        for (int u = 0; u < U; ++u) {
+            const uint32_t row = row_base + G * u;
+            const bool rv = row < r1;
+            const u4* qp;
+            const float* sp;
+            row_ptr_q8<MAP>(a, rv ? row : r0, K, &qp, &sp);
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const uint32_t c = tr + j * TPR;
+                const bool ok = rv && act[j];
+                wd[u][j] = ld_nt_u4(ok ? qp + c : (const u4*)a.x);
+                sd[u][j] = *(ok ? sp + (c >> 1) : a.x);
             }
         }
     };
-#pragma unroll
-    for (int u = 0; u < U; ++u) issue(u, r0 + grp + G * u);
+    fetch(w, sc, r0 + grp);
 
     if (PRO == PRO_RMSNORM) {
         // RMSNorm * gamma on the thread's own 16*KI columns; every row group holds the same x and reduces it identically
@@ -133,7 +135,13 @@ __global__ __launch_bounds__(1024) void k_gemv_q8(const GemvArgs a) {
             }
     }
 
+    // The arithmetic per byte is 12x the fp32 kernel's (16 cvt + 16 fma per 16-byte load), so the next batch is requested
+    // into a SECOND register set at the top of the iteration: with in-place refills hipcc sinks the loads below the dot
+    // products (WAR on the slot registers) and the wave then idles a full memory latency per batch.
     for (uint32_t rb = r0 + grp; rb < r1; rb += G * U) {
+        u4 wn[U][KI];
+        float scn[U][KI];
+        fetch(wn, scn, rb + G * U);
         float acc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -141,17 +149,20 @@ __global__ __launch_bounds__(1024) void k_gemv_q8(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < KI; ++j) s = fmaf(sc[u][j], dot16_q8(w[u][j], xr[j]), s);
             acc[u] = s;
-            issue(u, rb + G * (U + u));
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
-        if (lane == 0) {
+        for (int u = 0; u < U; ++u) acc[u] = wave_sum_lane63(acc[u]);
+        if (lane == 63) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t row = rb + G * u;
                 if (row < r1) red[(row - r0) * NWR + wr] = acc[u];
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < KI; ++j) { w[u][j] = wn[u][j]; sc[u][j] = scn[u][j]; }
     }
     __syncthreads();
     gemv_finish<EPI, NWR>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);

@@ -1,6 +1,7 @@
 // tools/kernel_ablate.hip — ablation of the PRODUCT GEMV kernel (csrc/kernels_llama.h) on 7B shapes: bare stream vs
 // + row mapping vs + RMSNorm prologue vs + fused epilogue.  Not product code.  Cycles through a 6 GiB weight pool.
 #include "../llama.go_amd/csrc/kernels_llama.h"
+#include "../llama.go_amd/csrc/kernels_q8.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -49,6 +50,34 @@ int main() {
     const uint32_t d = 4096, F = 11008, V = 32000;
     auto base = [&](uint32_t M, uint32_t K) { GemvArgs a = {}; a.w[0] = pool; a.M = M; a.K = K; a.x = x; a.gamma = g; a.y = y; a.resid = res; a.q_out = q; a.k_cache = kc; a.v_cache = vc; a.rope = rope; a.hd = 128; a.d = d; a.sp = sp; a.rows_per_mat = d; return a; };
 
+    if (getenv("ABL_Q8")) {
+        printf("[q8 22016x4096, 36/32 B per weight]\n");
+        GemvArgs a = base(2 * F, d); size_t B = (size_t)2 * F * d / 32 * 36;
+        a.ws[0] = pool + (size_t)2 * F * d / 4;   // scales somewhere inside the pool (values irrelevant for timing)
+        auto runq = [&](const char* label, auto kern) {
+            const size_t lds = 96 * 1024;
+            CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            size_t nmat = POOL / (B + (1 << 20)); int iters = 60;
+            auto launch = [&](int i) { GemvArgs b = a; float* bs = pool + (size_t)(i % nmat) * ((B + (1 << 20)) / 4); b.w[0] = bs; b.ws[0] = bs + (size_t)2 * F * d / 4; b.w[1] = (const float*)((const char*)bs + (size_t)F * d); b.ws[1] = b.ws[0] + (size_t)F * d / 32;
+                                       hipLaunchKernelGGL(kern, dim3(nCU), dim3(1024), lds, st, b); };
+            for (int i = 0; i < 3; ++i) launch(i);
+            CK(hipStreamSynchronize(st)); CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) launch(i);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+            printf("  %-58s %8.2f us  %7.1f GB/s\n", label, us, B / us / 1e3); CK(hipGetLastError());
+        };
+        runq("q8 TPR256 U2 plain/store", k_gemv_q8<1, 2, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>);
+        runq("q8 TPR256 U4 plain/store", k_gemv_q8<1, 4, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>);
+        runq("q8 TPR256 U6 plain/store", k_gemv_q8<1, 6, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>);
+        runq("q8 TPR256 U8 plain/store", k_gemv_q8<1, 8, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>);
+        runq("q8 TPR1024 KI1 U8 plain/store (256 of 1024 lanes active)", k_gemv_q8<1, 8, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>);
+        runq("q8 TPR256 U1 plain/store", k_gemv_q8<1, 1, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>);
+        runq("q8 TPR256 U2 rmsnorm/silu/pair", k_gemv_q8<1, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>);
+        runq("q8 TPR256 U4 rmsnorm/silu/pair", k_gemv_q8<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>);
+        printf("done\n");
+        return 0;
+    }
     printf("[w1w3 2x11008x4096]\n");
     { GemvArgs a = base(2 * F, d); size_t B = (size_t)2 * F * d * 4;
       run("U4 plain/store/single (bare stream)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);
