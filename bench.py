@@ -84,11 +84,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # BENCH_SHARED_GPU=1: functional test of the N > 1 path on a box with ONE GPU (all ranks on device 0, p2p staged through
+    # the host over gloo).  Never a measurement: RCCL cannot place two ranks on one device.
+    shared_gpu = os.environ.get("BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     os.environ["LLAMAGO_DEVICE"] = str(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as graft
     if rank == 0:
@@ -209,8 +217,13 @@ def main():
         R = world
         pods = args.pods or R
         l0, l1 = rank * L // R, (rank + 1) * L // R
-        stream = torch.cuda.current_stream().cuda_stream
-        prod.lib.llamago_SetStream(C.c_void_p(stream))
+        # ONE explicit stream for everything: torch's copies and (R)CCL work order themselves against torch's CURRENT stream, so the
+        # library must enqueue on that very stream (the default stream's handle is NULL, which the C-ABI reads as "make a private
+        # stream" — a private stream would race with the p2p traffic).
+        tstream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(tstream)
+        assert tstream.cuda_stream != 0
+        prod.lib.llamago_SetStream(C.c_void_p(tstream.cuda_stream))
         model = prod.NewSyntheticModel(hp, SEED, l0, l1)
         F = model.ffSize
         ctxs = [model.NewContext(ctx_size, 1) for _ in range(pods)]
@@ -260,7 +273,11 @@ def main():
                 tok_first[p].copy_(tok_in[p])
 
         from llama_go_amd.pipeline import PipelineRunner
-        runner = PipelineRunner(rank, R, pods, dist, stage_cb, send_buf, recv_buf, on_recv)
+        pdist = dist
+        if shared_gpu:
+            from llama_go_amd.pipeline import HostStagedDist
+            pdist = HostStagedDist(dist)
+        runner = PipelineRunner(rank, R, pods, pdist, stage_cb, send_buf, recv_buf, on_recv)
         runner.run_phase(1 + W, "warm")   # prefill + W warm-up decode steps per stream; the pipeline drains at the end
         sync_all()
         t0 = time.perf_counter()
@@ -268,7 +285,7 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         tokens_total = K * pods
-        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
         prof = profile_decode(ctxs[0], 1, P0, repeats=2)

@@ -89,3 +89,44 @@ class PipelineRunner:
 def layer_range(rank: int, world: int, layers: int):
     """Contiguous block of layers owned by `rank` (7B: 32/16/8/4 layers for 1/2/4/8 ranks)."""
     return rank * layers // world, (rank + 1) * layers // world
+
+
+class HostStagedDist:
+    """torch.distributed look-alike for FUNCTIONAL testing of the N > 1 path when every rank shares one GPU (RCCL refuses two
+    ranks on one device): device tensors are bounced through host memory and exchanged over gloo.  Not a performance path."""
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def __init__(self, dist):
+        self.d = dist
+        self.isend, self.irecv = "isend", "irecv"
+
+    def batch_isend_irecv(self, ops):
+        reqs, post = [], []
+        for o in ops:
+            if o.op == "isend":
+                host = o.tensor.detach().cpu()
+                post.append((None, host))  # keep the host copy alive until the send completed
+                reqs.append(self.d.isend(host, o.peer))
+            else:
+                host = o.tensor.detach().cpu()
+                reqs.append(self.d.irecv(host, o.peer))
+                post.append((o.tensor, host))
+
+        class _Done:
+            def __init__(self, reqs, post):
+                self.reqs, self.post, self.done = reqs, post, False
+
+            def wait(self):
+                if self.done:
+                    return
+                for r in self.reqs:
+                    r.wait()
+                for dev, host in self.post:
+                    if dev is not None:
+                        dev.copy_(host)
+                self.done = True
+
+        return [_Done(reqs, post)]

@@ -210,3 +210,15 @@ def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, lay
     (th, lh_), (to, lo) = res["hip"], res["orc"]
     assert rel(lh_, lo) <= TOL
     assert th == to
+
+
+@pytest.mark.parametrize("shape", ["13B", "65B"])
+def test_larger_shapes_slice_matches_oracle(product, oracle, shape):
+    """13B (d 5120, ff 13824) and 65B (d 8192, ff 22016) layer shapes, 1 layer: exercises the KI = 2/4/6 column splits of the
+    weight-streaming kernels and the small-N prefill with 4-row chunks."""
+    out = decode_both(product, oracle, shape, 32, PROMPT, 3, layers=1, threads=64)
+    toks_h, lg_h = out["hip"]
+    toks_o, lg_o = out["orc"]
+    assert out["fused"] == 1
+    assert rel(lg_h, lg_o) <= TOL
+    assert toks_h == toks_o
