@@ -144,9 +144,16 @@ def main():
         prof = profile_decode(ctx, first, P0, repeats=2)
         result["kernels"] = {k["name"]: {"avg_us": round(k["avg_us"], 2), "launches": k["launches"], "GBps": round(k["gbps"], 1)} for k in prof}
         dom = max(prof, key=lambda k: k["avg_us"] * k["launches"])
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch from the committed PMC pass (counters cannot be collected from inside this process)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if not args.int8 and args.shape == "7B":
+                traffic, traffic_src = pmc["bytes_per_launch"].get(dom["name"]), pmc["source"]
+        except Exception:
+            pass
         result["roofline"] = {
             "bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+            "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": dom["bytes_per_launch"], "avg_us": round(dom["avg_us"], 2),
             "note": "algorithmic bytes = rows*cols*4 of the weights one launch streams (SURVEY 8d); traffic (PMC) in profiles/",
         }

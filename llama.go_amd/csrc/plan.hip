@@ -129,20 +129,83 @@ static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
     return 0;
 }
 
-static int gemm_mfma(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n, uint32_t ldx,
-                     uint32_t ldy, const char* name) {
+template <int WN, int WM, int TN, int TM>
+static int launch_gemm(lh_ctx* ctx, const GemmArgs& a, const char* name, uint32_t batch = 1) {
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+    auto kern = k_gemm_mfma<WN, WM, TN, TM>;
     static bool flags[16] = {};
-    const size_t lds = (size_t)4 * GBK * GLD * sizeof(float);
-    int rc = set_lds_once(ctx, k_gemm_mfma, lds, flags);
+    const size_t lds = (size_t)2 * GBK * (BN + 1 + BM + 1) * sizeof(float);
+    int rc = set_lds_once(ctx, kern, lds, flags);
     if (rc) return rc;
     if (g_prepare_only) return 0;
-    GemmArgs a;
-    a.x = x; a.w = w; a.y = y; a.r = resid; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
-    const uint32_t tiles = ((n + GBN - 1) / GBN) * ((M + GBM - 1) / GBM);
-    ProfScope ps(ctx->stream, name, (uint64_t)M * K * 4);
-    hipLaunchKernelGGL(k_gemm_mfma, dim3(tiles), dim3(256), lds, ctx->stream, a);
+    const uint32_t tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.groups;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4 * a.groups);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(256), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
+}
+
+// Large-N prefill attention as batched MFMA GEMMs over heads, mirroring the reference's own structure (llama.go:300-333):
+//   S_h = Q_h K_h^T (full block, like MulMat(K, Q))  ->  scale + causal mask + softmax  ->  V^T copy  ->  O_h = P_h V_h.
+static int attention_gemm(Plan* p, const float* q, const float* kc, const float* vc, float* out, uint32_t n, uint32_t past, float scale) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    const uint32_t T = past + n, Tp = (T + 31) & ~31u, H = m.H, hd = m.hd, d = m.d;
+    const uint64_t need_s = (uint64_t)H * n * Tp, need_v = (uint64_t)H * hd * Tp;
+    if (need_s > p->scores_cap) {
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p->scores) LH_HIP(ctx, hipFree(p->scores));
+        p->scores = nullptr; p->scores_cap = 0;
+        LH_HIP(ctx, hipMalloc((void**)&p->scores, need_s * 4));
+        p->scores_cap = need_s;
+    }
+    if (need_v > p->vt_cap) {
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p->vt) LH_HIP(ctx, hipFree(p->vt));
+        p->vt = nullptr; p->vt_cap = 0;
+        LH_HIP(ctx, hipMalloc((void**)&p->vt, need_v * 4));
+        p->vt_cap = need_v;
+    }
+    int rc;
+    {   // S[h][j][t] = sum_c Q[j][h*hd + c] * K[t][h*hd + c]
+        GemmArgs a = {};
+        a.x = q; a.w[0] = kc; a.y[0] = p->scores; a.groups = 1; a.N = n; a.M = T; a.K = hd; a.ldx = d; a.ldw = d; a.ldy = Tp;
+        a.xbs = hd; a.wbs = hd; a.ybs = (uint64_t)n * Tp;
+        if ((rc = launch_gemm<2, 2, 2, 2>(ctx, a, "attn_qk_gemm", H))) return rc;
+    }
+    hipLaunchKernelGGL(k_softmax_causal, dim3(n, H), dim3(256), 0, ctx->stream, p->scores, n, Tp, past, scale);
+    hipLaunchKernelGGL(k_transpose_v, dim3(Tp / 32, hd / 32, H), dim3(256), 0, ctx->stream, vc, p->vt, T, Tp, d, hd);
+    LH_HIP(ctx, hipGetLastError());
+    {   // O[j][h*hd + c] = sum_t P[h][j][t] * VT[h][c][t]
+        GemmArgs a = {};
+        a.x = p->scores; a.w[0] = p->vt; a.y[0] = out; a.groups = 1; a.N = n; a.M = hd; a.K = Tp; a.ldx = Tp; a.ldw = Tp; a.ldy = d;
+        a.xbs = (uint64_t)n * Tp; a.wbs = (uint64_t)hd * Tp; a.ybs = hd;
+        if ((rc = launch_gemm<2, 2, 2, 1>(ctx, a, "attn_pv_gemm", H))) return rc;
+    }
+    return 0;
+}
+
+// groups (<= 3) weight matrices of equal shape multiplied with the same X in ONE launch (wq|wk|wv, w1|w3): more tiles per
+// launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
+int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
+                    uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
+    GemmArgs a = {};
+    a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
+    for (uint32_t g = 0; g < groups; ++g) { a.w[g] = w[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, tn = (n + 127) / 128;
+    auto cost = [&](uint32_t bm, double penalty) {
+        const uint32_t tiles = tn * ((M + bm - 1) / bm) * groups;
+        return (double)((tiles + ncu - 1) / ncu) * bm * penalty;
+    };
+    const double c128 = cost(128, 1.0), c160 = cost(160, 1.03), c64 = cost(64, 1.10);
+    if (c160 < c128 && c160 <= c64) return launch_gemm<4, 1, 1, 5>(ctx, a, name);
+    if (c64 < c128) return launch_gemm<2, 2, 2, 1>(ctx, a, name);
+    return launch_gemm<2, 2, 2, 2>(ctx, a, name);
+}
+
+static int gemm_mfma(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n, uint32_t ldx,
+                     uint32_t ldy, const char* name) {
+    return gemm_mfma_group(ctx, x, ldx, 1, &w, &y, resid ? &resid : nullptr, M, K, n, ldy, name);
 }
 
 // Y[n][M] = X[n][K] . W[M][K]^T (+ resid).  N >= 32: fp32 MFMA GEMM (compute-bound side); smaller N: the weight-streaming
@@ -250,7 +313,7 @@ void plan_destroy(Plan* p) {
     if (p->exec_step_adv) hipGraphExecDestroy(p->exec_step_adv);
     if (p->graph_step) hipGraphDestroy(p->graph_step);
     if (p->graph_step_adv) hipGraphDestroy(p->graph_step_adv);
-    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits};
+    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt};
     for (float* b : bufs) if (b) hipFree(b);
     if (p->tokens_dev) hipFree(p->tokens_dev);
     if (p->sp_dev) hipFree(p->sp_dev);
@@ -452,18 +515,35 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
         hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d);
-        if ((rc = gemm_small_n(ctx, L.wq, p->h, p->qraw, nullptr, d, d, n, d, d, "gemm_wq"))) return rc;
-        if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
-        if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
+        const bool mfma = n >= 32 && d % GBK == 0 && F % GBK == 0;
+        if (mfma) {
+            const float* ws[3] = {L.wq, L.wk, L.wv};
+            float* ys[3] = {p->qraw, p->kraw, p->vraw};
+            if ((rc = gemm_mfma_group(ctx, p->h, d, 3, ws, ys, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
+        } else {
+            if ((rc = gemm_small_n(ctx, L.wq, p->h, p->qraw, nullptr, d, d, n, d, d, "gemm_wq"))) return rc;
+            if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
+            if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
+        }
         hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
                            m.vc + slot, rope, d, m.hd, past);
-        AttnArgs a = {};
-        a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
-        if ((rc = launch_attention(ctx, a, past + n))) return rc;
+        if (mfma && m.hd % 32 == 0) {
+            if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
+        } else {
+            AttnArgs a = {};
+            a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
+            if ((rc = launch_attention(ctx, a, past + n))) return rc;
+        }
         if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
         hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d);
-        if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
-        if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
+        if (mfma) {
+            const float* ws[2] = {L.w1, L.w3};
+            float* ys[2] = {p->a1, p->a3};
+            if ((rc = gemm_mfma_group(ctx, p->h, d, 2, ws, ys, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
+        } else {
+            if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
+            if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
+        }
         hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
                            (const float*)p->a3, p->g, (uint64_t)n * F);
         const bool last = il + 1 == m.layer1;
