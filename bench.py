@@ -113,6 +113,7 @@ def main():
     ctx_size = max(128, len(PROMPT) + max(K, W) + 1)
     hp = make_hparams(**kw, ctx=ctx_size)
     d, L, V = hp.embdSize, hp.layersCount, hp.vocabSize
+    PROMPT = [t % V for t in PROMPT]  # the fixed ids are 7B-vocabulary ids; debug shapes have smaller tables
     P0 = len(PROMPT)
 
     def sync_all():
@@ -140,6 +141,22 @@ def main():
         tokens_total = K
         tokens = [first] + toks[:-1]  # ids evaluated by the timed steps; toks = ids they produced
         produced = toks
+        # ---- the reference's own loop shape: llama.Eval per token through ml_GraphCompute (graph build + structural match on the
+        # host, hipGraph replay, 128 KB logits D2H, argmax on the host) = the PCIe-inclusive rate a Go caller of the shim gets
+        c3 = model.NewContext(ctx_size, 1)
+        c3.Eval(PROMPT, 0)
+        tk = first
+        for s_ in range(min(W, 2)):
+            tk = int(np.argmax(c3.Eval([tk], P0 + s_)))
+        tk = first
+        torch.cuda.synchronize()
+        t_e = time.perf_counter()
+        for s_ in range(K):
+            tk = int(np.argmax(c3.Eval([tk], P0 + s_)))
+        eval_dt = time.perf_counter() - t_e
+        c3.free()
+        result["eval_per_token_loop"] = {"tokens_per_s": round(K / eval_dt, 2), "ms_per_token": round(eval_dt / K * 1e3, 4),
+                                         "note": "llama.Eval per token via ml_GraphCompute incl. host graph build, logits D2H and host argmax (not `value`)"}
         # ---- dominant kernel, HIP-event timed with eager launches of the same kernels (all weights distinct: HBM-cold)
         prof = profile_decode(ctx, first, P0, repeats=2)
         result["kernels"] = {k["name"]: {"avg_us": round(k["avg_us"], 2), "launches": k["launches"], "GBps": round(k["gbps"], 1)} for k in prof}

@@ -288,6 +288,12 @@ static int run_node(lh_ctx* ctx, const lh_tensor* T, const std::vector<float*>& 
         case OP_GET_ROWS: {
             const lh_tensor &a = T[t.src0], &b = T[t.src1];
             if (t.ne[0] != a.ne[0] || t.ne[1] != nelem(b) || a.nb[0] != 4) LH_FAIL(ctx, LH_ESHAPE, "[HALT]ComputeForwardGetRows : wrong dimensions!");
+            if (b.host) {  // Go panics on src0.Data[r*NE[0]:] past the table (ml.go:1748); never let the GPU read out of range
+                for (uint64_t k = 0; k < nelem(b); ++k)
+                    if (!(b.host[k] >= 0.f) || (uint64_t)b.host[k] >= a.ne[1]) LH_FAIL(ctx, LH_EINVAL, "GetRows: row index %g outside the table of %u rows", (double)b.host[k], a.ne[1]);
+            } else {
+                LH_FAIL(ctx, LH_EUNSUPPORTED, "GetRows: indices must be a host leaf (they cannot be bounds-checked on the device)");
+            }
             hipLaunchKernelGGL(g_get_rows, dim3((unsigned)nelem(b)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
             break;
         }

@@ -22,11 +22,31 @@ struct ProfSink {
 };
 static thread_local ProfSink* g_prof = nullptr;
 
+// LLAMAHIP_TRACE=1: print every launch and synchronise after it (debugging aid: the last line names a faulting kernel)
+static bool trace_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("LLAMAHIP_TRACE"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+struct TraceScope {
+    hipStream_t st;
+    const char* name;
+    TraceScope(hipStream_t s, const char* n) : st(s), name(n) { if (trace_on() && !g_prepare_only) { fprintf(stderr, "[lh] launch %s\n", n); fflush(stderr); } }
+    ~TraceScope() {
+        if (trace_on() && !g_prepare_only) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            hipStreamIsCapturing(st, &cs);
+            if (cs == hipStreamCaptureStatusNone) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[lh]   done %s: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
+        }
+    }
+};
+
 struct ProfScope {
     hipStream_t st;
     ProfSink::Rec rec;
     bool on;
-    ProfScope(hipStream_t s, const char* name, uint64_t bytes) : st(s), on(g_prof && g_prof->on && !g_prepare_only) {
+    TraceScope tr;
+    ProfScope(hipStream_t s, const char* name, uint64_t bytes) : st(s), on(g_prof && g_prof->on && !g_prepare_only), tr(s, name) {
         if (on) {
             rec.name = name; rec.bytes = bytes;
             hipEventCreate(&rec.e0); hipEventCreate(&rec.e1);
@@ -348,6 +368,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     if (m.first_stage()) {
         if (!g_prepare_only) {
             ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
+            TraceScope ts_(ctx->stream, "embed1");
             hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d);
             LH_HIP(ctx, hipGetLastError());
         }
@@ -397,6 +418,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
         if ((argmax_advance || argmax_out) && !g_prepare_only) {
             ProfScope ps(ctx->stream, "argmax", (uint64_t)m.V * 4);
+            TraceScope ts_(ctx->stream, "argmax");
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)p->logits, m.V, (StepParams*)sp, p->out_tokens_dev,
                                argmax_out, argmax_advance ? 1 : 0);
             LH_HIP(ctx, hipGetLastError());
@@ -504,6 +526,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
         memcpy(ctx->staging, tokens_host, (size_t)n * 4);
         LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        TraceScope ts_(ctx->stream, "embedN");
         hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d);
         LH_HIP(ctx, hipGetLastError());
     } else {
@@ -514,7 +537,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d);
+        { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
         const bool mfma = n >= 32 && d % GBK == 0 && F % GBK == 0;
         if (mfma) {
             const float* ws[3] = {L.wq, L.wk, L.wv};
@@ -525,8 +548,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
             if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
         }
-        hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
-                           m.vc + slot, rope, d, m.hd, past);
+        { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
+                           m.vc + slot, rope, d, m.hd, past); }
         if (mfma && m.hd % 32 == 0) {
             if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
         } else {
@@ -535,7 +558,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if ((rc = launch_attention(ctx, a, past + n))) return rc;
         }
         if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d);
+        { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
         if (mfma) {
             const float* ws[2] = {L.w1, L.w3};
             float* ys[2] = {p->a1, p->a3};
@@ -544,8 +567,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
             if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
         }
-        hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
-                           (const float*)p->a3, p->g, (uint64_t)n * F);
+        { TraceScope ts_(ctx->stream, "silu_mul"); hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
+                           (const float*)p->a3, p->g, (uint64_t)n * F); }
         const bool last = il + 1 == m.layer1;
         float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
         if ((rc = gemm_small_n(ctx, L.w2, p->g, y, p->xb, d, F, n, F, d, "gemm_w2"))) return rc;
@@ -553,7 +576,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         LH_HIP(ctx, hipGetLastError());
     }
     if (m.last_stage()) {
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, m.norm, p->h, d);
+        { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, m.norm, p->h, d); }
         // the reference evaluates lm_head for all N rows (llama.go:384) although only row N-1 is read (llama.go:394-401)
         if ((rc = gemm_small_n(ctx, m.output, p->h, p->logits, nullptr, m.V, d, n, d, m.V, "gemm_lmhead"))) return rc;
     }

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <unordered_set>
 #include "../../include/llamago.h"
 #include "../../include/llamahip.h"
 
@@ -71,6 +72,7 @@ struct ml_tensor {  // ml.Tensor ml.go:180-203
 
 struct ml_graph {  // ml.Graph ml.go:31-45
     std::vector<ml_tensor*> nodes, leafs;
+    std::unordered_set<const ml_tensor*> seen;  // same visit order as the reference's linear scans (ml.go:657-668), without the O(n^2)
 };
 
 static thread_local ml_tensor* g_gc_head = nullptr;
@@ -110,7 +112,9 @@ static ml_tensor* new_leaf(int dt, uint32_t dims, uint32_t ne0, uint32_t ne1, ui
     return t;
 }
 static ml_tensor* view_tensor(ml_tensor* s) { return new_tensor(s->type, s->dims, s->ne[0], s->ne[1], s->ne[2], s->ne[3], s, 0); }  // ml.go:231
-static ml_tensor* dup_tensor(ml_tensor* s) { return new_tensor(s->type, s->dims, s->ne[0], s->ne[1], s->ne[2], s->ne[3], nullptr, 0); }  // ml.go:236
+// DupTensor ml.go:236 — a fresh result tensor.  Results live in HBM only: no host Data is allocated for them (the
+// reference's per-node make([]float32) + forced GC is exactly the churn SURVEY §8a row 21 lists); read them with ml_TensorRead.
+static ml_tensor* dup_tensor(ml_tensor* s) { return new_tensor(s->type, s->dims, s->ne[0], s->ne[1], s->ne[2], s->ne[3], nullptr, 0, false); }
 static ml_tensor* node2(ml_tensor* r, int op, ml_tensor* a, ml_tensor* b) { r->op = op; r->src0 = a; r->src1 = b; return r; }
 static void free_tensor(ml_tensor* t) {
     if (!t) return;
@@ -169,15 +173,15 @@ ml_tensor* ml_Mul(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:241-287
 }
 ml_tensor* ml_Add(ml_context*, ml_tensor* a, ml_tensor* b) { return node2(dup_tensor(a), ML_OP_ADD, a, b); }  // ml.go:321-360
 ml_tensor* ml_MulMat(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:295-318
-    ml_tensor* r = new_tensor(ML_TYPE_F32, a->dims < b->dims ? a->dims : b->dims, a->ne[1], b->ne[1], a->ne[2], b->ne[3], nullptr, 0);
+    ml_tensor* r = new_tensor(ML_TYPE_F32, a->dims < b->dims ? a->dims : b->dims, a->ne[1], b->ne[1], a->ne[2], b->ne[3], nullptr, 0, false);
     return node2(r, ML_OP_MUL_MAT, a, b);
 }
 ml_tensor* ml_Repeat(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:487-513
     if (same_shape(a, b)) return a;
-    return node2(new_tensor(a->type, b->dims, b->ne[0], b->ne[1], b->ne[2], b->ne[3], nullptr, 0), ML_OP_REPEAT, a, b);
+    return node2(new_tensor(a->type, b->dims, b->ne[0], b->ne[1], b->ne[2], b->ne[3], nullptr, 0, false), ML_OP_REPEAT, a, b);
 }
 ml_tensor* ml_GetRows(ml_context*, ml_tensor* a, ml_tensor* b) {  // ml.go:528-557
-    return node2(new_tensor(ML_TYPE_F32, 2, a->ne[0], b->ne[0], 1, 1, nullptr, 0), ML_OP_GET_ROWS, a, b);
+    return node2(new_tensor(ML_TYPE_F32, 2, a->ne[0], b->ne[0], 1, 1, nullptr, 0, false), ML_OP_GET_ROWS, a, b);
 }
 ml_tensor* ml_RMSNorm(ml_context*, ml_tensor* a) { return node2(dup_tensor(a), ML_OP_RMS_NORM, a, nullptr); }  // ml.go:559-597
 ml_tensor* ml_View1D(ml_context*, ml_tensor* a, uint32_t ne0, uint32_t offset) {  // ml.go:601-617 (offset in floats)
@@ -221,8 +225,7 @@ void ml_FreeGraph(ml_graph* g) {
     delete g;
 }
 static int visit_parents(ml_graph* g, ml_tensor* node) {  // ml.go:647-697
-    for (ml_tensor* t : g->nodes) if (t == node) return 0;
-    for (ml_tensor* t : g->leafs) if (t == node) return 0;
+    if (!g->seen.insert(node).second) return 0;
     if (node->src0 && visit_parents(g, node->src0)) return 1;
     if (node->src1 && visit_parents(g, node->src1)) return 1;
     if (node->op == ML_OP_NONE) {
@@ -617,7 +620,7 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
                 if (ml_BuildForwardExpand(graph, ml_Copy(ctx0, Kcur, k)) || ml_BuildForwardExpand(graph, ml_Copy(ctx0, Vcur, v))) { fail = true; break; }
             }
             ml_tensor* Q = ml_Permute(ctx0,                                       // :281-288
-                ml_Rope(ctx0, ml_Copy(ctx0, Qcur, new_tensor(ML_TYPE_F32, 3, embdSize / headsCount, headsCount, N, 1, nullptr, 0)), pastCount, rotCount, 0),
+                ml_Rope(ctx0, ml_Copy(ctx0, Qcur, new_tensor(ML_TYPE_F32, 3, embdSize / headsCount, headsCount, N, 1, nullptr, 0, false)), pastCount, rotCount, 0),
                 0, 2, 1, 3);
             ml_tensor* K = ml_Permute(ctx0,                                       // :290-297
                 ml_Rope(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, lctx->K, (pastCount + N) * embdSize, il * ctxSize * embdSize),
@@ -632,10 +635,10 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
             ml_tensor* VTrans = ml_Copy(ctx0,                                     // :315-322
                 ml_Permute(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, lctx->V, (pastCount + N) * embdSize, il * ctxSize * embdSize),
                                               embdSize / headsCount, headsCount, pastCount + N), 1, 2, 0, 3),
-                new_tensor(ML_TYPE_F32, 3, pastCount + N, embdSize / headsCount, headsCount, 1, nullptr, 0));
+                new_tensor(ML_TYPE_F32, 3, pastCount + N, embdSize / headsCount, headsCount, 1, nullptr, 0, false));
             ml_tensor* KQV = ml_MulMat(ctx0, VTrans, KQSoftMax);                  // :325
             ml_tensor* KQVMerged = ml_Permute(ctx0, KQV, 0, 2, 1, 3);             // :328
-            cur = ml_Copy(ctx0, KQVMerged, new_tensor(ML_TYPE_F32, 2, embdSize, N, 1, 1, nullptr, 0));  // :331-333
+            cur = ml_Copy(ctx0, KQVMerged, new_tensor(ML_TYPE_F32, 2, embdSize, N, 1, 1, nullptr, 0, false));  // :331-333
             cur = ml_MulMat(ctx0, L.wo, cur);                                     // :336
             ml_tensor* inpFF = ml_Add(ctx0, cur, inpSA);                          // :340
             cur = ml_RMSNorm(ctx0, inpFF);                                        // :346

@@ -163,6 +163,19 @@ def test_ggjt_roundtrip_through_hbm(product, oracle, tmp_path):
     mo.free()
 
 
+def test_out_of_range_token_is_an_error_not_a_gpu_fault(product):
+    """A token id >= vocab makes Go panic on the embedding slice (ml.go:1748); here it must come back as an error."""
+    hp = make_hparams(**SHAPES["tiny"], ctx=8)
+    m = product.NewSyntheticModel(hp, 1)
+    c = m.NewContext(8, 1)
+    with pytest.raises(Exception):
+        c.Eval([1, hp.vocabSize + 5], 0)
+    assert "GetRows" in product.last_error() or "outside" in product.last_error()
+    c.Eval([1, 2], 0)  # the context is still usable
+    c.free()
+    m.free()
+
+
 def test_context_overflow_is_an_error_not_a_crash(product):
     hp = make_hparams(**SHAPES["tiny"], ctx=8)
     m = product.NewSyntheticModel(hp, 1)
