@@ -319,8 +319,8 @@ __global__ __launch_bounds__(TH) void k_gemv_cols(const GemmColsArgs a) {
 // Replaces KQ / Scale / DiagMaskInf / SoftMax / VTrans copy / KQV / merge (llama.go:300-333) without
 // materialising the transposed V or the [T x N x H] score tensor.  Keys beyond the causal limit are
 // skipped: in the reference they become exactly 0 after the softmax (ml.go:2476-2477) and add nothing.
-//   grid = (H, N), 256 threads.  K/V rows are strided by d floats in the cache; 8 groups of 32 lanes each
-//   take one key (float4 per lane, 128-float head), reduce with DPP.  T <= TMAX scores live in LDS.
+//   grid = (H, N), 1024 threads.  K/V rows are strided by d floats in the cache; 32 groups of 32 lanes each take one key
+//   (float4 per lane, 128-float head) with 4 keys in flight per group, reduce with DPP.  Scores of the row live in LDS.
 // ---------------------------------------------------------------------------------------------------
 struct AttnArgs {
     const float* q;        // [N][d] roped queries
@@ -333,66 +333,131 @@ struct AttnArgs {
     uint32_t past_host;    // ... or host value when sp == nullptr
 };
 
-__global__ __launch_bounds__(256) void k_attention(const AttnArgs a) {
+constexpr int ATT_TH = 1024;
+
+__global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int NWV = ATT_TH / 64, NG = ATT_TH / 32;  // waves, 32-lane key groups
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t h = blockIdx.x, j = blockIdx.y;
     const uint32_t past = a.sp ? a.sp->past : a.past_host;
     const uint32_t T = past + j + 1;  // keys 0..past+j are visible to query j (mask: i > past + j, ml.go:2401-2404)
     const uint32_t Tp = (T + 63) & ~63u;
     float* sc = (float*)smem_raw;     // [Tp] scaled scores
-    float* pr = sc + Tp;              // [Tp] un-normalised probabilities (every wave writes identical values)
-    float* scratch = pr + Tp;         // [256] PV partials
+    float* pr = sc + Tp;              // [Tp] un-normalised probabilities
+    float* scratch = pr + Tp;         // [ATT_TH] PV partials / reduction scratch
     const uint32_t d = a.d, hd = a.hd;
     const float* q = a.q + (size_t)j * d + h * hd;
     const float* Kc = a.k_cache + h * hd;
     const float* Vc = a.v_cache + h * hd;
-    // --- V prefetch for the PV phase: issued first so its latency hides under scores + softmax
-    const uint32_t phases = 256 / hd;  // hd = 128 -> 2 key phases
+    // The cache rows of one head are 512 B segments strided by embd: every loop below keeps several INDEPENDENT row
+    // loads in flight per lane (a dependent one-row-per-iteration loop costs a full L2 latency per key: 0.27 us/key measured).
+    const uint32_t phases = ATT_TH / hd;  // hd = 128 -> 8 key phases in the PV step
     const uint32_t c = tid % hd, ph = tid / hd;
-    constexpr int VP = 16;
+    constexpr int VP = 8;
     float vpre[VP];
 #pragma unroll
-    for (int i = 0; i < VP; ++i) {
+    for (int i = 0; i < VP; ++i) {   // first V rows: issued before anything else, consumed last
         const uint32_t t = ph + (uint32_t)i * phases;
         vpre[i] = t < T ? Vc[(size_t)t * d + c] : 0.f;
     }
-    // --- scores: one key per 32-lane group per iteration (hd = 128 -> float4 per lane)
+    // --- scores: one key per 32-lane group, UN keys in flight per group (hd = 128 -> float4 per lane; other hd: strided loop)
     const int g = tid >> 5, gl = tid & 31;
-    for (uint32_t t = g; t < T; t += 8) {
-        float s = 0.f;
-        for (uint32_t cc = gl * 4; cc < hd; cc += 128) {
-            const f4 kv = *(const f4*)(Kc + (size_t)t * d + cc);
-            const f4 qv = *(const f4*)(q + cc);
-            s = fmaf(kv.x, qv.x, s); s = fmaf(kv.y, qv.y, s); s = fmaf(kv.z, qv.z, s); s = fmaf(kv.w, qv.w, s);
+    constexpr int UN = 4;
+    if (hd == 128) {
+        const f4 qv = *(const f4*)(q + gl * 4);
+        for (uint32_t t0 = g; t0 < T; t0 += NG * UN) {
+            f4 kv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint32_t t = t0 + u * NG;
+                kv[u] = *(const f4*)(Kc + (size_t)(t < T ? t : 0) * d + gl * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const uint32_t t = t0 + u * NG;
+                float s = fmaf(kv[u].x, qv.x, 0.f);
+                s = fmaf(kv[u].y, qv.y, s); s = fmaf(kv[u].z, qv.z, s); s = fmaf(kv[u].w, qv.w, s);
+                s = half_wave_sum(s);
+                if (gl == 0 && t < T) sc[t] = __fmul_rn(s, a.scale);  // Scale ml.go:2331-2374
+            }
         }
-        s = half_wave_sum(s);
-        if (gl == 0) sc[t] = __fmul_rn(s, a.scale);  // Scale ml.go:2331-2374
+    } else {
+        for (uint32_t t = g; t < T; t += NG) {
+            float s = 0.f;
+            for (uint32_t cc = gl * 4; cc < hd; cc += 128) {
+                const f4 kv = *(const f4*)(Kc + (size_t)t * d + cc);
+                const f4 qv = *(const f4*)(q + cc);
+                s = fmaf(kv.x, qv.x, s); s = fmaf(kv.y, qv.y, s); s = fmaf(kv.z, qv.z, s); s = fmaf(kv.w, qv.w, s);
+            }
+            s = half_wave_sum(s);
+            if (gl == 0) sc[t] = __fmul_rn(s, a.scale);
+        }
     }
     __syncthreads();
-    // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum.
-    // Each wave evaluates the whole row redundantly with wave-level reductions (same code -> same bits), which removes
-    // every block barrier of this phase; waves only read sc[] and write identical values to pr[].
-    float m = -INFINITY;
-    for (uint32_t t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
-    m = wave_max(m);
-    float psum = 0.f;
-    for (uint32_t t = lane; t < T; t += 64) {
-        const float p = (float)exp((double)__fsub_rn(sc[t], m));
-        pr[t] = p;
-        psum += p;
+    // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum
+    float inv;
+    if (T <= 128) {
+        // short rows: every wave evaluates the whole row redundantly with wave-level reductions (same code -> same bits):
+        // no block barrier in this phase; waves only read sc[] and write identical values to pr[]
+        float m = -INFINITY;
+        for (uint32_t t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
+        m = wave_max(m);
+        float psum = 0.f;
+        for (uint32_t t = lane; t < T; t += 64) {
+            const float p = (float)exp((double)__fsub_rn(sc[t], m));
+            pr[t] = p;
+            psum += p;
+        }
+        psum = wave_sum(psum);
+        inv = __fdiv_rn(1.0f, psum);
+    } else {
+        // long rows: the f64 exps are spread over all threads, two block reductions in fixed order
+        float m = -INFINITY;
+        for (uint32_t t = tid; t < T; t += ATT_TH) m = fmaxf(m, sc[t]);
+        m = wave_max(m);
+        if (lane == 0) scratch[wave] = m;
+        __syncthreads();
+        m = scratch[0];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) m = fmaxf(m, scratch[w]);
+        __syncthreads();
+        float psum = 0.f;
+        for (uint32_t t = tid; t < T; t += ATT_TH) {
+            const float p = (float)exp((double)__fsub_rn(sc[t], m));
+            pr[t] = p;
+            psum += p;
+        }
+        psum = wave_sum(psum);
+        if (lane == 0) scratch[wave] = psum;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += scratch[w];
+        inv = __fdiv_rn(1.0f, tot);
+        __syncthreads();
     }
-    psum = wave_sum(psum);
-    const float inv = __fdiv_rn(1.0f, psum);
-    // --- PV: thread (c, ph) accumulates its key phase; DS operations of a wave execute in order, so pr[] written above by
-    // this wave is visible to its own reads below
+    // --- PV: thread (c, ph) accumulates its key phase, VP independent row loads in flight.  (T <= 128: DS operations of a
+    // wave execute in order, so pr[] written above by this wave is visible to its own reads; T > 128: barrier above.)
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
         const uint32_t t = ph + (uint32_t)i * phases;
         if (t < T) acc = fmaf(vpre[i], __fmul_rn(pr[t], inv), acc);
     }
-    for (uint32_t t = ph + VP * phases; t < T; t += phases) acc = fmaf(Vc[(size_t)t * d + c], __fmul_rn(pr[t], inv), acc);
+    for (uint32_t t0 = ph + VP * phases; t0 < T; t0 += VP * phases) {
+        float vv[VP];
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const uint32_t t = t0 + (uint32_t)i * phases;
+            vv[i] = Vc[(size_t)(t < T ? t : 0) * d + c];
+        }
+#pragma unroll
+        for (int i = 0; i < VP; ++i) {
+            const uint32_t t = t0 + (uint32_t)i * phases;
+            if (t < T) acc = fmaf(vv[i], __fmul_rn(pr[t], inv), acc);
+        }
+    }
     scratch[tid] = acc;
     __syncthreads();
     if (tid < (int)hd) {

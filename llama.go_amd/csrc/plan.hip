@@ -257,8 +257,8 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
 }
 
 static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
-    if (a.hd > 256 || 256 % a.hd || a.hd % 4) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: head dim %u unsupported (needs to divide 256)", a.hd);
-    const size_t lds = (2 * (size_t)((max_T + 63) & ~63u) + 256) * 4;
+    if (a.hd > ATT_TH || ATT_TH % a.hd || a.hd % 4) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: head dim %u unsupported (needs to divide %d)", a.hd, ATT_TH);
+    const size_t lds = (2 * (size_t)((max_T + 63) & ~63u) + ATT_TH) * 4;
     static bool flags[16] = {};
     static size_t cur[16] = {};
     if (lds > 48 * 1024 && lds > cur[ctx->device & 15]) {
@@ -270,7 +270,7 @@ static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
     if (lds > 160 * 1024) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: %u keys exceed the single-pass LDS budget", max_T);
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, "attention", (uint64_t)2 * max_T * a.d * 4);
-    hipLaunchKernelGGL(k_attention, dim3(a.d / a.hd, a.n), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_attention, dim3(a.d / a.hd, a.n), dim3(ATT_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }

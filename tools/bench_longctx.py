@@ -1,0 +1,26 @@
+"""Decode step time vs position (long-context check): LLaMA-7B fp32, prefill P tokens, then 16 resident decode steps.
+usage: python tools/bench_longctx.py [--past 1000]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from llama_go_amd.mlapi import SHAPES, load_product, make_hparams, decode_greedy_resident, profile_decode
+ap = argparse.ArgumentParser(); ap.add_argument("--past", type=int, nargs="+", default=[8, 120, 500, 1000, 2000]); ap.add_argument("--shape", default="7B")
+args = ap.parse_args()
+prod = load_product()
+ctx_size = max(args.past) + 32
+hp = make_hparams(**SHAPES[args.shape], ctx=ctx_size)
+m = prod.NewSyntheticModel(hp, 1234)
+rng = np.random.default_rng(0)
+out = []
+for P in args.past:
+    c = m.NewContext(ctx_size, 1)
+    toks = [int(t) for t in rng.integers(0, hp.vocabSize, P)]
+    lg = c.Eval(toks, 0)
+    first = int(np.argmax(lg))
+    decode_greedy_resident(c, first, P, 2)
+    t0 = time.perf_counter(); decode_greedy_resident(c, first, P, 16); dt = (time.perf_counter() - t0) / 16
+    prof = {k["name"]: round(k["avg_us"], 2) for k in profile_decode(c, first, P, 2)}
+    out.append({"past": P, "ms_per_token": round(dt * 1e3, 4), "tok_s": round(1 / dt, 1), "attention_us": prof.get("attention")})
+    c.free()
+print(json.dumps(out))
