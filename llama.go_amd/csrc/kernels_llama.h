@@ -468,6 +468,111 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Long contexts (plans with ctx > 256), decode: one workgroup per head reads 2*T*hd*4 bytes alone (1 MB at T = 1024) and
+// 32 workgroups cannot pull that out of L2 fast enough (38 us per layer at T = 1000).  Split the keys of a head into
+// chunks of ATT_TC, one workgroup per (head, chunk) writes an un-normalised partial {o_c[hd], m_c, l_c} (softmax local to
+// the chunk), and k_attention_combine merges the chunks: M = max m_c, w_c = exp(m_c - M), l = sum l_c w_c,
+// out = (sum o_c w_c) / l.  Same mathematics as the single pass, two more fp32 roundings per output (<= 1e-7 relative).
+// The grid is static (ceil(ctx / ATT_TC) chunks, so one captured hipGraph serves every position); chunks beyond the
+// current length exit immediately.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ATT_TC = 128;
+
+__global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, float* __restrict__ part) {
+    __shared__ float sc[ATT_TC];
+    __shared__ float pr[ATT_TC];
+    __shared__ float scratch[ATT_TH];
+    constexpr int NG = ATT_TH / 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t h = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
+    const uint32_t past = a.sp ? a.sp->past : a.past_host;
+    const uint32_t T = past + 1, c0 = ch * ATT_TC;
+    if (c0 >= T) return;
+    const uint32_t Tl = (T - c0 < (uint32_t)ATT_TC) ? T - c0 : (uint32_t)ATT_TC;  // keys of this chunk
+    const uint32_t d = a.d, hd = a.hd;
+    const float* q = a.q + h * hd;
+    const float* Kc = a.k_cache + (size_t)c0 * d + h * hd;
+    const float* Vc = a.v_cache + (size_t)c0 * d + h * hd;
+    const uint32_t phases = ATT_TH / hd, c = tid % hd, ph = tid / hd;
+    constexpr int VP = ATT_TC / 8;  // hd = 128: 8 phases x 16 keys = the whole chunk in flight
+    float vpre[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const uint32_t t = ph + (uint32_t)i * phases;
+        vpre[i] = t < Tl ? Vc[(size_t)t * d + c] : 0.f;
+    }
+    const int g = tid >> 5, gl = tid & 31;
+    {   // scores of the chunk in one batch: 32 groups x 4 keys, all K rows requested before the first is used (hd = 128)
+        constexpr int UN = ATT_TC / NG;
+        const f4 qv = *(const f4*)(q + gl * 4);
+        f4 kv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t t = g + u * NG;
+            kv[u] = *(const f4*)(Kc + (size_t)(t < Tl ? t : 0) * d + gl * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const uint32_t t = g + u * NG;
+            float s = fmaf(kv[u].x, qv.x, 0.f);
+            s = fmaf(kv[u].y, qv.y, s); s = fmaf(kv[u].z, qv.z, s); s = fmaf(kv[u].w, qv.w, s);
+            s = half_wave_sum(s);
+            if (gl == 0 && t < Tl) sc[t] = __fmul_rn(s, a.scale);  // Scale ml.go:2331-2374
+        }
+    }
+    __syncthreads();
+    // chunk-local softmax statistics, evaluated redundantly per wave (Tl <= 128: at most 2 exps per lane)
+    float m = -INFINITY;
+    for (uint32_t t = lane; t < Tl; t += 64) m = fmaxf(m, sc[t]);
+    m = wave_max(m);
+    float psum = 0.f;
+    for (uint32_t t = lane; t < Tl; t += 64) {
+        const float p = (float)exp((double)__fsub_rn(sc[t], m));
+        pr[t] = p;
+        psum += p;
+    }
+    psum = wave_sum(psum);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+        const uint32_t t = ph + (uint32_t)i * phases;
+        if (t < Tl) acc = fmaf(vpre[i], pr[t], acc);
+    }
+    scratch[tid] = acc;
+    __syncthreads();
+    float* dst = part + ((size_t)h * nch + ch) * (hd + 2);
+    if (tid < (int)hd) {
+        float o = scratch[tid];
+        for (uint32_t p2 = 1; p2 < phases; ++p2) o += scratch[tid + p2 * hd];
+        dst[tid] = o;
+    }
+    if (tid == 0) { dst[hd] = m; dst[hd + 1] = psum; }
+}
+
+__global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, const float* __restrict__ part, uint32_t nch) {
+    const uint32_t h = blockIdx.x, hd = a.hd;
+    const uint32_t past = a.sp ? a.sp->past : a.past_host;
+    const uint32_t T = past + 1, n = (T + ATT_TC - 1) / ATT_TC;  // active chunks
+    const float* base = part + (size_t)h * nch * (hd + 2);
+    float M = -INFINITY;
+    for (uint32_t s = 0; s < n; ++s) M = fmaxf(M, base[(size_t)s * (hd + 2) + hd]);
+    float l = 0.f;
+    for (uint32_t s = 0; s < n; ++s) {
+        const float w = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
+        l = fmaf(base[(size_t)s * (hd + 2) + hd + 1], w, l);
+    }
+    const float inv = __fdiv_rn(1.0f, l);
+    for (uint32_t c = threadIdx.x; c < hd; c += 128) {
+        float o = 0.f;
+        for (uint32_t s = 0; s < n; ++s) {
+            const float w = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
+            o = fmaf(base[(size_t)s * (hd + 2) + c], w, o);
+        }
+        a.out[h * hd + c] = __fmul_rn(o, inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Small kernels
 // ---------------------------------------------------------------------------------------------------
 // GetRows ml.go:1711-1750 — embedding lookup; token ids from the device step parameters (decode) or a device array.

@@ -39,6 +39,7 @@ struct Plan {
     uint32_t n_cap = 0;
     float *xa = nullptr, *xb = nullptr, *h = nullptr, *qraw = nullptr, *kraw = nullptr, *vraw = nullptr, *q = nullptr, *attn = nullptr;
     float *a1 = nullptr, *a3 = nullptr, *g = nullptr, *logits = nullptr;
+    float* attn_part = nullptr;               // split-T decode attention partials [H][chunks][hd + 2] (plans with ctx > 256)
     float *scores = nullptr, *vt = nullptr;   // large-N prefill attention: S[H][N][Tp], V^T[H][hd][Tp]
     uint64_t scores_cap = 0, vt_cap = 0;
     uint32_t* tokens_dev = nullptr;

@@ -275,6 +275,25 @@ static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
     return 0;
 }
 
+// decode attention for long-context plans: chunks of ATT_TC keys per workgroup + combine
+static int launch_attention_split(Plan* p, const AttnArgs& a) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    if (a.hd != 128) LH_FAIL(ctx, LH_EUNSUPPORTED, "split attention: head dim %u", a.hd);
+    const uint32_t nch = (m.ctx + ATT_TC - 1) / ATT_TC;
+    if (g_prepare_only) return 0;
+    {
+        ProfScope ps(ctx->stream, "attention_split", (uint64_t)2 * m.ctx * a.d * 4);
+        hipLaunchKernelGGL(k_attention_split, dim3(m.H, nch), dim3(ATT_TH), 0, ctx->stream, a, p->attn_part);
+    }
+    {
+        ProfScope ps(ctx->stream, "attention_combine", (uint64_t)m.H * nch * (a.hd + 2) * 4);
+        hipLaunchKernelGGL(k_attention_combine, dim3(m.H), dim3(128), 0, ctx->stream, a, (const float*)p->attn_part, nch);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 int plan_ensure_rows(Plan* p, uint32_t n) {
     if (n <= p->n_cap) return 0;
@@ -321,6 +340,13 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
     rc = plan_ensure_rows(p, 1);
     if (rc) { plan_destroy(p); return rc; }
+    const char* envs = getenv("LLAMAHIP_SPLIT_ATTN");  // 0 = never, 1 = always (default: contexts longer than 256)
+    const bool split = envs ? envs[0] == '1' : md.ctx > 256;
+    if (split && md.hd == 128) {
+        const size_t nch = (md.ctx + ATT_TC - 1) / ATT_TC;
+        e = hipMalloc((void**)&p->attn_part, (size_t)md.H * nch * (md.hd + 2) * 4);
+        if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
+    }
     *out = p;
     return 0;
 }
@@ -340,6 +366,7 @@ void plan_destroy(Plan* p) {
     if (p->sp_host) hipHostFree(p->sp_host);
     if (p->out_tokens_dev) hipFree(p->out_tokens_dev);
     if (p->argmax_dev) hipFree(p->argmax_dev);
+    if (p->attn_part) hipFree(p->attn_part);
     delete p;
 }
 
@@ -391,7 +418,8 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
             AttnArgs a = {};
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = m.d; a.hd = m.hd; a.n = 1; a.scale = scale; a.sp = sp;
-            if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
+            if (p->attn_part) { if ((rc = launch_attention_split(p, a))) return rc; }
+            else if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
         }
         {   // wo + residual   (llama.go:336-340)
             GemvArgs a = {};

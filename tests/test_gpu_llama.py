@@ -235,3 +235,16 @@ def test_larger_shapes_slice_matches_oracle(product, oracle, shape):
     assert out["fused"] == 1
     assert rel(lg_h, lg_o) <= TOL
     assert toks_h == toks_o
+
+
+def test_long_context_split_attention_matches_oracle(product, oracle):
+    """Plans with ctx > 256 decode with the split-T attention (chunks of 128 keys per workgroup + combine).  A 250-token prompt
+    (MFMA prefill) followed by decode steps that cross the 256-key chunk boundary must match the oracle."""
+    rng = np.random.default_rng(5)
+    prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], 250)]
+    out = decode_both(product, oracle, "small", 320, prompt, 12, threads=64)
+    toks_h, lg_h = out["hip"]
+    toks_o, lg_o = out["orc"]
+    assert out["fused"] == 1
+    assert rel(lg_h, lg_o) <= TOL
+    assert toks_h == toks_o
