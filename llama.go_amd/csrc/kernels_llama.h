@@ -575,6 +575,15 @@ __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, con
 // ---------------------------------------------------------------------------------------------------
 // Small kernels
 // ---------------------------------------------------------------------------------------------------
+// Step parameters travel as KERNEL ARGUMENTS into device memory (stream-ordered, nothing on the host to keep alive: an
+// async copy from a pinned slot could be overwritten by a caller that runs many steps ahead of the GPU).
+__global__ void k_set_step(StepParams* sp, uint32_t token, uint32_t past, uint32_t step) {
+    sp->token = token;
+    sp->past = past;
+    sp->step = step;
+    sp->pad = 0;
+}
+
 // GetRows ml.go:1711-1750 — embedding lookup; token ids from the device step parameters (decode) or a device array.
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ emb, const uint32_t* __restrict__ tokens, const StepParams* sp,
                                                 float* __restrict__ x, uint32_t d) {

@@ -52,6 +52,7 @@ struct Plan {
     hipGraphExec_t exec_step = nullptr;       // one Eval(N=1): embed .. logits
     hipGraphExec_t exec_step_adv = nullptr;   // the same + argmax + advance (resident greedy loop)
     hipGraph_t graph_step = nullptr, graph_step_adv = nullptr;
+    uint32_t slot_counter = 0;   // round-robin over the pinned StepParams slots of eager (non-graph) steps
     bool use_graph = true;
 };
 

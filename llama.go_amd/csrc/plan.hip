@@ -491,11 +491,8 @@ static int ensure_decode_graph(Plan* p, bool adv) {
 
 static int upload_step_params(Plan* p, uint32_t slot, uint32_t token, uint32_t past, uint32_t step) {
     lh_ctx* ctx = p->ctx;
-    p->sp_host[slot].token = token;
-    p->sp_host[slot].past = past;
-    p->sp_host[slot].step = step;
-    p->sp_host[slot].pad = 0;
-    LH_HIP(ctx, hipMemcpyAsync(p->sp_dev + slot, p->sp_host + slot, sizeof(StepParams), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, ctx->stream, p->sp_dev + slot, token, past, step);
+    LH_HIP(ctx, hipGetLastError());
     return 0;
 }
 
@@ -516,7 +513,6 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
 }
 
 // ---- general Eval on the plan (N >= 1) ----------------------------------------------------------------
-static uint32_t g_slot_counter = 0;
 
 int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past) {
     lh_ctx* ctx = p->ctx;
@@ -530,7 +526,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     if ((rc = plan_ensure_rows(p, n))) return rc;
     if (n == 1) {
         if (m.first_stage() && m.last_stage() && p->use_graph) return plan_decode_step(p, tokens_host[0], past);
-        const uint32_t slot = 1 + (g_slot_counter++ % (SP_SLOTS - 1));
+        const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
@@ -539,7 +535,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         // (bit-identical to what the decode path produces for them), logits row i from step i like llama.go:384.
         if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EUNSUPPORTED, "block-int8 prefill on a pipeline stage is not supported yet");
         for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t slot = 1 + (g_slot_counter++ % (SP_SLOTS - 1));
+            const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
             if ((rc = upload_step_params(p, slot, tokens_host[i], past + i, 0))) return rc;
             if ((rc = enqueue_decode(p, p->sp_dev + slot, nullptr, nullptr, false, nullptr, nullptr, i))) return rc;
             if ((i + 1) % (SP_SLOTS - 2) == 0) LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned parameter slots are recycled
@@ -751,7 +747,7 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
     if (n == 1) {
         if ((rc = plan_ensure_rows(p, 1))) return rc;
         if ((uint64_t)past + 1 > md.ctx) LH_FAIL(ctx, LH_EINVAL, "stage: position %u outside the context window", past);
-        const uint32_t slot = 1 + (g_slot_counter++ % (SP_SLOTS - 1));
+        const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if (md.first_stage() && !tokens && !tokens_dev) LH_FAIL(ctx, LH_EINVAL, "stage: first stage needs a token id (host or device)");
         if ((rc = upload_step_params(p, slot, tokens ? tokens[0] : 0, past, 0))) return rc;
         if ((rc = enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, md.last_stage() ? argmax_dev : nullptr, tokens ? nullptr : tokens_dev))) return rc;
