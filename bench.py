@@ -157,6 +157,21 @@ def main():
         c3.free()
         result["eval_per_token_loop"] = {"tokens_per_s": round(K / eval_dt, 2), "ms_per_token": round(eval_dt / K * 1e3, 4),
                                          "note": "llama.Eval per token via ml_GraphCompute incl. host graph build, logits D2H and host argmax (not `value`)"}
+        # ---- the reference's real generation loop: SampleTopPTopK (topK 40, topP 0.95, repeat penalty 1.10 — main.go:87-90) after every
+        # Eval, sampler resident on the device (no logits D2H).  Decode rate = (t[K+1 samples] - t[1 sample]) / K, same prefill in both.
+        SMP = dict(topK=min(40, V), topP=0.95, temp=0.8, repeatPenalty=1.10, seed=SEED)
+        c4 = model.NewContext(ctx_size, 1)
+        c4.SampleDecode(PROMPT, min(W, 2) + 1, **SMP)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        c4.SampleDecode(PROMPT, 1, **SMP)
+        t_s1 = time.perf_counter()
+        sampled = c4.SampleDecode(PROMPT, K + 1, **SMP)
+        t_s2 = time.perf_counter()
+        c4.free()
+        smp_dt = max(1e-9, (t_s2 - t_s1) - (t_s1 - t_s))
+        result["sampled_decode"] = {"tokens_per_s": round(K / smp_dt, 2), "ms_per_token": round(smp_dt / K * 1e3, 4), "params": SMP,
+                                    "note": "llama.SampleTopPTopK on the device after every Eval (server.go:201-204); counter-based uniforms (not `value`)"}
         # ---- dominant kernel, HIP-event timed with eager launches of the same kernels (all weights distinct: HBM-cold)
         prof = profile_decode(ctx, first, P0, repeats=2)
         result["kernels"] = {k["name"]: {"avg_us": round(k["avg_us"], 2), "launches": k["launches"], "GBps": round(k["gbps"], 1)} for k in prof}
@@ -199,6 +214,8 @@ def main():
             oc = om.NewContext(ctx_size, ncpu, False)
             otoks, ologits = oc.GreedyDecode(PROMPT, nsteps + 1)
             oc.free()
+            oc = om.NewContext(ctx_size, ncpu, False)
+            osampled = oc.SampleDecode(PROMPT, nsteps + 1, **SMP)
             # one scalar step on ONE thread for the 1-thread figure of BASELINE.md row A
             oc1 = om.NewContext(ctx_size, 1, False)
             t2 = time.perf_counter()
@@ -231,6 +248,7 @@ def main():
                 "token_ids_match": gt[: nsteps + 1] == list(otoks[: nsteps + 1]) and gt[1: nsteps + 1] == produced[:nsteps],
                 "max_rel_logit_err": max([rel0] + rels), "tolerance": 1e-4, "steps_compared": nsteps + 1,
                 "min_top2_margin_rel": float(((srt[:, -1] - srt[:, -2]) / np.abs(ologits).max(axis=-1)).min()),
+                "sampled_token_ids_match": list(sampled[: nsteps + 1]) == list(osampled),
             }
         ctx.free()
         model.free()

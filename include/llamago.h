@@ -124,6 +124,20 @@ ml_context* llama_MLContext(llama_context* lctx);
 int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prompt, uint32_t n_prompt,
                        uint32_t n_predict, uint32_t* out_tokens, float* step_logits);
 
+/* SampleTopPTopK (llama.go:455-707).  Differences in the SIGNATURE only: the container/ring of the reference
+ * (server.go:127) arrives as the array of its contents (the reference scans the whole ring, llama.go:509, so only
+ * membership matters); the wall-clock seed of llama.go:658 becomes the explicit (seed, draw) pair, draw = index of
+ * the sampling call; the id is returned through *token so that errors can be reported (0 = ok).  `ctx` selects the
+ * device in the product and is ignored by the CPU checker.  Equal values sort by ascending id. */
+int llama_SampleTopPTopK(ml_context* ctx, const float* logits, uint32_t logitsCount, const uint32_t* lastNTokens,
+                         uint32_t lastNTokensSize, uint32_t topK, float topP, float temp, float repeatPenalty,
+                         uint64_t seed, uint64_t draw, uint32_t* token);
+/* The generation loop of server.Do (server.go:127-217) with that sampler: ring of CtxSize zeros, prompt ids appended
+ * and evaluated in one Eval, then n_predict x { sample (draw = s) -> append -> Eval(N = 1) }, no Eval after the last
+ * sample, no context swap (prompt + predictions must fit CtxSize). */
+int llama_SampleDecode(llama_context* lctx, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict,
+                       uint32_t topK, float topP, float temp, float repeatPenalty, uint64_t seed, uint32_t* out_tokens);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,32 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
                    uint32_t n, uint32_t past, float* logits_dev, uint32_t* argmax_dev);
 /* Time each kernel class of one decode step with HIP events on the context's stream (eager launches,
  * same kernels as the replayed graph).  Writes up to cap entries; returns the number of classes. */
+/* ---- sampler on the device --------------------------------------------------------------
+ * SampleTopPTopK (llama.go:455-707): repeat penalty over the whole lastNTokens ring (llama.go:497-525), sort + topK
+ * (llama.go:548-567), softmax with f64 exp (llama.go:581-609), topP cut (llama.go:623-639), then the reference's
+ * "probs^2 * rand^2, first maximum" pick (llama.go:661-673).  The reference seeds math/rand from the clock on every
+ * call (llama.go:658); here the uniforms come from a counter-based generator over (seed, call index, rank), so a
+ * run is reproducible.  Ties in the sort (unspecified in the reference, sort.Slice) go to the lower token id. */
+typedef struct lh_sample_params {
+    uint32_t top_k;        /* ModelParams.TopK, 40 (main.go:87); 1..min(vocab, 1024) */
+    float top_p;           /* 0.95 (main.go:88); >= 1 disables the cut */
+    float temp;            /* > 0 (main.go:379-381 turns 0 into 0.5) */
+    float repeat_penalty;  /* 1.10 (main.go:90) */
+    uint64_t seed;
+} lh_sample_params;
+/* One call on host logits (op-level parity): last_n_tokens = the ring contents (membership only, order free).
+ * cand_ids / cand_probs / n_keep (optional, top_k entries) return the kept candidates in rank order after the
+ * topP rescale, i.e. the reference's logitsID / probs right before the random pick. */
+int lh_sample_top_p_top_k(lh_ctx* ctx, const float* logits, uint32_t n_logits, const uint32_t* last_n_tokens, uint32_t n_last,
+                          const lh_sample_params* sp, uint64_t draw, uint32_t* token_out,
+                          uint32_t* cand_ids, float* cand_probs, uint32_t* n_keep);
+/* The generation loop of server.Do (server.go:127-217) resident on the device: ring of ring_size zeros
+ * (server.go:127-138; the reference uses CtxSize), prompt ids appended and evaluated in one Eval, then
+ * n_predict x { sample -> append -> Eval(N = 1) } with no Eval after the last sample.  Sampling call s uses draw = s.
+ * No host round trip per token; out_tokens gets the n_predict sampled ids. */
+int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t ring_size,
+                           const lh_sample_params* sp, uint32_t* out_tokens);
+
 typedef struct lh_kernel_time { char name[48]; uint32_t launches; float total_ms; uint64_t bytes_per_launch; } lh_kernel_time;
 int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap);
 

@@ -5,6 +5,8 @@
 
 namespace lh {
 
+struct SampleState;
+
 struct LayerW {
     const float *attn_norm = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
     // block-int8 models: scale planes of the seven matrices (the pointers above are then the int8 planes)
@@ -52,6 +54,12 @@ struct Plan {
     hipGraphExec_t exec_step = nullptr;       // one Eval(N=1): embed .. logits
     hipGraphExec_t exec_step_adv = nullptr;   // the same + argmax + advance (resident greedy loop)
     hipGraph_t graph_step = nullptr, graph_step_adv = nullptr;
+    hipGraphExec_t exec_step_smp = nullptr;   // the same + device sampler + advance (resident sampling loop)
+    hipGraph_t graph_step_smp = nullptr;
+    struct SampleState* ss_dev = nullptr;     // sampler parameters + counters (read by the captured sampler kernel)
+    uint32_t* ring_dev = nullptr;             // lastNTokens ring
+    uint32_t ring_cap = 0;
+    uint32_t smp_topk = 0;                    // topK the sampler launches (and the captured graph) were chosen for
     uint32_t slot_counter = 0;   // round-robin over the pinned StepParams slots of eager (non-graph) steps
     bool use_graph = true;
 };
@@ -66,6 +74,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
 int plan_enqueue_decode(Plan* p, const float* x_in_dev, float* x_out_dev, bool with_argmax_advance, lh_kernel_time* prof, uint32_t prof_cap, uint32_t* prof_n);
 int plan_decode_step(Plan* p, uint32_t token, uint32_t past);  // graph replay of one step; logits in p->logits
 void destroy_plans(lh_ctx* ctx);
+
+// sample.hip
+int sample_check(lh_ctx* ctx, const lh_sample_params* sp, uint32_t V);
+int sample_launch(lh_ctx* ctx, const float* logits, uint32_t V, SampleState* st, uint32_t* ring, StepParams* sp, uint32_t* out_tokens, uint32_t* token_out,
+                  uint32_t* dbg_ids, float* dbg_probs, uint32_t* dbg_keep, int advance, uint32_t topk_hint);
 
 }  // namespace lh
 

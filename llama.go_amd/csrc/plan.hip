@@ -5,6 +5,7 @@
 #include "kernels_llama.h"
 #include "kernels_gemm.h"
 #include "kernels_q8.h"
+#include "kernels_sample.h"
 #include <math.h>
 #include <algorithm>
 
@@ -320,6 +321,8 @@ int plan_ensure_rows(Plan* p, uint32_t n) {
     if (p->exec_step_adv) { hipGraphExecDestroy(p->exec_step_adv); p->exec_step_adv = nullptr; }
     if (p->graph_step) { hipGraphDestroy(p->graph_step); p->graph_step = nullptr; }
     if (p->graph_step_adv) { hipGraphDestroy(p->graph_step_adv); p->graph_step_adv = nullptr; }
+    if (p->exec_step_smp) { hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr; }
+    if (p->graph_step_smp) { hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr; }
     return 0;
 }
 
@@ -357,6 +360,10 @@ void plan_destroy(Plan* p) {
     hipStreamSynchronize(p->ctx->stream);
     if (p->exec_step) hipGraphExecDestroy(p->exec_step);
     if (p->exec_step_adv) hipGraphExecDestroy(p->exec_step_adv);
+    if (p->exec_step_smp) hipGraphExecDestroy(p->exec_step_smp);
+    if (p->graph_step_smp) hipGraphDestroy(p->graph_step_smp);
+    if (p->ss_dev) hipFree(p->ss_dev);
+    if (p->ring_dev) hipFree(p->ring_dev);
     if (p->graph_step) hipGraphDestroy(p->graph_step);
     if (p->graph_step_adv) hipGraphDestroy(p->graph_step_adv);
     float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt};
@@ -385,7 +392,8 @@ void destroy_plans(lh_ctx* ctx) {
 }
 
 // ---- decode step (N = 1): 5 kernels per layer --------------------------------------------------------
-static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, bool argmax_advance, uint32_t* argmax_out,
+// advance: 0 = logits only, 1 = greedy argmax + loop bookkeeping, 2 = device sampler + loop bookkeeping
+static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, int argmax_advance, uint32_t* argmax_out,
                           const uint32_t* tokens_dev = nullptr, uint32_t logits_row = 0) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
@@ -444,7 +452,11 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         GemvArgs a = {};
         a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
         if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
-        if ((argmax_advance || argmax_out) && !g_prepare_only) {
+        if (argmax_advance == 2 && !g_prepare_only) {
+            ProfScope ps(ctx->stream, "sample", (uint64_t)m.V * 4);
+            TraceScope ts_(ctx->stream, "sample");
+            if ((rc = sample_launch(ctx, p->logits, m.V, p->ss_dev, p->ring_dev, (StepParams*)sp, p->out_tokens_dev, argmax_out, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
+        } else if ((argmax_advance || argmax_out) && !g_prepare_only) {
             ProfScope ps(ctx->stream, "argmax", (uint64_t)m.V * 4);
             TraceScope ts_(ctx->stream, "argmax");
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)p->logits, m.V, (StepParams*)sp, p->out_tokens_dev,
@@ -467,13 +479,15 @@ static int ensure_out_tokens(Plan* p, uint32_t n) {
     // graphs captured the old pointer
     if (p->exec_step_adv) { hipGraphExecDestroy(p->exec_step_adv); p->exec_step_adv = nullptr; }
     if (p->graph_step_adv) { hipGraphDestroy(p->graph_step_adv); p->graph_step_adv = nullptr; }
+    if (p->exec_step_smp) { hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr; }
+    if (p->graph_step_smp) { hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr; }
     return 0;
 }
 
-static int ensure_decode_graph(Plan* p, bool adv) {
+static int ensure_decode_graph(Plan* p, int adv) {
     lh_ctx* ctx = p->ctx;
-    hipGraphExec_t& exec = adv ? p->exec_step_adv : p->exec_step;
-    hipGraph_t& graph = adv ? p->graph_step_adv : p->graph_step;
+    hipGraphExec_t& exec = adv == 2 ? p->exec_step_smp : adv ? p->exec_step_adv : p->exec_step;
+    hipGraph_t& graph = adv == 2 ? p->graph_step_smp : adv ? p->graph_step_adv : p->graph_step;
     if (exec) return 0;
     if (adv) { int rc = ensure_out_tokens(p, 1); if (rc) return rc; }
     g_prepare_only = true;
@@ -732,6 +746,65 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
     }
     if (out_tokens) LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, p->logits, (size_t)md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LH_OK;
+}
+
+int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t ring_size, const lh_sample_params* sp,
+                           uint32_t* out_tokens) {
+    if (!m) return LH_EINVAL;
+    lh_ctx* ctx = m->ctx;
+    Plan* p = m->plan;
+    const ModelDesc& md = p->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!prompt || !n_prompt || !n_predict || !out_tokens) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_sample: empty prompt, no tokens to predict or null output");
+    if (!md.first_stage() || !md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_sample needs a whole-model plan");
+    if (ring_size == 0) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_sample: the lastNTokens ring needs at least one slot (the reference uses CtxSize, server.go:127)");
+    // the reference swaps context when pastCount + len(embd) > CtxSize (server.go:163-172); that re-evaluation is not part of this path
+    if ((uint64_t)n_prompt + n_predict - 1 > md.ctx)
+        LH_FAIL(ctx, LH_EINVAL, "decode: %u prompt + %u predicted tokens exceed the context window of %u", n_prompt, n_predict, md.ctx);
+    int rc;
+    if ((rc = sample_check(ctx, sp, md.V))) return rc;
+    if ((rc = ensure_out_tokens(p, n_predict))) return rc;
+    if (!p->ss_dev) LH_HIP(ctx, hipMalloc((void**)&p->ss_dev, sizeof(SampleState)));
+    if ((sp->top_k <= 64) != (p->smp_topk <= 64) && p->exec_step_smp) {  // the captured graph holds the kernel variant
+        hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr;
+        hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr;
+    }
+    p->smp_topk = sp->top_k;
+    if (ring_size > p->ring_cap) {  // the captured sampler holds the ring pointer
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p->ring_dev) LH_HIP(ctx, hipFree(p->ring_dev));
+        p->ring_dev = nullptr;
+        p->ring_cap = 0;
+        LH_HIP(ctx, hipMalloc((void**)&p->ring_dev, (size_t)ring_size * 4));
+        p->ring_cap = ring_size;
+        if (p->exec_step_smp) { hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr; }
+        if (p->graph_step_smp) { hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr; }
+    }
+    // ring: ring_size zeros, then the prompt ids (appendToken, server.go:129-138, 193-197): what remains is the last ring_size of them
+    {
+        std::vector<uint32_t> ring(ring_size, 0u);
+        for (uint32_t i = 0; i < n_prompt; ++i) ring[i % ring_size] = prompt[i];
+        SampleState st = {sp->top_k, sp->top_p, sp->temp, sp->repeat_penalty, sp->seed, 0, ring_size, n_prompt};
+        if ((rc = ensure_staging(ctx, (uint64_t)ring_size * 4 + sizeof st))) return rc;
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
+        memcpy(ctx->staging, ring.data(), (size_t)ring_size * 4);
+        memcpy((char*)ctx->staging + (size_t)ring_size * 4, &st, sizeof st);
+        LH_HIP(ctx, hipMemcpyAsync(p->ring_dev, ctx->staging, (size_t)ring_size * 4, hipMemcpyHostToDevice, ctx->stream));
+        LH_HIP(ctx, hipMemcpyAsync(p->ss_dev, (char*)ctx->staging + (size_t)ring_size * 4, sizeof st, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((rc = plan_eval(p, prompt, nullptr, nullptr, n_prompt, 0))) return rc;
+    if (p->use_graph && n_predict > 1 && (rc = ensure_decode_graph(p, 2))) return rc;
+    // first sample on the last prompt row; the bookkeeping moves {past: n_prompt - 1, step: 0} to {token, past: n_prompt, step: 1}
+    if ((rc = upload_step_params(p, 0, 0, n_prompt - 1, 0))) return rc;
+    const float* last_row = n_prompt == 1 ? p->logits : p->logits + (size_t)(n_prompt - 1) * md.V;
+    if ((rc = sample_launch(ctx, last_row, md.V, p->ss_dev, p->ring_dev, p->sp_dev, p->out_tokens_dev, nullptr, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
+    for (uint32_t s = 1; s < n_predict; ++s) {
+        if (p->use_graph) LH_HIP(ctx, hipGraphLaunch(p->exec_step_smp, ctx->stream));
+        else if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
+    }
+    LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_predict * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;
 }

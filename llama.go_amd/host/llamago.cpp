@@ -710,6 +710,32 @@ static lh_llama* resident(llama_context* c) {
     if (lh_llama_create(c->mlctx->hip, &d, &c->resident)) { g_err = lh_last_error(c->mlctx->hip); return nullptr; }
     return c->resident;
 }
+// ---- sampler (llama.go:455-707) on the device ----------------------------------------------------------------
+int llamago_SampleDebug(ml_context* ctx, const float* logits, uint32_t logitsCount, const uint32_t* lastNTokens, uint32_t lastNTokensSize, uint32_t topK, float topP,
+                        float temp, float repeatPenalty, uint64_t seed, uint64_t draw, uint32_t* token, uint32_t* cand_ids, float* cand_probs, uint32_t* n_keep) {
+    if (!ctx) { g_err = "llama_SampleTopPTopK: no context"; return 1; }
+    const lh_sample_params sp = {topK, topP, temp, repeatPenalty, seed};
+    if (lh_sample_top_p_top_k(ctx->hip, logits, logitsCount, lastNTokens, lastNTokensSize, &sp, draw, token, cand_ids, cand_probs, n_keep)) {
+        g_err = lh_last_error(ctx->hip);
+        return 1;
+    }
+    return 0;
+}
+int llama_SampleTopPTopK(ml_context* ctx, const float* logits, uint32_t logitsCount, const uint32_t* lastNTokens, uint32_t lastNTokensSize, uint32_t topK, float topP,
+                         float temp, float repeatPenalty, uint64_t seed, uint64_t draw, uint32_t* token) {
+    return llamago_SampleDebug(ctx, logits, logitsCount, lastNTokens, lastNTokensSize, topK, topP, temp, repeatPenalty, seed, draw, token, nullptr, nullptr, nullptr);
+}
+static lh_llama* resident(llama_context* c);
+int llama_SampleDecode(llama_context* c, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t topK, float topP, float temp,
+                       float repeatPenalty, uint64_t seed, uint32_t* out_tokens) {  // server.go:127-217, resident on the device
+    if (!c || c->model != m) { g_err = "llama_SampleDecode: context does not belong to this model"; return 1; }
+    lh_llama* r = resident(c);
+    if (!r) return 1;
+    const lh_sample_params sp = {topK, topP, temp, repeatPenalty, seed};
+    if (lh_llama_decode_sample(r, prompt, n_prompt, n_predict, c->ctxSize, &sp, out_tokens)) { g_err = lh_last_error(c->mlctx->hip); return 1; }
+    return 0;
+}
+
 int llamago_DecodeGreedyResident(llama_context* c, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last) {
     lh_llama* r = resident(c);
     if (!r) return 1;

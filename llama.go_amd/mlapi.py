@@ -88,6 +88,10 @@ class MLLib:
         sig("llama_Logits", c_f32p, VP)
         sig("llama_MLContext", VP, VP)
         sig("llama_GreedyDecode", C.c_int, VP, VP, c_u32p, c_u32, c_u32, c_u32p, c_f32p)
+        sig("llama_SampleTopPTopK", C.c_int, VP, c_f32p, c_u32, c_u32p, c_u32, c_u32, C.c_float, C.c_float, C.c_float, c_u64, c_u64, c_u32p)
+        sig("llama_SampleDecode", C.c_int, VP, VP, c_u32p, c_u32, c_u32, c_u32, C.c_float, C.c_float, C.c_float, c_u64, c_u32p)
+        sig("llamago_SampleDebug", C.c_int, VP, c_f32p, c_u32, c_u32p, c_u32, c_u32, C.c_float, C.c_float, C.c_float, c_u64, c_u64, c_u32p,
+            c_u32p, c_f32p, c_u32p)
 
     # ---- helpers -------------------------------------------------------------------------------
     def last_error(self):
@@ -97,6 +101,27 @@ class MLLib:
         if not handle:
             raise MLError(f"{what}: {self.last_error()}")
         return handle
+
+    # ---- llama.SampleTopPTopK (llama.go:455-707) ------------------------------------------------
+    def SampleTopPTopK(self, ctx, logits, lastNTokens, topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=0, draw=0, debug=False):
+        """One sampling call.  debug=True also returns (candidate ids, probabilities) in rank order after the topP rescale."""
+        lg = np.ascontiguousarray(logits, dtype=np.float32)
+        ring = (c_u32 * max(1, len(lastNTokens)))(*[int(t) for t in lastNTokens])
+        tok = c_u32(0)
+        if not debug:
+            rc = self.lib.llama_SampleTopPTopK(ctx, lg.ctypes.data_as(c_f32p), lg.size, ring, len(lastNTokens), topK, topP, temp, repeatPenalty, seed, draw,
+                                               C.byref(tok))
+            if rc:
+                raise MLError(f"llama_SampleTopPTopK: {self.last_error()}")
+            return tok.value
+        ids = (c_u32 * topK)()
+        probs = np.zeros(topK, dtype=np.float32)
+        keep = c_u32(0)
+        rc = self.lib.llamago_SampleDebug(ctx, lg.ctypes.data_as(c_f32p), lg.size, ring, len(lastNTokens), topK, topP, temp, repeatPenalty, seed, draw,
+                                          C.byref(tok), ids, probs.ctypes.data_as(c_f32p), C.byref(keep))
+        if rc:
+            raise MLError(f"llama_SampleTopPTopK: {self.last_error()}")
+        return tok.value, list(ids)[:keep.value], probs[:keep.value].copy()
 
     # ---- ml.* ------------------------------------------------------------------------------------
     def NewContext(self, maxThreads=1, useAVX=False, useNEON=False):
@@ -276,6 +301,14 @@ class Context:
         if rc:
             raise MLError(f"llama_GreedyDecode: {self.ml.last_error()}")
         return list(out), lg
+
+    def SampleDecode(self, prompt, n_predict, topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=0):
+        """server.Do's generation loop (server.go:127-217) with SampleTopPTopK; returns the n_predict sampled ids."""
+        toks = (c_u32 * len(prompt))(*[int(t) for t in prompt])
+        out = (c_u32 * n_predict)()
+        if self.ml.lib.llama_SampleDecode(self.h, self.model.h, toks, len(prompt), n_predict, topK, topP, temp, repeatPenalty, seed, out):
+            raise MLError(f"llama_SampleDecode: {self.ml.last_error()}")
+        return list(out)
 
     def free(self):
         if self.h:
