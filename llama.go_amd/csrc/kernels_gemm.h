@@ -35,6 +35,34 @@ struct GemmArgs {
 
 constexpr int GBK = 32;
 
+// C/D layout (dtype-independent on gfx950): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+// The residual is fetched for a whole 32 x 32 block before any of it is used, through clamped (always valid) addresses: a load
+// inside `if (n < N && m < M)` waits out a memory latency per element (80 dependent round trips per lane, ~40 us per tile).
+template <int TN, int TM>
+__device__ __forceinline__ void gemm_store(const GemmArgs& a, f16v (&acc)[TN][TM], float* Y, const float* R, uint32_t nb, uint32_t mb, int li, int lh) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const uint32_t m = mb + j * 32 + li;
+            const uint32_t mc = m < a.M ? m : a.M - 1;
+            float rv[16];
+            if (R) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t n = nb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    rv[e] = R[(size_t)(n < a.N ? n : a.N - 1) * a.ldy + mc];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t n = nb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (n < a.N && m < a.M) Y[(size_t)n * a.ldy + m] = R ? __fadd_rn(acc[i][j][e], rv[e]) : acc[i][j][e];
+            }
+        }
+}
+
+
 template <int WN, int WM, int TN, int TM>
 __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
     static_assert(WN * WM == 4, "4 waves");
@@ -101,6 +129,9 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#ifndef GEMM_ABL
+#define GEMM_ABL 0   // tools/gemm_probe.hip: 1 = no global fetch, 2 = + no LDS stash, 3 = + no barrier, 4 = + operands not re-read from LDS
+#endif
     const uint32_t nk = a.K / GBK;
     fetch(0);
     stash(0);
@@ -108,41 +139,126 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     for (uint32_t kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) fetch((kt + 1) * GBK);
+        if (GEMM_ABL < 1 && kt + 1 < nk) fetch((kt + 1) * GBK);
         const float* xs = Xs + buf * GBK * LDX + wn * TN * 32 + li;
         const float* ws = Ws + buf * GBK * LDW + wm * TM * 32 + li;
 #pragma unroll
         for (int ks = 0; ks < GBK; ks += 2) {
             float af[TN], bf[TM];
+            const int kr = GEMM_ABL >= 4 ? 0 : ks;
 #pragma unroll
-            for (int i = 0; i < TN; ++i) af[i] = xs[(ks + lh) * LDX + 32 * i];
+            for (int i = 0; i < TN; ++i) af[i] = xs[(kr + lh) * LDX + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = ws[(ks + lh) * LDW + 32 * j];
+            for (int j = 0; j < TM; ++j) bf[j] = ws[(kr + lh) * LDW + 32 * j];
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) stash(buf ^ 1);
-        __syncthreads();
+        if (GEMM_ABL < 2 && kt + 1 < nk) stash(buf ^ 1);
+        if (GEMM_ABL < 3) __syncthreads();
     }
-    // C/D layout (dtype-independent on gfx950): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+}
+
+// ---- the same GEMM with LDS-DMA operand staging --------------------------------------------------------------------
+// tools/gemm_probe (13B prefill shapes) prices the register-staged kernel above at 70-75 % of the 155.7 TFLOP/s this chip
+// sustains on bare v_mfma_f32_32x32x2_f32: global loads into staging registers cost 6-14 points, the 4-byte transposing LDS
+// stores 5-7, the 4-byte operand reads 8; the barrier itself is free.  This variant removes all three:
+//   * operands travel global -> LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass).  The LDS image is
+//     row-major, 32 floats = 128 B per tile row, 8 rows = 1 KB per wave-instruction.  LDS-DMA writes lane-linearly, so the
+//     bank swizzle is applied on the SOURCE side: lane L of a piece (row L>>3, slot L&7) fetches 16-byte granule
+//     (L&7) ^ (L>>3) of its row — still one full 128-byte line per 8 lanes.
+//   * an MFMA step may pair any two k's as long as A and B agree, so lane (row i, half h) takes one ds_read_b128 = granule
+//     2q+h of its row and feeds its 4 floats to 4 consecutive MFMAs (step e multiplies k = 8q+e and k = 8q+4+e): 4x fewer LDS
+//     instructions, conflict-free through the XOR on the slot (slot = granule ^ (row & 7)).
+//   * two LDS stages; per K-slab: wait for MY slab-kt pieces (vmcnt(0)), raw s_barrier (everybody's pieces landed, everybody
+//     is done reading the other stage), issue the pieces of slab kt+1, multiply slab kt.
+// Rows past N / M load a clamped address; their products land in accumulator entries the epilogue never stores.
+// Accumulation order differs from the kernel above (k pairs re-grouped): a different fixed order of exact-f32 fmaf, the same
+// class of difference as any other summation order (|diff| ~ 1e-7 relative).
+template <int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
+    static_assert(WN * WM == 4, "4 waves");
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, ROWS = BN + BM, STAGE = ROWS * 32, PIECES = ROWS / 8, PPW = PIECES / 4;
+    static_assert(PIECES % 4 == 0, "pieces divide over the 4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][ROWS][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
+    uint32_t bid = blockIdx.x;
+    if (total % 8 == 0) {
+        const uint32_t per = total / 8;
+        bid = (bid % 8) * per + bid / 8;
+    }
+    const uint32_t g = bid / per_group, t = bid % per_group;
+    const uint32_t tm = t / tiles_n, tn = t % tiles_n;
+    const uint32_t n0 = tn * BN, m0 = tm * BM;
+    const uint32_t ldw = a.ldw ? a.ldw : a.K;
+    const float* X = a.x + (size_t)blockIdx.y * a.xbs;
+    const float* W = a.w[g] + (size_t)blockIdx.y * a.wbs;
+    float* Y = a.y[g] + (size_t)blockIdx.y * a.ybs;
+    const float* R = a.r[g] ? a.r[g] + (size_t)blockIdx.y * a.ybs : nullptr;
+
+    // piece p (8 tile rows) is fetched by wave p % 4; this lane's source pointer for each of its pieces
+    const float* src[PPW];
+    const uint32_t gran = (uint32_t)((lane & 7) ^ (lane >> 3));
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        const uint32_t row = (uint32_t)(wave + 4 * pp) * 8 + (uint32_t)(lane >> 3);  // tile row: X rows first, then W rows
+        if (row < (uint32_t)BN) {
+            const uint32_t n = n0 + row;
+            src[pp] = X + (size_t)(n < a.N ? n : a.N - 1) * a.ldx + 4 * gran;
+        } else {
+            const uint32_t m = m0 + row - BN;
+            src[pp] = W + (size_t)(m < a.M ? m : a.M - 1) * ldw + 4 * gran;
+        }
+    }
+    auto issue = [&](int stage, uint32_t k0) {
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[pp] + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (wave + 4 * pp) * 256), 16, 0, 0);
+    };
+
+    f16v acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const uint32_t m = m0 + (wm * TM + j) * 32 + li;
+        for (int j = 0; j < TM; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t n = n0 + (wn * TN + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (n < a.N && m < a.M) {
-                    const size_t o = (size_t)n * a.ldy + m;
-                    float v = acc[i][j][e];
-                    if (R) v = __fadd_rn(v, R[o]);
-                    Y[o] = v;
-                }
-            }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5, sw = li & 7;
+    const uint32_t nk = a.K / GBK;
+    issue(0, 0);
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * GBK);
+        const float* xs = smem + (kt & 1) * STAGE + (wn * TN * 32 + li) * 32;
+        const float* ws = smem + (kt & 1) * STAGE + (BN + wm * TM * 32 + li) * 32;
+        // (requesting granule pair q+1 before the MFMAs of q through a second register set + scheduling barriers was measured:
+        // the same for a lone workgroup per CU, 5-6 points WORSE for two co-resident ones — left to hipcc's own schedule)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = ((2 * q + lh) ^ sw) * 4;
+            f4 af[TN], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) af[i] = *(const f4*)(xs + i * 32 * 32 + slot);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) bf[j] = *(const f4*)(ws + j * 32 * 32 + slot);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
+    }
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
 }
 
 // Scale + causal mask + softmax on the full score block S[h][j][0..Tp) in place (Scale ml.go:2331-2374, DiagMaskInf

@@ -150,13 +150,24 @@ static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
     return 0;
 }
 
+// LDS-DMA kernel when every tile row starts on a 16-byte boundary (the DMA moves 16-byte granules), register-staged one otherwise
+static bool gemm_dma_ok(const GemmArgs& a) {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    const uint32_t ldw = a.ldw ? a.ldw : a.K;
+    if (a.K % GBK || a.ldx % 4 || ldw % 4 || a.xbs % 4 || a.wbs % 4 || !al(a.x)) return false;
+    for (uint32_t g = 0; g < a.groups; ++g)
+        if (!al(a.w[g])) return false;
+    return true;
+}
+
 template <int WN, int WM, int TN, int TM>
 static int launch_gemm(lh_ctx* ctx, const GemmArgs& a, const char* name, uint32_t batch = 1) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
-    auto kern = k_gemm_mfma<WN, WM, TN, TM>;
-    static bool flags[16] = {};
-    const size_t lds = (size_t)2 * GBK * (BN + 1 + BM + 1) * sizeof(float);
-    int rc = set_lds_once(ctx, kern, lds, flags);
+    const bool dma = gemm_dma_ok(a) && !getenv("LLAMAHIP_GEMM_NO_DMA");
+    auto kern = dma ? k_gemm_glds<WN, WM, TN, TM> : k_gemm_mfma<WN, WM, TN, TM>;
+    static bool flags[2][16] = {};
+    const size_t lds = dma ? (size_t)2 * (BN + BM) * 32 * sizeof(float) : (size_t)2 * GBK * (BN + 1 + BM + 1) * sizeof(float);
+    int rc = set_lds_once(ctx, kern, lds, flags[dma ? 1 : 0]);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     const uint32_t tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.groups;
