@@ -89,7 +89,13 @@ typedef struct lh_tensor {
 } lh_tensor;
 
 enum { LH_T_OUTPUT = 1 /* host wants to read this node back (kept materialised by fused plans) */ };
-enum { LH_GRAPH_NO_FUSION = 1 /* run every node 1:1 with the generic kernels (debug / op-level parity tests) */ };
+enum {
+    LH_GRAPH_NO_FUSION = 1,        /* run every node 1:1 with the generic kernels (debug / op-level parity tests) */
+    LH_GRAPH_LAST_ROW_LOGITS = 2   /* caller reads only row N-1 of the final MulMat (what llama.Eval does: it builds the
+                                      lm_head for all N rows, llama.go:384, and copies out the last, llama.go:394-401): a
+                                      fused plan then evaluates the lm_head for that row only and leaves rows 0..N-2 of the
+                                      final node unwritten.  Ignored by the node-by-node path. */
+};
 
 int lh_graph_compute(lh_ctx* ctx, const lh_tensor* tensors, uint32_t n_leafs, uint32_t n_nodes, uint32_t flags);
 /* Read elements of a tensor of the LAST computed graph (flat, in storage order from the tensor's first

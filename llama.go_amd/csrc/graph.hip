@@ -406,7 +406,7 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
             int rc = 0;
             Plan* p = plan_find_or_create(ctx, m.md, &rc);
             if (!p) return rc;
-            if ((rc = plan_eval(p, m.tokens.data(), nullptr, nullptr, m.N, m.past))) return rc;
+            if ((rc = plan_eval(p, m.tokens.data(), nullptr, nullptr, m.N, m.past, (flags & LH_GRAPH_LAST_ROW_LOGITS) != 0))) return rc;
             LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
             ctx->last_ptr[total - 1] = p->logits;  // [N][V], the final node's layout (ne0 = V, ne1 = N)
             ctx->last_len[total - 1] = (uint64_t)m.N * m.md.V;

@@ -30,10 +30,19 @@ struct GemmArgs {
     const float* r[3];  // per group optional residual, same layout as y
     uint32_t groups, N, M, K, ldx, ldy;
     uint32_t ldw;                 // row pitch of W in floats (0 = K)
-    uint64_t xbs, wbs, ybs;       // blockIdx.y batch strides in floats (attention: one batch entry per head)
+    uint64_t xbs, wbs, ybs;       // batch strides in floats (attention: one batch entry per head)
+    uint32_t batch;               // k_gemm_glds: number of batch entries (0 = 1); k_gemm_mfma takes the batch from gridDim.y
+    // Causal structure of prefill attention (row n = query at position past + n, DiagMaskInf ml.go:2377-2414): the reference
+    // computes the full block and masks afterwards; the masked part contributes exact zeros, so it can be skipped.
+    //   causal = 1 (scores S = Q.K^T, columns = keys): a tile whose first key lies beyond its last query's position is not
+    //              computed (softmax rewrites those entries with 0 without reading them);
+    //   causal = 2 (O = P.V, contraction over keys): P[n][t] = 0 for t > past + n, so the K loop stops after the last key any
+    //              row of the tile can see.
+    uint32_t causal, past;
 };
 
 constexpr int GBK = 32;
+constexpr int GST = 3;  // LDS stages of k_gemm_glds
 
 // C/D layout (dtype-independent on gfx950): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // The residual is fetched for a whole 32 x 32 block before any of it is used, through clamped (always valid) addresses: a load
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
     const uint32_t g = bid / per_group, t = bid % per_group;
     const uint32_t tm = t / tiles_n, tn = t % tiles_n;  // n fastest: neighbours share the W panel
     const uint32_t n0 = tn * BN, m0 = tm * BM;
+    if (a.causal == 1 && m0 > a.past + n0 + BN - 1) return;
     const uint32_t ldw = a.ldw ? a.ldw : a.K;
     const float* X = a.x + (size_t)blockIdx.y * a.xbs;
     const float* W = a.w[g] + (size_t)blockIdx.y * a.wbs;
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
 #ifndef GEMM_ABL
 #define GEMM_ABL 0   // tools/gemm_probe.hip: 1 = no global fetch, 2 = + no LDS stash, 3 = + no barrier, 4 = + operands not re-read from LDS
 #endif
-    const uint32_t nk = a.K / GBK;
+    uint32_t nk = a.K / GBK;
+    if (a.causal == 2) nk = min(nk, (a.past + n0 + BN + GBK - 1) / GBK);
     fetch(0);
     stash(0);
     __syncthreads();
@@ -168,12 +179,12 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
 //   * operands travel global -> LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass).  The LDS image is
 //     row-major, 32 floats = 128 B per tile row, 8 rows = 1 KB per wave-instruction.  LDS-DMA writes lane-linearly, so the
 //     bank swizzle is applied on the SOURCE side: lane L of a piece (row L>>3, slot L&7) fetches 16-byte granule
-//     (L&7) ^ (L>>3) of its row — still one full 128-byte line per 8 lanes.
+//     (L&7) ^ key(row) of its row — still one full 128-byte line per 8 lanes.
 //   * an MFMA step may pair any two k's as long as A and B agree, so lane (row i, half h) takes one ds_read_b128 = granule
 //     2q+h of its row and feeds its 4 floats to 4 consecutive MFMAs (step e multiplies k = 8q+e and k = 8q+4+e): 4x fewer LDS
-//     instructions, conflict-free through the XOR on the slot (slot = granule ^ (row & 7)).
-//   * two LDS stages; per K-slab: wait for MY slab-kt pieces (vmcnt(0)), raw s_barrier (everybody's pieces landed, everybody
-//     is done reading the other stage), issue the pieces of slab kt+1, multiply slab kt.
+//     instructions, conflict-free through the XOR on the slot (slot = granule ^ key(row), key = (row >> 1) & 7).
+//   * a ring of GST LDS stages; once per K-slab: counted vmcnt (MY pieces of the next slab landed, newer ones stay in
+//     flight), raw s_barrier (everybody's landed), DMA of slab kt+GST into the stage just drained.
 // Rows past N / M load a clamped address; their products land in accumulator entries the epilogue never stores.
 // Accumulation order differs from the kernel above (k pairs re-grouped): a different fixed order of exact-f32 fmaf, the same
 // class of difference as any other summation order (|diff| ~ 1e-7 relative).
@@ -182,28 +193,41 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     static_assert(WN * WM == 4, "4 waves");
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32, ROWS = BN + BM, STAGE = ROWS * 32, PIECES = ROWS / 8, PPW = PIECES / 4;
     static_assert(PIECES % 4 == 0, "pieces divide over the 4 waves");
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][ROWS][32]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [GST][ROWS][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
     const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
-    uint32_t bid = blockIdx.x;
-    if (total % 8 == 0) {
-        const uint32_t per = total / 8;
-        bid = (bid % 8) * per + bid / 8;
-    }
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups, work = total * (a.batch ? a.batch : 1);
+    const uint32_t ldw = a.ldw ? a.ldw : a.K;
+    const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
+    const uint32_t nk_full = a.K / GBK;
+    // Persistent workgroups, ONE per CU (the host pads the LDS request so that two cannot co-reside): with the software
+    // pipeline below a lone workgroup keeps the matrix pipe busier (84-86 %) than two co-resident ones (81-83 %), and a grid of
+    // perfectly balanced tiles otherwise ends with the last partial round packed two-per-CU onto half of the chip.
+    // Work item w = batch entry * tiles + tile; workgroup b owns w = v, v + G, v + 2G, ... with v = (b % 8) * G/8 + b / 8:
+    // the workgroups of one XCD (b % 8, observed round-robin; speed only) run CONSECUTIVE tiles, n fastest, so the tiles that
+    // share a weight panel meet in one L2.
+    const uint32_t G = gridDim.x;
+    const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+  for (uint32_t wi = v0; wi < work; wi += G) {
+    const uint32_t be = wi / total, bid = wi % total;
     const uint32_t g = bid / per_group, t = bid % per_group;
     const uint32_t tm = t / tiles_n, tn = t % tiles_n;
     const uint32_t n0 = tn * BN, m0 = tm * BM;
-    const uint32_t ldw = a.ldw ? a.ldw : a.K;
-    const float* X = a.x + (size_t)blockIdx.y * a.xbs;
-    const float* W = a.w[g] + (size_t)blockIdx.y * a.wbs;
-    float* Y = a.y[g] + (size_t)blockIdx.y * a.ybs;
-    const float* R = a.r[g] ? a.r[g] + (size_t)blockIdx.y * a.ybs : nullptr;
+    if (a.causal == 1 && m0 > a.past + n0 + BN - 1) continue;
+    const uint32_t nk = a.causal == 2 ? min(nk_full, (a.past + n0 + BN + GBK - 1) / GBK) : nk_full;
+    const float* X = a.x + (size_t)be * a.xbs;
+    const float* W = a.w[g] + (size_t)be * a.wbs;
+    float* Y = a.y[g] + (size_t)be * a.ybs;
+    const float* R = a.r[g] ? a.r[g] + (size_t)be * a.ybs : nullptr;
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
 
     // piece p (8 tile rows) is fetched by wave p % 4; this lane's source pointer for each of its pieces
     const float* src[PPW];
-    const uint32_t gran = (uint32_t)((lane & 7) ^ (lane >> 3));
+    // swizzle key of tile row r = (r >> 1) & 7: a 128-byte row covers HALF of the 64 LDS banks (even rows the lower half, odd
+    // rows the upper), so the 8 rows of equal parity among 16 consecutive ones must land in 8 different granule slots
+    // (with key = r & 7 SQ_LDS_BANK_CONFLICT was 50 % of the LDS-active cycles).  Row of lane L in piece P: 8 P + (L >> 3).
+    const uint32_t gran = (uint32_t)((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7));
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
         const uint32_t row = (uint32_t)(wave + 4 * pp) * 8 + (uint32_t)(lane >> 3);  // tile row: X rows first, then W rows
@@ -215,10 +239,10 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
             src[pp] = W + (size_t)(m < a.M ? m : a.M - 1) * ldw + 4 * gran;
         }
     }
-    auto issue = [&](int stage, uint32_t k0) {
+    auto issue = [&](int stage, uint32_t k0, int p0, int p1) {
 #pragma unroll
-        for (int pp = 0; pp < PPW; ++pp)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[pp] + k0),
+        for (int pp = p0; pp < p1; ++pp)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GEMM_ABL == 8 ? a.x + lane * 4 : src[pp] + k0),
                                              (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (wave + 4 * pp) * 256), 16, 0, 0);
     };
 
@@ -230,35 +254,79 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int li = lane & 31, lh = lane >> 5, sw = li & 7;
-    const uint32_t nk = a.K / GBK;
-    issue(0, 0);
-    for (uint32_t kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Software pipeline.  Inside a slab the operands of granule pair q+1 are read (second register set) in the MIDDLE of the
+    // MFMAs of q, so neither the reads' latency nor their issue slots stall the matrix pipe (sched_group_barrier pins the
+    // interleaving: mask 0x008 = MFMA, 0x100 = DS read; left alone hipcc puts each q's reads directly in front of their first
+    // use).  The slab boundary sits in the middle of q = 3: by then every read of the current stage has completed (its data
+    // feeds MFMAs already issued), so after "my pieces of the next slab landed" + s_barrier the wave may read q = 0 of the next
+    // stage AND start the DMA of slab kt+2 into the current one, all under the second half of q = 3's MFMAs.
+    constexpr int NM = 4 * TN * TM, NR = TN + TM;
+    f4 af[2][TN], bf[2][TM];
+    auto fetch_ops = [&](int set, int stage, int q) {
+        const float* xs = smem + stage * STAGE + (wn * TN * 32 + li) * 32;
+        const float* ws = smem + stage * STAGE + (BN + wm * TM * 32 + li) * 32;
+        const int slot = ((2 * q + lh) ^ sw) * 4;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) af[set][i] = *(const f4*)(xs + i * 32 * 32 + slot);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) bf[set][j] = *(const f4*)(ws + j * 32 * 32 + slot);
+    };
+    auto mfmas = [&](int set, int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; ++e)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][e], bf[set][j][e], acc[i][j], 0, 0, 0);
+    };
+    // GST stages in a ring, slab j in stage j % GST.  "Landed" = all but the newest GST-2 slabs of MY pieces have arrived
+    // (vmcnt counts in order), then the barrier makes that true for everybody's.  Slabs past the end re-read the last one
+    // (keeps the count uniform; harmless).
+    auto landed = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * (GST - 2)) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * GBK);
-        const float* xs = smem + (kt & 1) * STAGE + (wn * TN * 32 + li) * 32;
-        const float* ws = smem + (kt & 1) * STAGE + (BN + wm * TM * 32 + li) * 32;
-        // (requesting granule pair q+1 before the MFMAs of q through a second register set + scheduling barriers was measured:
-        // the same for a lone workgroup per CU, 5-6 points WORSE for two co-resident ones — left to hipcc's own schedule)
+    };
+    auto slab_k0 = [&](uint32_t j) { return (j < nk ? j : nk - 1) * GBK; };
+    // DMA schedule: slab kt+GST-1 is requested DURING slab kt, a third of its pieces after the first MFMA half of each of
+    // q = 0, 1, 2, into the stage drained at the previous boundary.  (All PPW instructions back to back at the boundary cost
+    // 7-8 % of the MFMA time: the wave cannot issue MFMAs while the texture path takes its 1-KB requests, and the matrix pipe
+    // holds only the one in flight.)
+    constexpr int P1 = (PPW + 2) / 3, P2 = (2 * PPW + 2) / 3;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int slot = ((2 * q + lh) ^ sw) * 4;
-            f4 af[TN], bf[TM];
-#pragma unroll
-            for (int i = 0; i < TN; ++i) af[i] = *(const f4*)(xs + i * 32 * 32 + slot);
-#pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = *(const f4*)(ws + j * 32 * 32 + slot);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < GST - 1; ++j) issue(j, slab_k0(j), 0, PPW);
+    landed();
+    fetch_ops(0, 0, 0);
+    uint32_t st = 0, sp = GST - 1;  // kt % GST, (kt - 1) % GST
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        const uint32_t kn = slab_k0(kt + GST - 1);
+#define LH_GEMM_QBLOCK(q, p0, p1)                                                                      \
+        if (GEMM_ABL < 7 || GEMM_ABL >= 8) fetch_ops(((q) + 1) & 1, st, (q) + 1);                                       \
+        if (GEMM_ABL < 5 || GEMM_ABL >= 8) issue(sp, kn, p0, p1);                                                       \
+        mfmas((q) & 1, 0, 4);                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / 2, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x020, (p1) - (p0), 0);                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NM / 2, 0);
+        LH_GEMM_QBLOCK(0, 0, P1)
+        LH_GEMM_QBLOCK(1, P1, P2)
+        LH_GEMM_QBLOCK(2, P2, PPW)
+#undef LH_GEMM_QBLOCK
+        mfmas(1, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            const uint32_t sn = st + 1 == GST ? 0 : st + 1;
+            if (GEMM_ABL < 6 || GEMM_ABL == 8) landed();
+            if (GEMM_ABL < 7 || GEMM_ABL >= 8) fetch_ops(0, sn, 0);
+            sp = st;
+            st = sn;
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 2, 4);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
     gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+  }
 }
 
 // Scale + causal mask + softmax on the full score block S[h][j][0..Tp) in place (Scale ml.go:2331-2374, DiagMaskInf

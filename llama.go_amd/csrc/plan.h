@@ -69,7 +69,7 @@ void plan_destroy(Plan* p);
 Plan* plan_find_or_create(lh_ctx* ctx, const ModelDesc& md, int* rc);
 int plan_ensure_rows(Plan* p, uint32_t n);
 // One llama.Eval on the plan: tokens (host) or x_in (device) -> logits rows in p->logits ([n][V]) or x_out (non-last stage).
-int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past);
+int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only = false);
 // enqueue the kernels of one decode step (N = 1), parameters from p->sp_dev
 int plan_enqueue_decode(Plan* p, const float* x_in_dev, float* x_out_dev, bool with_argmax_advance, lh_kernel_time* prof, uint32_t prof_cap, uint32_t* prof_n);
 int plan_decode_step(Plan* p, uint32_t token, uint32_t past);  // graph replay of one step; logits in p->logits

@@ -161,18 +161,34 @@ static bool gemm_dma_ok(const GemmArgs& a) {
 }
 
 template <int WN, int WM, int TN, int TM>
-static int launch_gemm(lh_ctx* ctx, const GemmArgs& a, const char* name, uint32_t batch = 1) {
+static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32_t batch = 1) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
-    const bool dma = gemm_dma_ok(a) && !getenv("LLAMAHIP_GEMM_NO_DMA");
-    auto kern = dma ? k_gemm_glds<WN, WM, TN, TM> : k_gemm_mfma<WN, WM, TN, TM>;
-    static bool flags[2][16] = {};
-    const size_t lds = dma ? (size_t)2 * (BN + BM) * 32 * sizeof(float) : (size_t)2 * GBK * (BN + 1 + BM + 1) * sizeof(float);
-    int rc = set_lds_once(ctx, kern, lds, flags[dma ? 1 : 0]);
-    if (rc) return rc;
-    if (g_prepare_only) return 0;
+    GemmArgs a = a0;
+    // the DMA ring needs a few slabs to pay for its prologue and its GST-1 redundant tail slabs: short contractions (Q.K^T, K = 128)
+    // stay on the register-staged kernel
+    const bool dma = gemm_dma_ok(a) && a.K >= 16 * GBK && !getenv("LLAMAHIP_GEMM_NO_DMA");
     const uint32_t tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.groups;
+    static bool flags[2][16] = {};
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4 * a.groups);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(256), lds, ctx->stream, a);
+    if (dma) {
+        // persistent: one workgroup per CU (the LDS request is padded past half a CU's 160 KB so that two never co-reside), each
+        // looping over its share of the tiles x batch entries
+        auto kern = k_gemm_glds<WN, WM, TN, TM>;
+        const size_t lds = std::max<size_t>((size_t)GST * (BN + BM) * 32 * sizeof(float), 82 * 1024);
+        int rc = set_lds_once(ctx, kern, lds, flags[1]);
+        if (rc) return rc;
+        if (g_prepare_only) return 0;
+        a.batch = batch;
+        const uint64_t work = (uint64_t)tiles * batch;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->ds->num_cu)), dim3(256), lds, ctx->stream, a);
+    } else {
+        auto kern = k_gemm_mfma<WN, WM, TN, TM>;
+        const size_t lds = (size_t)2 * GBK * (BN + 1 + BM + 1) * sizeof(float);
+        int rc = set_lds_once(ctx, kern, lds, flags[0]);
+        if (rc) return rc;
+        if (g_prepare_only) return 0;
+        hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(256), lds, ctx->stream, a);
+    }
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -203,6 +219,7 @@ static int attention_gemm(Plan* p, const float* q, const float* kc, const float*
         GemmArgs a = {};
         a.x = q; a.w[0] = kc; a.y[0] = p->scores; a.groups = 1; a.N = n; a.M = T; a.K = hd; a.ldx = d; a.ldw = d; a.ldy = Tp;
         a.xbs = hd; a.wbs = hd; a.ybs = (uint64_t)n * Tp;
+        a.causal = 1; a.past = past;
         if ((rc = launch_gemm<2, 2, 2, 2>(ctx, a, "attn_qk_gemm", H))) return rc;
     }
     hipLaunchKernelGGL(k_softmax_causal, dim3(n, H), dim3(256), 0, ctx->stream, p->scores, n, Tp, past, scale);
@@ -212,6 +229,7 @@ static int attention_gemm(Plan* p, const float* q, const float* kc, const float*
         GemmArgs a = {};
         a.x = p->scores; a.w[0] = p->vt; a.y[0] = out; a.groups = 1; a.N = n; a.M = hd; a.K = Tp; a.ldx = Tp; a.ldw = Tp; a.ldy = d;
         a.xbs = (uint64_t)n * Tp; a.wbs = (uint64_t)hd * Tp; a.ybs = hd;
+        a.causal = 2; a.past = past;
         if ((rc = launch_gemm<2, 2, 2, 1>(ctx, a, "attn_pv_gemm", H))) return rc;
     }
     return 0;
@@ -539,7 +557,7 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
 
 // ---- general Eval on the plan (N >= 1) ----------------------------------------------------------------
 
-int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past) {
+int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     if (n == 0) LH_FAIL(ctx, LH_EINVAL, "Eval: empty token batch");
@@ -625,9 +643,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         LH_HIP(ctx, hipGetLastError());
     }
     if (m.last_stage()) {
-        { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, m.norm, p->h, d); }
-        // the reference evaluates lm_head for all N rows (llama.go:384) although only row N-1 is read (llama.go:394-401)
-        if ((rc = gemm_small_n(ctx, m.output, p->h, p->logits, nullptr, m.V, d, n, d, m.V, "gemm_lmhead"))) return rc;
+        // the reference evaluates norm + lm_head for all N rows (llama.go:372-384) although only row N-1 is read (llama.go:394-401);
+        // callers that say so (LH_GRAPH_LAST_ROW_LOGITS, the lh_llama_* entry points) get that row only, in its usual place
+        const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
+        { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(nr), dim3(256), 0, ctx->stream, x + (size_t)r0 * d, m.norm, p->h + (size_t)r0 * d, d); }
+        if ((rc = gemm_small_n(ctx, m.output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_lmhead"))) return rc;
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -731,7 +751,7 @@ int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past
     Plan* p = m->plan;
     LH_HIP(ctx, hipSetDevice(ctx->device));
     if (!p->md.first_stage() || !p->md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_eval needs a whole-model plan; use lh_llama_stage");
-    int rc = plan_eval(p, tokens, nullptr, nullptr, n, past);
+    int rc = plan_eval(p, tokens, nullptr, nullptr, n, past, true);
     if (rc) return rc;
     if (logits_host)
         LH_HIP(ctx, hipMemcpyAsync(logits_host, p->logits + (size_t)(n - 1) * p->md.V, (size_t)p->md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -805,7 +825,7 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
         LH_HIP(ctx, hipMemcpyAsync(p->ring_dev, ctx->staging, (size_t)ring_size * 4, hipMemcpyHostToDevice, ctx->stream));
         LH_HIP(ctx, hipMemcpyAsync(p->ss_dev, (char*)ctx->staging + (size_t)ring_size * 4, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     }
-    if ((rc = plan_eval(p, prompt, nullptr, nullptr, n_prompt, 0))) return rc;
+    if ((rc = plan_eval(p, prompt, nullptr, nullptr, n_prompt, 0, true))) return rc;
     if (p->use_graph && n_predict > 1 && (rc = ensure_decode_graph(p, 2))) return rc;
     // first sample on the last prompt row; the bookkeeping moves {past: n_prompt - 1, step: 0} to {token, past: n_prompt, step: 1}
     if ((rc = upload_step_params(p, 0, 0, n_prompt - 1, 0))) return rc;
@@ -837,7 +857,7 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
         if ((rc = enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, md.last_stage() ? argmax_dev : nullptr, tokens ? nullptr : tokens_dev))) return rc;
     } else {
         if (md.first_stage() && !tokens) LH_FAIL(ctx, LH_EINVAL, "stage: multi-row first stage needs host token ids");
-        if ((rc = plan_eval(p, tokens, x_in_dev, x_out_dev, n, past))) return rc;
+        if ((rc = plan_eval(p, tokens, x_in_dev, x_out_dev, n, past, true))) return rc;
         if (md.last_stage() && argmax_dev) {
             hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)(p->logits + (size_t)(n - 1) * md.V), md.V, (StepParams*)nullptr,
                                (uint32_t*)nullptr, argmax_dev, 0);

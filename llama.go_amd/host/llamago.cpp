@@ -656,7 +656,10 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
         inpL = ml_Mul(ctx0, ml_Repeat(ctx0, model->norm, inpL), inpL);            // :377-379
         inpL = ml_MulMat(ctx0, model->output, inpL);                              // :384
         if (ml_BuildForwardExpand(graph, inpL)) break;                            // :387
-        if (ml_GraphCompute(ctx0, graph)) break;                                  // :389
+        {   // :389 — this caller reads only row N-1 of the result (:394-401) and says so
+            const char* e = getenv("LLAMAGO_NO_FUSION");
+            if (graph_compute(ctx0, graph, (e && e[0] == '1') ? LH_GRAPH_NO_FUSION : LH_GRAPH_LAST_ROW_LOGITS)) break;
+        }
         // :394-401 — only the last token's logits are copied out
         if (lh_node_read(ctx0->hip, inpL->last_index, (uint64_t)vocabSize * (N - 1), lctx->logits.data(), vocabSize)) { g_err = lh_last_error(ctx0->hip); break; }
         rc = 0;

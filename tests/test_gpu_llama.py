@@ -72,6 +72,33 @@ def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
     assert toks_h == toks_o
 
 
+def test_long_prefill_dma_gemm_and_causal_skip_match_oracle(product, oracle):
+    """Prompts long enough for every prefill GEMM to take the LDS-DMA kernel (contraction >= 512, incl. P.V over >= 512 keys) and
+    for the attention GEMMs to skip fully masked tiles — in one Eval and continued from a non-empty cache (past > 0)."""
+    kw = dict(SHAPES["small"])
+    kw["layers"] = 2
+    ctx = 640
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(7)
+    prompt = [int(t) for t in rng.integers(0, kw["vocab"], 600)]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 1234)
+        c = m.NewContext(ctx, 16, False)
+        one = c.Eval(prompt, 0)                    # N = 600, past = 0
+        nxt = c.Eval([5], 600)                     # decode step on the cache the prefill wrote
+        c.free()
+        c = m.NewContext(ctx, 16, False)
+        c.Eval(prompt[:264], 0)
+        two = c.Eval(prompt[264:], 264)            # N = 336, past = 264: P.V contracts over 608 (padded) keys
+        c.free()
+        m.free()
+        res[name] = (one, nxt, two)
+    for a, b in zip(res["hip"], res["orc"]):
+        assert rel(a, b) <= TOL
+    assert rel(res["hip"][0], res["hip"][2]) <= TOL   # chunked == single-shot
+
+
 def test_generic_path_matches_fused_and_oracle(product, oracle):
     """Node-by-node execution of the very same graph (what an arbitrary ml graph gets) agrees with both."""
     hp = make_hparams(**SHAPES["tiny"], ctx=32)

@@ -34,8 +34,15 @@ for _ in range(args.reps):
     lg = c.Eval(toks, 0)
     ts.append(time.perf_counter() - t0)
 dt = min(ts)
-flops_w = 2.0 * N * (L * (4 * d * d + 3 * d * F) + V * d)
-flops_a = L * 4.0 * N * N * d  # full (unmasked) score block, as the reference computes it
-print(json.dumps({"shape": args.shape, "layers": L, "N": N, "seconds": round(dt, 4), "tflop_weights": round(flops_w / 1e12, 2),
-                  "tflop_attention_full": round(flops_a / 1e12, 2), "TFLOPs_per_s_weights_only": round(flops_w / dt / 1e12, 1),
-                  "frac_of_157.3TF_fp32_mfma_peak": round(flops_w / dt / 157.3e12, 3), "logit_checksum": float(np.abs(lg).sum())}))
+# executed flops: the layer matmuls for all N rows, the lm_head for the ONE row llama.Eval reads (llama.go:394-401; the reference
+# itself multiplies all N rows, llama.go:384 — LH_GRAPH_LAST_ROW_LOGITS), attention over the causal half only
+flops_layers = 2.0 * N * L * (4 * d * d + 3 * d * F)
+flops_w = flops_layers + 2.0 * V * d
+flops_ref = flops_layers + 2.0 * N * V * d            # what the reference's graph multiplies
+flops_a = L * 4.0 * N * N * d                          # full (unmasked) score block, as the reference computes it
+print(json.dumps({"shape": args.shape, "layers": L, "N": N, "seconds": round(dt, 4), "tflop_weights_executed": round(flops_w / 1e12, 2),
+                  "tflop_weights_reference_graph": round(flops_ref / 1e12, 2), "tflop_attention_full": round(flops_a / 1e12, 2),
+                  "TFLOPs_per_s_weights_executed": round(flops_w / dt / 1e12, 1),
+                  "frac_of_157.3TF_fp32_mfma_peak": round(flops_w / dt / 157.3e12, 3),
+                  "TFLOPs_per_s_reference_graph_equivalent": round((flops_ref + flops_a) / dt / 1e12, 1),
+                  "logit_checksum": float(np.abs(lg).sum())}))

@@ -10,7 +10,8 @@ using namespace lh;
 template <int WN, int WM, int TN, int TM>
 static void run_glds(const char* name, uint32_t N, uint32_t M, uint32_t K, uint32_t groups, float* x, float* w, float* y) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
-    const size_t lds = (size_t)2 * (BN + BM) * 32 * sizeof(float);
+    size_t lds = (size_t)GST * (BN + BM) * 32 * sizeof(float);
+    if (lds < 82 * 1024) lds = 82 * 1024;
     auto kern = k_gemm_glds<WN, WM, TN, TM>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     GemmArgs a = {};
@@ -21,18 +22,19 @@ static void run_glds(const char* name, uint32_t N, uint32_t M, uint32_t K, uint3
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, 0, a);
+    const uint32_t grid = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a);
     hipDeviceSynchronize();
     const int reps = 5;
     hipEventRecord(e0);
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, 0, a);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
     const double fl = 2.0 * N * M * K * groups;
-    printf("GLDS  %-10s <%d,%d,%d,%d> tile %3dx%3d tiles %5u (%.2f/CU)  %8.1f us  %6.1f TFLOP/s  %.1f %%\n", name, WN, WM, TN, TM, BN, BM, tiles, tiles / 256.0, ms * 1e3,
+    printf("GLDS(abl %d) %-10s <%d,%d,%d,%d> tile %3dx%3d tiles %5u (%.2f/CU)  %8.1f us  %6.1f TFLOP/s  %.1f %%\n", GEMM_ABL, name, WN, WM, TN, TM, BN, BM, tiles, tiles / 256.0, ms * 1e3,
            fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
 }
 
@@ -71,23 +73,23 @@ static int check(uint32_t N, uint32_t M, uint32_t K) {
     a.y[0] = yb;
     {
         auto k1 = k_gemm_glds<4, 1, 1, 5>;
-        const size_t lds = 2 * (128 + 160) * 32 * 4;
+        const size_t lds = GST * (128 + 160) * 32 * 4;
         hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k1, dim3(((N + 127) / 128) * ((M + 159) / 160)), dim3(256), lds, 0, a);
+        hipLaunchKernelGGL(k1, dim3(3), dim3(256), lds, 0, a);
         cmp("glds 128x160");
     }
     {
         auto k1 = k_gemm_glds<2, 2, 2, 2>;
-        const size_t lds = 2 * (128 + 128) * 32 * 4;
+        const size_t lds = GST * (128 + 128) * 32 * 4;
         hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k1, dim3(((N + 127) / 128) * ((M + 127) / 128)), dim3(256), lds, 0, a);
+        hipLaunchKernelGGL(k1, dim3(8), dim3(256), lds, 0, a);
         cmp("glds 128x128");
     }
     {
         auto k1 = k_gemm_glds<2, 2, 2, 1>;
-        const size_t lds = 2 * (128 + 64) * 32 * 4;
+        const size_t lds = GST * (128 + 64) * 32 * 4;
         hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k1, dim3(((N + 127) / 128) * ((M + 63) / 64)), dim3(256), lds, 0, a);
+        hipLaunchKernelGGL(k1, dim3(5), dim3(256), lds, 0, a);
         cmp("glds 128x64");
     }
     hipFree(x); hipFree(w); hipFree(ya); hipFree(yb);
@@ -139,8 +141,12 @@ int main() {
     run<2, 2, 2, 2>("w1w3", N, F, d, 2, x, w, y);
     run<4, 1, 1, 5>("w2", N, d, F, 1, x, w, y);
     run<2, 2, 2, 2>("wo_128", N, d, d, 1, x, w, y);
-#if GEMM_ABL == 0
+#if GEMM_ABL == 0 || GEMM_ABL >= 5
     run_glds<4, 1, 1, 5>("qkv", N, d, d, 3, x, w, y);
+    run_glds<4, 1, 1, 5>("qk(2grp)", N, d, d, 2, x, w, y);
+    run_glds<4, 1, 1, 5>("M=15360", N, 3 * d, d, 1, x, w, y);
+    run_glds<4, 1, 1, 5>("M=10240", N, 2 * d, d, 1, x, w, y);
+    run_glds<2, 2, 2, 2>("qkv_128", N, d, d, 3, x, w, y);
     run_glds<4, 1, 1, 5>("wo", N, d, d, 1, x, w, y);
     run_glds<2, 2, 2, 2>("w1w3", N, F, d, 2, x, w, y);
     run_glds<4, 1, 1, 5>("w1w3_160", N, F, d, 2, x, w, y);
