@@ -159,7 +159,13 @@ func hipGraphCompute(ctx *Context, graph *Graph) {
 		}
 	}
 
-	if rc := C.lh_graph_compute(ctx.hip.ctx, &arr[0], C.uint32_t(nl), C.uint32_t(nn), 0); rc != 0 {
+	// HIPLastRowLogits: set by llama.Eval (which copies out only row N-1 of the lm_head, llama.go:394-401) so that a fused plan
+	// skips the other N-1 logits rows; generic ml.Graph users leave it false and get every node in full.
+	flags := C.uint32_t(0)
+	if ctx.HIPLastRowLogits {
+		flags = C.LH_GRAPH_LAST_ROW_LOGITS
+	}
+	if rc := C.lh_graph_compute(ctx.hip.ctx, &arr[0], C.uint32_t(nl), C.uint32_t(nn), flags); rc != 0 {
 		fmt.Printf("\n[HALT] %s", C.GoString(C.lh_last_error(ctx.hip.ctx))) // same print-and-exit as ml.go:1538-1539
 		os.Exit(1)
 	}
