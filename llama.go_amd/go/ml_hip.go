@@ -8,7 +8,7 @@
 // in the test-suite.
 //
 // What it does:
-//   - Context gains `UseHIP bool` + `hip *hipState`, routed exactly like UseAVX/UseNEON
+//   - Context gains `UseHIP bool`, `HIPLastRowLogits bool` + `hip *hipState`, routed exactly like UseAVX/UseNEON
 //     (Options -> ModelParams llama.go:38-39 -> ml.Context ml.go:52-53).
 //   - RegisterPersistent() copies a weight / KV-cache tensor to HBM once (LoadModel end,
 //     llama.go:975; NewContext, llama.go:91-98).  The Go slice may then be dropped.
