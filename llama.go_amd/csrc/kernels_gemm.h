@@ -25,7 +25,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
     const float* x;     // [N][K] rows at ldx
-    const float* w[3];  // per group [M][K]
+    const float* w[3];  // per group [M][K] (k_gemm_q8: the int8 quant plane, [M][K] bytes)
+    const float* ws[3]; // k_gemm_q8: per group block scales [M][K/32]
     float* y[3];        // per group [N][M] rows at ldy
     const float* r[3];  // per group optional residual, same layout as y
     uint32_t groups, N, M, K, ldx, ldy;
@@ -325,6 +326,160 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
         mfmas(1, 2, 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+  }
+}
+
+// ---- block-int8 weights: dequantising GEMM (prefill of config-4 models) -------------------------------------------------
+// Y_g = X . dequant(W_g)^T with W in the device layout of kernels_q8.h (int8 plane [M][K] + fp32 scales [M][K/32], one scale
+// per 32 weights = per K-slab).  Semantics: w = fl32(d * q), then the exact-f32 MFMA chain — literally "dequantise, then the
+// fp32 MulMat" (DESIGN 3b), no reordering of the scale.  X travels by LDS-DMA exactly as in k_gemm_glds; a W slab row is 32
+// bytes, so each thread loads 16 quants + the row's scale into registers a slab ahead, converts (16 cvt + 16 mul) and stores
+// the 64 bytes into the same swizzled row-major image the MFMA loop reads (4 x ds_write_b128).  Two LDS stages; everything
+// for slab b+2 is issued at the boundary inside slab b (after the barrier that retires the reads of the stage it replaces).
+template <int WN, int WM, int TN, int TM>
+__global__ __launch_bounds__(256) void k_gemm_q8(const GemmArgs a) {
+    static_assert(WN * WM == 4, "4 waves");
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32, ROWS = BN + BM, STAGE = ROWS * 32, XPIECES = BN / 8, XPW = XPIECES / 4, PW = (BM + 127) / 128;
+    static_assert(XPIECES % 4 == 0, "X pieces divide over the 4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][ROWS][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
+    const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
+    const uint32_t nk = a.K / GBK, KB = a.K / 32;
+    const uint32_t G = gridDim.x;
+    const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const uint32_t gran = (uint32_t)((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7));
+    const int wrow = tid >> 1, whalf = tid & 1;  // W staging: thread -> (row within a 128-row pass, 16-weight half of the slab)
+  for (uint32_t wi = v0; wi < total; wi += G) {
+    const uint32_t g = wi / per_group, t = wi % per_group;
+    const uint32_t tm = t / tiles_n, tn = t % tiles_n;
+    const uint32_t n0 = tn * BN, m0 = tm * BM;
+    const float* X = a.x;
+    const signed char* Wq = (const signed char*)a.w[g];
+    const float* Ws = a.ws[g];
+    float* Y = a.y[g];
+    const float* R = a.r[g];
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
+
+    const float* src[XPW];
+#pragma unroll
+    for (int pp = 0; pp < XPW; ++pp) {
+        const uint32_t n = n0 + (uint32_t)(wave + 4 * pp) * 8 + (uint32_t)(lane >> 3);
+        src[pp] = X + (size_t)(n < a.N ? n : a.N - 1) * a.ldx + 4 * gran;
+    }
+    const signed char* wsrc[PW];
+    const float* ssrc[PW];
+#pragma unroll
+    for (int ps = 0; ps < PW; ++ps) {
+        const uint32_t m = m0 + ps * 128 + wrow;
+        const uint32_t mc = m < a.M ? m : a.M - 1;
+        wsrc[ps] = Wq + (size_t)mc * a.K + 16 * whalf;
+        ssrc[ps] = Ws + (size_t)mc * KB;
+    }
+    auto issue_x = [&](int stage, uint32_t kt) {
+#pragma unroll
+        for (int pp = 0; pp < XPW; ++pp)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[pp] + kt * GBK),
+                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (wave + 4 * pp) * 256), 16, 0, 0);
+    };
+    u4 wq[PW];
+    float wd[PW];
+    auto load_w = [&](uint32_t kt) {  // unconditional (clamped rows); rows past BM are never stored
+#pragma unroll
+        for (int ps = 0; ps < PW; ++ps) {
+            wq[ps] = *(const u4*)(wsrc[ps] + (size_t)kt * 32);
+            wd[ps] = ssrc[ps][kt];
+        }
+    };
+    auto store_w = [&](int stage) {
+#pragma unroll
+        for (int ps = 0; ps < PW; ++ps) {
+            const int row = ps * 128 + wrow;
+            if (row < BM) {
+                float* dst = smem + stage * STAGE + (BN + row) * 32;
+                const int key = (row >> 1) & 7;  // BN is a multiple of 16: key(BN + row) = key(row)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int v = (int)wq[ps][i];
+                    f4 f;
+                    f.x = __fmul_rn(wd[ps], (float)(int)(signed char)(v));
+                    f.y = __fmul_rn(wd[ps], (float)(int)(signed char)(v >> 8));
+                    f.z = __fmul_rn(wd[ps], (float)(int)(signed char)(v >> 16));
+                    f.w = __fmul_rn(wd[ps], (float)(v >> 24));
+                    *(f4*)(dst + 4 * ((4 * whalf + i) ^ key)) = f;
+                }
+            }
+        }
+    };
+
+    f16v acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    constexpr int NM = 4 * TN * TM, NR = TN + TM;
+    f4 af[2][TN], bf[2][TM];
+    auto fetch_ops = [&](int set, int stage, int q) {
+        const float* xs = smem + stage * STAGE + (wn * TN * 32 + li) * 32;
+        const float* ws = smem + stage * STAGE + (BN + wm * TM * 32 + li) * 32;
+        const int slot = ((2 * q + lh) ^ sw) * 4;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) af[set][i] = *(const f4*)(xs + i * 32 * 32 + slot);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) bf[set][j] = *(const f4*)(ws + j * 32 * 32 + slot);
+    };
+    auto mfmas = [&](int set, int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; ++e)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][e], bf[set][j][e], acc[i][j], 0, 0, 0);
+    };
+    auto landed = [&]() {  // my DMA pieces and my LDS stores are done; after the barrier so are everybody's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto slab = [&](uint32_t j) { return j < nk ? j : nk - 1; };  // past the end: re-read the last slab (never consumed)
+    issue_x(0, 0);
+    load_w(0);
+    store_w(0);
+    issue_x(1, slab(1));
+    load_w(slab(1));
+    store_w(1);
+    load_w(slab(2));
+    landed();
+    fetch_ops(0, 0, 0);
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            fetch_ops((q + 1) & 1, st, q + 1);
+            mfmas(q & 1, 0, 4);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM / 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NM / 2, 0);
+        }
+        mfmas(1, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            landed();                      // slab kt+1 is complete in stage st^1; every read of stage st has retired
+            fetch_ops(0, st ^ 1, 0);
+            store_w(st);                   // slab kt+2 (registers loaded one boundary ago) -> the stage just drained
+            issue_x(st, slab(kt + 2));
+            load_w(slab(kt + 3));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 2, 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
   }
 }

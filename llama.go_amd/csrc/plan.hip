@@ -193,6 +193,44 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
     return 0;
 }
 
+// block-int8 weights, N >= 32: dequantising MFMA GEMM (k_gemm_q8), 128 x 128 tiles, persistent one workgroup per CU
+static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* wq, const float* const* wsc, float* const* y,
+                         const float* const* r, uint32_t M, uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
+    if (K % GBK || ldx % 4 || ((uintptr_t)x & 15)) LH_FAIL(ctx, LH_ESHAPE, "gemm_q8 %s: K=%u / ldx=%u / X alignment not supported", name, K, ldx);
+    GemmArgs a = {};
+    a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
+    for (uint32_t g = 0; g < groups; ++g) { a.w[g] = wq[g]; a.ws[g] = wsc[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }
+    // tile shape by the same balance model as the fp32 GEMM: rounds of the busiest CU x tile width
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, tn = (n + 127) / 128;
+    auto rounds = [&](uint32_t bm) { return (double)((tn * ((M + bm - 1) / bm) * groups + ncu - 1) / ncu) * bm; };
+    const bool wide = rounds(160) * 1.03 < rounds(128);
+    ProfScope ps(ctx->stream, name, (uint64_t)M * K / 32 * 36 * groups);
+    int rc;
+    if (wide) {
+        auto kern = k_gemm_q8<4, 1, 1, 5>;
+        static bool flags[16] = {};
+        const size_t lds = std::max<size_t>((size_t)2 * (128 + 160) * 32 * sizeof(float), 82 * 1024);
+        if ((rc = set_lds_once(ctx, kern, lds, flags))) return rc;
+        if (g_prepare_only) return 0;
+        const uint32_t tiles = tn * ((M + 159) / 160) * groups;
+        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(tiles, ncu)), dim3(256), lds, ctx->stream, a);
+    } else {
+        auto kern = k_gemm_q8<2, 2, 2, 2>;
+        static bool flags[16] = {};
+        const size_t lds = std::max<size_t>((size_t)2 * (128 + 128) * 32 * sizeof(float), 82 * 1024);
+        if ((rc = set_lds_once(ctx, kern, lds, flags))) return rc;
+        if (g_prepare_only) return 0;
+        const uint32_t tiles = tn * ((M + 127) / 128) * groups;
+        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(tiles, ncu)), dim3(256), lds, ctx->stream, a);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+static int gemm_q8(lh_ctx* ctx, const float* wq, const float* wsc, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n, uint32_t ldx,
+                   uint32_t ldy, const char* name) {
+    return gemm_q8_group(ctx, x, ldx, 1, &wq, &wsc, &y, resid ? &resid : nullptr, M, K, n, ldy, name);
+}
+
 // Large-N prefill attention as batched MFMA GEMMs over heads, mirroring the reference's own structure (llama.go:300-333):
 //   S_h = Q_h K_h^T (full block, like MulMat(K, Q))  ->  scale + causal mask + softmax  ->  V^T copy  ->  O_h = P_h V_h.
 static int attention_gemm(Plan* p, const float* q, const float* kc, const float* vc, float* out, uint32_t n, uint32_t past, float scale) {
@@ -573,9 +611,9 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    if (m.wtype == 7) {
-        // block-int8 prefill: the dequantising GEMM is not built yet; evaluate the n tokens as n causal single-token steps
-        // (bit-identical to what the decode path produces for them), logits row i from step i like llama.go:384.
+    if (m.wtype == 7 && (n < 32 || m.d % GBK || m.F % GBK || m.hd % 32)) {
+        // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
+        // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
         if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EUNSUPPORTED, "block-int8 prefill on a pipeline stage is not supported yet");
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
@@ -606,7 +644,13 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
         { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
         const bool mfma = n >= 32 && d % GBK == 0 && F % GBK == 0;
-        if (mfma) {
+        const bool q8 = m.wtype == 7;
+        if (q8) {
+            const float* ws[3] = {L.wq, L.wk, L.wv};
+            const float* sc[3] = {L.s_wq, L.s_wk, L.s_wv};
+            float* ys[3] = {p->qraw, p->kraw, p->vraw};
+            if ((rc = gemm_q8_group(ctx, p->h, d, 3, ws, sc, ys, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
+        } else if (mfma) {
             const float* ws[3] = {L.wq, L.wk, L.wv};
             float* ys[3] = {p->qraw, p->kraw, p->vraw};
             if ((rc = gemm_mfma_group(ctx, p->h, d, 3, ws, ys, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
@@ -624,9 +668,15 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
             if ((rc = launch_attention(ctx, a, past + n))) return rc;
         }
-        if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
+        if (q8) { if ((rc = gemm_q8(ctx, L.wo, L.s_wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_q8_wo"))) return rc; }
+        else if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
         { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
-        if (mfma) {
+        if (q8) {
+            const float* ws[2] = {L.w1, L.w3};
+            const float* sc[2] = {L.s_w1, L.s_w3};
+            float* ys[2] = {p->a1, p->a3};
+            if ((rc = gemm_q8_group(ctx, p->h, d, 2, ws, sc, ys, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
+        } else if (mfma) {
             const float* ws[2] = {L.w1, L.w3};
             float* ys[2] = {p->a1, p->a3};
             if ((rc = gemm_mfma_group(ctx, p->h, d, 2, ws, ys, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
@@ -638,7 +688,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                            (const float*)p->a3, p->g, (uint64_t)n * F); }
         const bool last = il + 1 == m.layer1;
         float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
-        if ((rc = gemm_small_n(ctx, L.w2, p->g, y, p->xb, d, F, n, F, d, "gemm_w2"))) return rc;
+        if (q8) { if ((rc = gemm_q8(ctx, L.w2, L.s_w2, p->g, y, p->xb, d, F, n, F, d, "gemm_q8_w2"))) return rc; }
+        else if ((rc = gemm_small_n(ctx, L.w2, p->g, y, p->xb, d, F, n, F, d, "gemm_w2"))) return rc;
         x = p->xa;
         LH_HIP(ctx, hipGetLastError());
     }
@@ -647,7 +698,17 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         // callers that say so (LH_GRAPH_LAST_ROW_LOGITS, the lh_llama_* entry points) get that row only, in its usual place
         const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
         { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(nr), dim3(256), 0, ctx->stream, x + (size_t)r0 * d, m.norm, p->h + (size_t)r0 * d, d); }
-        if ((rc = gemm_small_n(ctx, m.output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_lmhead"))) return rc;
+        if (m.wtype == 7) {
+            if (nr >= 32) {
+                if ((rc = gemm_q8(ctx, m.output, m.s_output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_q8_lmhead"))) return rc;
+            } else {
+                for (uint32_t i = 0; i < nr; ++i) {  // a few rows: the int8 weight stream of the decode path, input already normalised
+                    GemvArgs ga = {};
+                    ga.w[0] = m.output; ga.ws[0] = m.s_output; ga.M = m.V; ga.K = d; ga.x = p->h + (size_t)(r0 + i) * d; ga.y = p->logits + (size_t)(r0 + i) * m.V;
+                    if ((rc = gemv<PRO_PLAIN, EPI_STORE, MAP_SINGLE>(ctx, ga, "gemv_lmhead_row", 7))) return rc;
+                }
+            }
+        } else if ((rc = gemm_small_n(ctx, m.output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_lmhead"))) return rc;
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;

@@ -252,6 +252,36 @@ def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, lay
     assert th == to
 
 
+@pytest.mark.parametrize("shape,n_prompt", [("small", 33), ("small", 100), ("small", 300), ("13B", 72)])
+def test_block_int8_prefill_gemm_matches_dequantised_oracle(product, oracle, shape, n_prompt):
+    """Prompts of >= 32 tokens on a block-int8 model run the dequantising MFMA GEMM (k_gemm_q8: int8 + scale -> fl32(d*q) -> LDS ->
+    exact-f32 MFMA); shorter ones and every decode step run the int8 GEMV stream.  Both must agree with the checker's
+    dequantise-then-fp32 evaluation, and with each other on the cache they share."""
+    kw = dict(SHAPES[shape])
+    kw["layers"] = 2 if shape == "small" else 1     # 13B shape: 5120 = 32 x 160 columns -> the 128 x 160 tile variant
+    hp = make_hparams(**kw, ctx=320)
+    rng = np.random.default_rng(n_prompt)
+    prompt = [int(t) for t in rng.integers(0, kw["vocab"], n_prompt)]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 321).QuantizeQ8()
+        c = m.NewContext(320, 16, False)
+        res[name] = c.GreedyDecode(prompt, 5)
+        if name == "hip":  # the same prompt fed in chunks < 32 goes through the GEMV path only
+            c2 = m.NewContext(320, 16, False)
+            past = 0
+            for i in range(0, n_prompt, 16):
+                lg_chunked = c2.Eval(prompt[i:i + 16], past)
+                past += len(prompt[i:i + 16])
+            c2.free()
+        c.free()
+        m.free()
+    (th, lh_), (to, lo) = res["hip"], res["orc"]
+    assert rel(lh_, lo) <= TOL
+    assert th == to
+    assert rel(lg_chunked, lh_[0]) <= TOL
+
+
 @pytest.mark.parametrize("shape", ["13B", "65B"])
 def test_larger_shapes_slice_matches_oracle(product, oracle, shape):
     """13B (d 5120, ff 13824) and 65B (d 8192, ff 22016) layer shapes, 1 layer: exercises the KI = 2/4/6 column splits of the

@@ -16,6 +16,7 @@ ap.add_argument("--shape", default="13B")
 ap.add_argument("--n", type=int, default=1024)
 ap.add_argument("--layers", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--int8", action="store_true", help="block-int8 weight matrices (config 4): the dequantising GEMM")
 args = ap.parse_args()
 prod = load_product()
 kw = dict(SHAPES[args.shape])
@@ -23,6 +24,8 @@ if args.layers:
     kw["layers"] = args.layers
 hp = make_hparams(**kw, ctx=args.n)
 m = prod.NewSyntheticModel(hp, 1234)
+if args.int8:
+    m.QuantizeQ8()
 c = m.NewContext(args.n, 1)
 d, L, V, F, N = hp.embdSize, hp.layersCount, hp.vocabSize, m.ffSize, args.n
 rng = np.random.default_rng(0)
@@ -40,7 +43,7 @@ flops_layers = 2.0 * N * L * (4 * d * d + 3 * d * F)
 flops_w = flops_layers + 2.0 * V * d
 flops_ref = flops_layers + 2.0 * N * V * d            # what the reference's graph multiplies
 flops_a = L * 4.0 * N * N * d                          # full (unmasked) score block, as the reference computes it
-print(json.dumps({"shape": args.shape, "layers": L, "N": N, "seconds": round(dt, 4), "tflop_weights_executed": round(flops_w / 1e12, 2),
+print(json.dumps({"shape": args.shape + (" block-int8" if args.int8 else ""), "layers": L, "N": N, "seconds": round(dt, 4), "tflop_weights_executed": round(flops_w / 1e12, 2),
                   "tflop_weights_reference_graph": round(flops_ref / 1e12, 2), "tflop_attention_full": round(flops_a / 1e12, 2),
                   "TFLOPs_per_s_weights_executed": round(flops_w / dt / 1e12, 1),
                   "frac_of_157.3TF_fp32_mfma_peak": round(flops_w / dt / 157.3e12, 3),
