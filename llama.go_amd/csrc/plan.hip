@@ -126,11 +126,10 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     const uint32_t K4 = a.K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
-    // few rows per workgroup (wo: 4096 rows / 256 CUs = 16): two rows in flight beat four (tools/kernel_ablate: 11.98 vs 12.85 us),
-    // the four-slot prologue/epilogue is a larger share of a 16-row stream
-    if (ki == 1 && a.M / (uint32_t)ctx->ds->num_cu < 32) return launch_gemv<1, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+    // rows in flight per wave (U): same-box A/B on the 7B decode loop, tok/s: U = 4 for every K <= 4096 kernel 219.0; U = 2 for wo
+    // only (16 rows per workgroup) 222.2; U = 2 for all of them 222.8
     switch (ki) {
-        case 1: return launch_gemv<1, 4, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 1: return launch_gemv<1, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 2: return launch_gemv<2, 4, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 3: return launch_gemv<3, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 4: return launch_gemv<4, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
