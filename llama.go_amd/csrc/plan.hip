@@ -127,11 +127,12 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     const int ki = (int)((K4 + TH - 1) / TH);
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
     // rows in flight per wave (U): same-box A/B on the 7B decode loop, tok/s: U = 4 for every K <= 4096 kernel 219.0; U = 2 for wo
-    // only (16 rows per workgroup) 222.2; U = 2 for all of them 222.8
+    // only (16 rows per workgroup) 222.2; U = 2 for all of them 222.8-223.6; (U for K = 4096, U for K = 11008) = (1,2) 200.0,
+    // (3,2) 220.8, (2,3) 222.4, (2,1) 224.1: about 32-48 bytes per lane in flight is the sweet spot
     switch (ki) {
         case 1: return launch_gemv<1, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 2: return launch_gemv<2, 4, PRO, EPI, MAP>(ctx, a, name, bytes);
-        case 3: return launch_gemv<3, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 3: return launch_gemv<3, 1, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 4: return launch_gemv<4, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 5: return launch_gemv<5, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 6: return launch_gemv<6, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
