@@ -12,6 +12,8 @@
 namespace lh {
 
 static thread_local bool g_prepare_only = false;  // set kernel attributes without launching (before graph capture)
+static thread_local const char* g_only = nullptr;   // lh_llama_profile_decode: launch only the kernels of this name (timing pass)
+static inline bool skip_launch(const char* name) { return g_prepare_only || (g_only && strcmp(g_only, name) != 0); }
 
 static constexpr int TH = 1024;
 static constexpr size_t FAT_LDS = 96 * 1024;  // > 80 KiB: one fat workgroup per CU
@@ -59,6 +61,13 @@ struct ProfScope {
     }
 };
 
+// Parks the stream for `ticks` of the 100 MHz realtime counter: lh_llama_profile_decode queues its whole event/kernel sequence
+// behind it, so host launch latency (event creation, API calls) does not leak into the per-kernel event intervals.
+__global__ void k_park(uint64_t ticks) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 template <typename KernT>
 static int set_lds_once(lh_ctx* ctx, KernT kern, size_t lds, bool* flags) {
     if (!flags[ctx->device & 15]) {
@@ -74,7 +83,7 @@ static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_
     static bool flags[16] = {};
     int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
     if (rc) return rc;
-    if (g_prepare_only) return 0;
+    if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
     hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
@@ -87,7 +96,7 @@ static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint
     static bool flags[16] = {};
     int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
     if (rc) return rc;
-    if (g_prepare_only) return 0;
+    if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
     hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
@@ -340,6 +349,7 @@ static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
     }
     if (lds > 160 * 1024) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: %u keys exceed the single-pass LDS budget", max_T);
     if (g_prepare_only) return 0;
+    if (g_only) return 0;
     ProfScope ps(ctx->stream, "attention", (uint64_t)2 * max_T * a.d * 4);
     hipLaunchKernelGGL(k_attention, dim3(a.d / a.hd, a.n), dim3(ATT_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
@@ -352,7 +362,7 @@ static int launch_attention_split(Plan* p, const AttnArgs& a) {
     const ModelDesc& m = p->md;
     if (a.hd != 128) LH_FAIL(ctx, LH_EUNSUPPORTED, "split attention: head dim %u", a.hd);
     const uint32_t nch = (m.ctx + ATT_TC - 1) / ATT_TC;
-    if (g_prepare_only) return 0;
+    if (g_prepare_only || g_only) return 0;
     {
         ProfScope ps(ctx->stream, "attention_split", (uint64_t)2 * m.ctx * a.d * 4);
         hipLaunchKernelGGL(k_attention_split, dim3(m.H, nch), dim3(ATT_TH), 0, ctx->stream, a, p->attn_part);
@@ -471,7 +481,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     int rc;
     const float* x = p->xa;
     if (m.first_stage()) {
-        if (!g_prepare_only) {
+        if (!g_prepare_only && !g_only) {
             ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
             TraceScope ts_(ctx->stream, "embed1");
             hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d);
@@ -522,7 +532,8 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         GemvArgs a = {};
         a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
         if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
-        if (argmax_advance == 2 && !g_prepare_only) {
+        if (g_only) {
+        } else if (argmax_advance == 2 && !g_prepare_only) {
             ProfScope ps(ctx->stream, "sample", (uint64_t)m.V * 4);
             TraceScope ts_(ctx->stream, "sample");
             if ((rc = sample_launch(ctx, p->logits, m.V, p->ss_dev, p->ring_dev, (StepParams*)sp, p->out_tokens_dev, argmax_out, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
@@ -950,6 +961,7 @@ int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t
     if ((rc = enqueue_decode(p, p->sp_dev, pin, pout, false, nullptr))) return rc;
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     g_prof = &sink;
+    hipLaunchKernelGGL(k_park, dim3(1), dim3(1), 0, ctx->stream, (uint64_t)(repeats * 1500000ull));  // 15 ms per repeat of host queueing time
     for (uint32_t r = 0; r < repeats && !rc; ++r) rc = enqueue_decode(p, p->sp_dev, pin, pout, false, p->md.last_stage() ? p->argmax_dev : nullptr);
     g_prof = nullptr;
     hipStreamSynchronize(ctx->stream);
@@ -971,6 +983,37 @@ int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t
         acc[i].total_ms += ms;
     }
     if (rc) return rc;
+    // Second pass for the dominant weight-stream kernel: all of its launches of a step (one per layer, all weights distinct)
+    // back to back between ONE event pair, queued behind the park kernel.  The per-kernel pairs above carry ~3 us of event
+    // processing each; this is the figure that agrees with a rocprofv3 kernel trace (entry "<name>/b2b").
+    size_t dom = acc.size();
+    for (size_t i = 0; i < acc.size(); ++i)
+        if (!strncmp(acc[i].name, "gemv_", 5) && (dom == acc.size() || acc[i].total_ms > acc[dom].total_ms)) dom = i;
+    if (dom < acc.size() && acc[dom].launches >= repeats) {
+        static thread_local char only_name[48];
+        snprintf(only_name, sizeof only_name, "%s", acc[dom].name);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        g_only = only_name;
+        hipLaunchKernelGGL(k_park, dim3(1), dim3(1), 0, ctx->stream, (uint64_t)(repeats * 300000ull));
+        hipEventRecord(e0, ctx->stream);
+        for (uint32_t r = 0; r < repeats && !rc; ++r) rc = enqueue_decode(p, p->sp_dev, pin, pout, false, nullptr);
+        hipEventRecord(e1, ctx->stream);
+        g_only = nullptr;
+        hipStreamSynchronize(ctx->stream);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        if (rc) return rc;
+        lh_kernel_time t = {};
+        snprintf(t.name, sizeof t.name, "%s/b2b", acc[dom].name);
+        t.bytes_per_launch = acc[dom].bytes_per_launch;
+        t.launches = acc[dom].launches;
+        t.total_ms = ms;
+        acc.push_back(t);
+    }
     uint32_t n = (uint32_t)std::min<size_t>(acc.size(), cap);
     for (uint32_t i = 0; i < n; ++i) out[i] = acc[i];
     return (int)n;
