@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the bounded CPU-baseline sample")
-    ap.add_argument("--pods", type=int, default=0, help="streams in flight for N > 1 (default N)")
+    ap.add_argument("--pods", type=int, default=0, help="independent greedy streams in flight for N > 1 (default 4 N; must be >= N)")
     ap.add_argument("--no-prefill", action="store_true", help="skip the config-3 side measurement (13B, one 1024-token Eval)")
     ap.add_argument("--int8", action="store_true", help="BASELINE config 4: block-int8 weight matrices (36 B per 32 weights); not the headline metric")
     args = ap.parse_args()
@@ -290,7 +290,10 @@ def main():
     else:
         # ---------------- layer-sharded pipeline over `world` ranks ----------------
         R = world
-        pods = args.pods or R
+        # streams in flight: a phase of K steps costs K * pods / R + (R - 1) ticks, so with pods = R and K = 16 pipeline fill + drain
+        # alone cap the efficiency at K / (K + R - 1) (70 % for R = 8); 4 R streams amortise it to 4K / (4K + R - 1) (90 %).
+        # The reference's own knob for this is --pods (server.go:88-101).
+        pods = args.pods or 4 * R
         l0, l1 = rank * L // R, (rank + 1) * L // R
         # ONE explicit stream for everything: torch's copies and (R)CCL work order themselves against torch's CURRENT stream, so the
         # library must enqueue on that very stream (the default stream's handle is NULL, which the C-ABI reads as "make a private
@@ -333,7 +336,7 @@ def main():
             if rc:
                 raise RuntimeError(prod.last_error())
             if last_stage and phase == "timed":
-                produced_dev[p, step] = tok_out[p][0]
+                produced_dev[p, step: step + 1].copy_(tok_out[p], non_blocking=True)
 
         def send_buf(p, step, phase):
             n, _ = rows_past(step, phase)

@@ -38,6 +38,6 @@ def test_two_rank_pipeline_reproduces_single_process_tokens(product):
                         cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     two = last_json(r2.stdout)
-    assert two["n_gpus"] == 2 and two["config"]["streams"] == 2
+    assert two["n_gpus"] == 2 and two["config"]["streams"] == 8   # default: 4 streams per rank in flight
     assert two["tokens_stream0"] == one["tokens_stream0"], (one["tokens_stream0"], two["tokens_stream0"])
     assert len(one["tokens_stream0"]) == 6
