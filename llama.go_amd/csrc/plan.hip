@@ -137,10 +137,11 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
     // rows in flight per wave (U): same-box A/B on the 7B decode loop, tok/s: U = 4 for every K <= 4096 kernel 219.0; U = 2 for wo
     // only (16 rows per workgroup) 222.2; U = 2 for all of them 222.8-223.6; (U for K = 4096, U for K = 11008) = (1,2) 200.0,
-    // (3,2) 220.8, (2,3) 222.4, (2,1) 224.1: about 32-48 bytes per lane in flight is the sweet spot
+    // (3,2) 220.8, (2,3) 222.4, (2,1) 224.1: about 32-48 bytes per lane in flight is the sweet spot.  13B decode (K = 5120, two
+    // float4 per thread): U = 4 118.8, U = 2 121.4, U = 1 120.6 tok/s; 65B shard (K = 8192 / 22016): U = 2 vs 1 within noise
     switch (ki) {
         case 1: return launch_gemv<1, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
-        case 2: return launch_gemv<2, 4, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 2: return launch_gemv<2, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 3: return launch_gemv<3, 1, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 4: return launch_gemv<4, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 5: return launch_gemv<5, 2, PRO, EPI, MAP>(ctx, a, name, bytes);

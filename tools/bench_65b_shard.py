@@ -9,10 +9,10 @@ import numpy as np
 import torch
 from llama_go_amd.mlapi import SHAPES, load_product, make_hparams
 
-ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=32); ap.add_argument("--ranks", type=int, default=8)
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=32); ap.add_argument("--ranks", type=int, default=8); ap.add_argument("--shape", default="65B")
 args = ap.parse_args()
 prod = load_product()
-hp = make_hparams(**SHAPES["65B"], ctx=128)
+hp = make_hparams(**SHAPES[args.shape], ctx=128)
 L, d, V, R = hp.layersCount, hp.embdSize, hp.vocabSize, args.ranks
 res = {}
 tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream)
