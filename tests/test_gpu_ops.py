@@ -81,7 +81,10 @@ def assert_close(out, tol):
 
 
 @pytest.mark.parametrize("K,M,N", [(4096, 512, 1), (11008, 256, 1), (4096, 300, 3), (128, 7, 5), (24, 128, 1), (100, 33, 2), (4, 2, 1),
-                                   (4096, 512, 64), (1024, 384, 130), (11008, 256, 33)])
+                                   (4096, 512, 64), (1024, 384, 130), (11008, 256, 33),
+                                   # N >= 32: MFMA GEMMs.  K >= 512 -> persistent LDS-DMA kernel (ragged M and N, K = 512 edge,
+                                   # more tiles than CUs); smaller K -> the register-staged kernel
+                                   (2048, 300, 200), (5120, 700, 257), (512, 256, 32), (480, 256, 40), (1024, 4200, 1100)])
 def test_mul_mat_weights(pair, K, M, N):
     r = rng(K + M + N)
     w = r.standard_normal((M, K)).astype(np.float32) / np.sqrt(K)
