@@ -10,6 +10,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -68,14 +70,25 @@ struct ml_tensor {  // ml.Tensor ml.go:180-203
     uint64_t last_gen = 0;
     uint32_t last_index = 0;
     ml_tensor* gc_next = nullptr;
+    // scratch marks of graph construction / flattening (valid when the generation matches): no hash containers on the Eval path
+    uint64_t visit_gen = 0, flat_gen = 0;
+    int flat_idx = 0;
 };
 
 struct ml_graph {  // ml.Graph ml.go:31-45
     std::vector<ml_tensor*> nodes, leafs;
-    std::unordered_set<const ml_tensor*> seen;  // same visit order as the reference's linear scans (ml.go:657-668), without the O(n^2)
+    // "already visited": per-Eval tensors (owned by the building thread) carry a generation mark; persistent tensors (weights, KV
+    // caches) are shared read-only by every pod's goroutine (server.go:45) and must not be written, so they go through a set.
+    // Same visit order as the reference's linear scans (ml.go:657-668) without the O(n^2).
+    uint64_t gen = 0;
+    std::unordered_set<const ml_tensor*> seen_shared;
 };
+static uint64_t g_mark_counter = 0;  // graphs are built and flattened under the caller's serialisation (one ml.Context per goroutine)
+static std::mutex g_mark_mu;
+static uint64_t next_mark() { std::lock_guard<std::mutex> lk(g_mark_mu); return ++g_mark_counter; }
 
 static thread_local ml_tensor* g_gc_head = nullptr;
+static thread_local std::vector<ml_tensor*> g_pool;  // recycled tensor records: an Eval creates ~1600 and frees them all
 static thread_local bool g_gc_enabled = true;
 
 static uint64_t nelements(const ml_tensor* t) { return (uint64_t)t->ne[0] * t->ne[1] * t->ne[2] * t->ne[3]; }
@@ -84,7 +97,8 @@ static bool same_shape(const ml_tensor* a, const ml_tensor* b) { return a->ne[0]
 // NewTensor ml.go:760-783 — strides always re-derived contiguous; data == alias of `alias_of` when given
 static ml_tensor* new_tensor(int dt, uint32_t dims, uint32_t ne0, uint32_t ne1, uint32_t ne2, uint32_t ne3, ml_tensor* alias_of, uint64_t extra_off,
                              bool alloc_host = true) {
-    ml_tensor* t = new ml_tensor();
+    ml_tensor* t;
+    if (!g_pool.empty()) { t = g_pool.back(); g_pool.pop_back(); *t = ml_tensor(); } else t = new ml_tensor();
     t->type = dt;
     t->dims = dims;
     t->ne[0] = ne0; t->ne[1] = ne1; t->ne[2] = ne2; t->ne[3] = ne3;
@@ -120,7 +134,7 @@ static void free_tensor(ml_tensor* t) {
     if (!t) return;
     if (t->owns) free(t->data);
     if (t->buf && t->persistent && g_model_ctx) lh_buf_free(g_model_ctx, t->buf);
-    delete t;
+    if (g_pool.size() < 8192) g_pool.push_back(t); else delete t;
 }
 
 extern "C" {
@@ -217,7 +231,7 @@ ml_tensor* ml_SoftMax(ml_context*, ml_tensor* a) { return node2(view_tensor(a), 
 ml_tensor* ml_Silu(ml_context*, ml_tensor* a) { return node2(dup_tensor(a), ML_OP_SILU, a, nullptr); }         // ml.go:1018-1043
 
 // ---- graph  ml.go:619-697 ------------------------------------------------------------------------------
-ml_graph* ml_NewGraph(void) { return new ml_graph(); }
+ml_graph* ml_NewGraph(void) { ml_graph* g = new ml_graph(); g->gen = next_mark(); g->nodes.reserve(2048); g->leafs.reserve(1024); return g; }
 void ml_FreeGraph(ml_graph* g) {
     ml_tensor* t = g_gc_head;
     while (t) { ml_tensor* n = t->gc_next; free_tensor(t); t = n; }
@@ -225,7 +239,12 @@ void ml_FreeGraph(ml_graph* g) {
     delete g;
 }
 static int visit_parents(ml_graph* g, ml_tensor* node) {  // ml.go:647-697
-    if (!g->seen.insert(node).second) return 0;
+    if (node->persistent) {
+        if (!g->seen_shared.insert(node).second) return 0;
+    } else {
+        if (node->visit_gen == g->gen) return 0;
+        node->visit_gen = g->gen;
+    }
     if (node->src0 && visit_parents(g, node->src0)) return 1;
     if (node->src1 && visit_parents(g, node->src1)) return 1;
     if (node->op == ML_OP_NONE) {
@@ -250,20 +269,23 @@ ml_tensor* ml_GraphNode(const ml_graph* g, uint32_t i) { return i < g->nodes.siz
 static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
     g_err.clear();
     if (!ctx || !ctx->hip) return halt_rc("ml_GraphCompute: no HIP context");
-    // every storage owner must be part of the array the C side sees
+    // every storage owner must be part of the array the C side sees; indices live in the tensors (flat_gen / flat_idx)
     std::vector<ml_tensor*> leafs = g->leafs;
-    std::unordered_map<const ml_tensor*, int> index;
-    auto collect = [&](const std::vector<ml_tensor*>& v, int base) { for (size_t i = 0; i < v.size(); ++i) index[v[i]] = base + (int)i; };
-    collect(leafs, 0);
-    for (ml_tensor* t : g->nodes) index[t] = -2;
+    const uint64_t fg = next_mark();
+    std::unordered_map<const ml_tensor*, int> shared_idx;  // persistent (shared, read-only) tensors: see ml_graph
+    auto set_idx = [&](ml_tensor* t, int i) { if (t->persistent) shared_idx[t] = i; else { t->flat_gen = fg; t->flat_idx = i; } };
+    auto has_idx = [&](const ml_tensor* t) { return t->persistent ? shared_idx.count(t) != 0 : t->flat_gen == fg; };
+    auto index_of = [&](const ml_tensor* t) { return t->persistent ? shared_idx.find(t)->second : t->flat_idx; };
+    for (size_t i = 0; i < leafs.size(); ++i) set_idx(leafs[i], (int)i);
+    for (ml_tensor* t : g->nodes) set_idx(t, -2);
     auto add_owner = [&](ml_tensor* t) {
-        if (!index.count(t->base)) { index[t->base] = (int)leafs.size(); leafs.push_back(t->base); }
+        ml_tensor* b = t->base;
+        if (!has_idx(b)) { set_idx(b, (int)leafs.size()); leafs.push_back(b); }
     };
     for (ml_tensor* t : g->leafs) add_owner(t);
     for (ml_tensor* t : g->nodes) add_owner(t);
     const uint32_t nl = (uint32_t)leafs.size(), nn = (uint32_t)g->nodes.size();
-    collect(leafs, 0);
-    collect(g->nodes, (int)nl);
+    for (uint32_t i = 0; i < nn; ++i) set_idx(g->nodes[i], (int)(nl + i));
     std::vector<lh_tensor> T(nl + nn);
     ctx->generation++;
     for (uint32_t i = 0; i < nl + nn; ++i) {
@@ -273,17 +295,19 @@ static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
         o.op = (uint8_t)t->op;
         o.dtype = (uint8_t)(t->type == ML_TYPE_I32 ? ML_TYPE_F32 : t->type);  // "I32" parameter tensors hold fp32 (ml.go:864-867)
         for (int k = 0; k < 4; ++k) { o.ne[k] = t->ne[k]; o.nb[k] = t->nb[k]; }
-        o.src0 = t->src0 ? index[t->src0] : -1;
-        o.src1 = t->src1 ? index[t->src1] : -1;
-        o.storage = index[t->base];
+        o.src0 = t->src0 ? index_of(t->src0) : -1;
+        o.src1 = t->src1 ? index_of(t->src1) : -1;
+        o.storage = index_of(t->base);
         o.view_off = t->base_off;
         if (t->base == t) {
             o.buf = t->persistent ? t->buf : 0;
             o.host = (t->op == ML_OP_NONE && !t->persistent) ? t->data : nullptr;
         }
-        t->last_ctx = ctx;
-        t->last_gen = ctx->generation;
-        t->last_index = i;
+        if (!t->persistent) {  // shared tensors stay read-only (they are read back through their buffer, ml_TensorRead)
+            t->last_ctx = ctx;
+            t->last_gen = ctx->generation;
+            t->last_index = i;
+        }
     }
     if (lh_graph_compute(ctx->hip, T.data(), nl, nn, flags)) return halt_rc(lh_last_error(ctx->hip));
     return 0;
@@ -595,6 +619,9 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
     const uint32_t headsCount = model->hp.headsCount, vocabSize = model->hp.vocabSize, rotCount = embdSize / headsCount;
     if (N == 0 || (uint64_t)pastCount + N > ctxSize) return halt_rc("llama_Eval: token window outside the context (the reference would index past the KV slice, llama.go:274)");
     ml_context* ctx0 = lctx->mlctx;
+    static const bool timing = getenv("LLAMAGO_TIMING") != nullptr;  // stderr: host-side phases of one Eval in microseconds
+    const auto tp0 = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point a) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count(); };
     ml_graph* graph = ml_NewGraph();
     int rc = 1;
     const bool save = g_gc_enabled;
@@ -656,12 +683,17 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
         inpL = ml_Mul(ctx0, ml_Repeat(ctx0, model->norm, inpL), inpL);            // :377-379
         inpL = ml_MulMat(ctx0, model->output, inpL);                              // :384
         if (ml_BuildForwardExpand(graph, inpL)) break;                            // :387
+        const long t_build = us_since(tp0);
+        const auto tp1 = std::chrono::steady_clock::now();
         {   // :389 — this caller reads only row N-1 of the result (:394-401) and says so
             const char* e = getenv("LLAMAGO_NO_FUSION");
             if (graph_compute(ctx0, graph, (e && e[0] == '1') ? LH_GRAPH_NO_FUSION : LH_GRAPH_LAST_ROW_LOGITS)) break;
         }
         // :394-401 — only the last token's logits are copied out
+        const long t_compute = us_since(tp1);
+        const auto tp2 = std::chrono::steady_clock::now();
         if (lh_node_read(ctx0->hip, inpL->last_index, (uint64_t)vocabSize * (N - 1), lctx->logits.data(), vocabSize)) { g_err = lh_last_error(ctx0->hip); break; }
+        if (timing) fprintf(stderr, "[llamago] Eval N=%u: graph build %ld us, GraphCompute %ld us, logits read %ld us\n", N, t_build, t_compute, us_since(tp2));
         rc = 0;
     } while (0);
     ml_FreeGraph(graph);
