@@ -629,12 +629,13 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     if (m.wtype == 7 && (n < 32 || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
-        if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EUNSUPPORTED, "block-int8 prefill on a pipeline stage is not supported yet");
+        // On a pipeline stage row i of the received / forwarded residual stream stands in for the token id / the logits row.
         for (uint32_t i = 0; i < n; ++i) {
             const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
-            if ((rc = upload_step_params(p, slot, tokens_host[i], past + i, 0))) return rc;
-            if ((rc = enqueue_decode(p, p->sp_dev + slot, nullptr, nullptr, false, nullptr, nullptr, i))) return rc;
-            if ((i + 1) % (SP_SLOTS - 2) == 0) LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pinned parameter slots are recycled
+            if ((rc = upload_step_params(p, slot, m.first_stage() ? tokens_host[i] : 0, past + i, 0))) return rc;
+            if ((rc = enqueue_decode(p, p->sp_dev + slot, m.first_stage() ? nullptr : x_in_dev + (size_t)i * m.d, m.last_stage() ? nullptr : x_out_dev + (size_t)i * m.d, false,
+                                     nullptr, nullptr, i)))
+                return rc;
         }
         return 0;
     }
