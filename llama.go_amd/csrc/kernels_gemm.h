@@ -213,7 +213,12 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
   for (uint32_t wi = v0; wi < work; wi += G) {
     const uint32_t be = wi / total, bid = wi % total;
     const uint32_t g = bid / per_group, t = bid % per_group;
-    const uint32_t tm = t / tiles_n, tn = t % tiles_n;
+    const uint32_t tm = t / tiles_n;
+    uint32_t tn = t % tiles_n;
+    // causal P.V: a tile's contraction length grows with its row block, and with G % tiles_n == 0 the static assignment would hand
+    // a workgroup the SAME row block every round (the unluckiest one the longest tile each time: 47 % balance at 8 row blocks).
+    // Odd rounds take the row blocks in reverse, so consecutive rounds of a workgroup sum to the same length.
+    if (a.causal == 2 && G % tiles_n == 0 && ((wi / G) & 1)) tn = tiles_n - 1 - tn;
     const uint32_t n0 = tn * BN, m0 = tm * BM;
     if (a.causal == 1 && m0 > a.past + n0 + BN - 1) continue;
     const uint32_t nk = a.causal == 2 ? min(nk_full, (a.past + n0 + BN + GBK - 1) / GBK) : nk_full;
