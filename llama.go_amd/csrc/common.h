@@ -82,6 +82,9 @@ struct lh_ctx {
     int last_fused = 0;
     // fused plans cached by structural signature
     std::vector<lh::Plan*> plans;
+    // split-K partial products of the prefill GEMM (short prompts); grows, never shrinks
+    float* splitk = nullptr;
+    uint64_t splitk_floats = 0;
 };
 
 namespace lh {

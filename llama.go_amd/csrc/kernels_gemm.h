@@ -40,6 +40,11 @@ struct GemmArgs {
     //   causal = 2 (O = P.V, contraction over keys): P[n][t] = 0 for t > past + n, so the K loop stops after the last key any
     //              row of the tile can see.
     uint32_t causal, past;
+    // Split-K (k_gemm_glds, few tiles: short prompts).  splits > 1: work item = (tile, K range ks); the partial product goes to
+    // part[group][ks][N][M] (row pitch M, no residual) and k_splitk_reduce adds the partials in ks order (+ residual) into Y:
+    // two passes, fixed order, bit-reproducible — no atomics.
+    uint32_t splits;
+    float* part;
 };
 
 constexpr int GBK = 32;
@@ -49,7 +54,8 @@ constexpr int GST = 3;  // LDS stages of k_gemm_glds
 // The residual is fetched for a whole 32 x 32 block before any of it is used, through clamped (always valid) addresses: a load
 // inside `if (n < N && m < M)` waits out a memory latency per element (80 dependent round trips per lane, ~40 us per tile).
 template <int TN, int TM>
-__device__ __forceinline__ void gemm_store(const GemmArgs& a, f16v (&acc)[TN][TM], float* Y, const float* R, uint32_t nb, uint32_t mb, int li, int lh) {
+__device__ __forceinline__ void gemm_store(const GemmArgs& a, f16v (&acc)[TN][TM], float* Y, const float* R, uint32_t nb, uint32_t mb, int li, int lh,
+                                           uint32_t ldy) {
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -61,13 +67,13 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& a, f16v (&acc)[TN][TM
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const uint32_t n = nb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    rv[e] = R[(size_t)(n < a.N ? n : a.N - 1) * a.ldy + mc];
+                    rv[e] = R[(size_t)(n < a.N ? n : a.N - 1) * ldy + mc];
                 }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const uint32_t n = nb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (n < a.N && m < a.M) Y[(size_t)n * a.ldy + m] = R ? __fadd_rn(acc[i][j][e], rv[e]) : acc[i][j][e];
+                if (n < a.N && m < a.M) Y[(size_t)n * ldy + m] = R ? __fadd_rn(acc[i][j][e], rv[e]) : acc[i][j][e];
             }
         }
 }
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
         if (GEMM_ABL < 2 && kt + 1 < nk) stash(buf ^ 1);
         if (GEMM_ABL < 3) __syncthreads();
     }
-    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, a.ldy);
 }
 
 // ---- the same GEMM with LDS-DMA operand staging --------------------------------------------------------------------
@@ -198,7 +204,8 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
     const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups, work = total * (a.batch ? a.batch : 1);
+    const uint32_t splits = a.splits ? a.splits : 1;
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups, work = total * (a.batch ? a.batch : 1) * splits;
     const uint32_t ldw = a.ldw ? a.ldw : a.K;
     const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
     const uint32_t nk_full = a.K / GBK;
@@ -210,7 +217,8 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     // share a weight panel meet in one L2.
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
-  for (uint32_t wi = v0; wi < work; wi += G) {
+  for (uint32_t wv = v0; wv < work; wv += G) {
+    const uint32_t ks = wv % splits, wi = wv / splits;  // K range fastest: the pieces of one tile run side by side
     const uint32_t be = wi / total, bid = wi % total;
     const uint32_t g = bid / per_group, t = bid % per_group;
     const uint32_t tm = t / tiles_n;
@@ -218,14 +226,16 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     // causal P.V: a tile's contraction length grows with its row block, and with G % tiles_n == 0 the static assignment would hand
     // a workgroup the SAME row block every round (the unluckiest one the longest tile each time: 47 % balance at 8 row blocks).
     // Odd rounds take the row blocks in reverse, so consecutive rounds of a workgroup sum to the same length.
-    if (a.causal == 2 && G % tiles_n == 0 && ((wi / G) & 1)) tn = tiles_n - 1 - tn;
+    if (a.causal == 2 && G % tiles_n == 0 && ((wv / G) & 1)) tn = tiles_n - 1 - tn;
     const uint32_t n0 = tn * BN, m0 = tm * BM;
     if (a.causal == 1 && m0 > a.past + n0 + BN - 1) continue;
-    const uint32_t nk = a.causal == 2 ? min(nk_full, (a.past + n0 + BN + GBK - 1) / GBK) : nk_full;
-    const float* X = a.x + (size_t)be * a.xbs;
-    const float* W = a.w[g] + (size_t)be * a.wbs;
-    float* Y = a.y[g] + (size_t)be * a.ybs;
-    const float* R = a.r[g] ? a.r[g] + (size_t)be * a.ybs : nullptr;
+    const uint32_t nk = splits > 1 ? nk_full / splits : a.causal == 2 ? min(nk_full, (a.past + n0 + BN + GBK - 1) / GBK) : nk_full;
+    const uint32_t kbase = ks * nk * GBK;  // first column of this work item's K range (0 unless split)
+    const float* X = a.x + (size_t)be * a.xbs + kbase;
+    const float* W = a.w[g] + (size_t)be * a.wbs + kbase;
+    float* Y = splits > 1 ? a.part + ((size_t)(g * splits + ks) * a.N) * a.M : a.y[g] + (size_t)be * a.ybs;
+    const float* R = (splits > 1 || !a.r[g]) ? nullptr : a.r[g] + (size_t)be * a.ybs;
+    const uint32_t ldy = splits > 1 ? a.M : a.ldy;
     __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
 
     // piece p (8 tile rows) is fetched by wave p % 4; this lane's source pointer for each of its pieces
@@ -331,8 +341,31 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
         mfmas(1, 2, 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
-    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, ldy);
   }
+}
+
+// Second pass of split-K: Y_g[n][m] = (R_g[n][m] +) sum over ks, in ks order, of part[g][ks][n][m].
+__global__ __launch_bounds__(256) void k_splitk_reduce(const GemmArgs a) {
+    const uint32_t M4 = a.M / 4;
+    const uint64_t per = (uint64_t)a.N * M4, tot = per * a.groups;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t g = (uint32_t)(i / per);
+        const uint64_t r = i % per;
+        const uint32_t n = (uint32_t)(r / M4), m = (uint32_t)(r % M4) * 4;
+        const float* p = a.part + ((size_t)(g * a.splits) * a.N + n) * a.M + m;
+        f4 s = *(const f4*)p;
+        for (uint32_t k = 1; k < a.splits; ++k) {
+            const f4 v = *(const f4*)(p + (size_t)k * a.N * a.M);
+            s.x = __fadd_rn(s.x, v.x); s.y = __fadd_rn(s.y, v.y); s.z = __fadd_rn(s.z, v.z); s.w = __fadd_rn(s.w, v.w);
+        }
+        const size_t o = (size_t)n * a.ldy + m;
+        if (a.r[g]) {
+            const f4 v = *(const f4*)(a.r[g] + o);
+            s.x = __fadd_rn(s.x, v.x); s.y = __fadd_rn(s.y, v.y); s.z = __fadd_rn(s.z, v.z); s.w = __fadd_rn(s.w, v.w);
+        }
+        *(f4*)(a.y[g] + o) = s;
+    }
 }
 
 // ---- block-int8 weights: dequantising GEMM (prefill of config-4 models) -------------------------------------------------
@@ -485,7 +518,7 @@ __global__ __launch_bounds__(256) void k_gemm_q8(const GemmArgs a) {
         mfmas(1, 2, 4);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, a.ldy);
   }
 }
 

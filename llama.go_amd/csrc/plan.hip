@@ -192,8 +192,38 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
         if (rc) return rc;
         if (g_prepare_only) return 0;
         a.batch = batch;
-        const uint64_t work = (uint64_t)tiles * batch;
-        hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(work, (uint64_t)ctx->ds->num_cu)), dim3(256), lds, ctx->stream, a);
+        const uint32_t ncu = (uint32_t)ctx->ds->num_cu;
+        // Split-K for launches with few tiles (prompts of <= 128 tokens are ONE row of tiles): S ranges of the contraction per tile,
+        // partial products summed by a second pass.  Cost in slab times: rounds of the busiest CU x (slabs per item + ~8 of
+        // prologue/epilogue); S must divide the slab count and leave >= 16 slabs per item.
+        uint32_t splits = 1;
+        if (!a.causal && batch == 1 && tiles < ncu && a.M % 4 == 0 && a.ldy % 4 == 0 && !getenv("LLAMAHIP_GEMM_NO_SPLITK")) {
+            const uint32_t nkf = a.K / GBK;
+            double best = (double)((tiles + ncu - 1) / ncu) * (nkf + 8);
+            for (uint32_t s2 = 2; s2 <= 32; s2 *= 2) {
+                if (nkf % s2 || nkf / s2 < 16) break;
+                const double c = (double)(((uint64_t)tiles * s2 + ncu - 1) / ncu) * (nkf / s2 + 8);
+                if (c < best * 0.95) { best = c; splits = s2; }
+            }
+        }
+        if (splits > 1) {
+            const uint64_t need = (uint64_t)a.groups * splits * a.N * a.M;
+            if (need > ctx->splitk_floats) {
+                LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
+                ctx->splitk = nullptr; ctx->splitk_floats = 0;
+                LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
+                ctx->splitk_floats = need;
+            }
+            a.splits = splits;
+            a.part = ctx->splitk;
+        }
+        const uint64_t work = (uint64_t)tiles * batch * splits;
+        hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(work, (uint64_t)ncu)), dim3(256), lds, ctx->stream, a);
+        if (splits > 1) {
+            const uint64_t quads = (uint64_t)a.groups * a.N * (a.M / 4);
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+        }
     } else {
         auto kern = k_gemm_mfma<WN, WM, TN, TM>;
         const size_t lds = (size_t)2 * GBK * (BN + 1 + BM + 1) * sizeof(float);
@@ -298,6 +328,8 @@ int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, 
         const uint32_t tiles = tn * ((M + bm - 1) / bm) * groups;
         return (double)((tiles + ncu - 1) / ncu) * bm * penalty;
     };
+    // up to 64 rows: 64 x 128 tiles (half the matrix work of a 128-row tile whose upper half would be padding)
+    if (n <= 64) return launch_gemm<2, 2, 1, 2>(ctx, a, name);
     const double c128 = cost(128, 1.0), c160 = cost(160, 1.03), c64 = cost(64, 1.10);
     if (c160 < c128 && c160 <= c64) return launch_gemm<4, 1, 1, 5>(ctx, a, name);
     if (c64 < c128) return launch_gemm<2, 2, 2, 1>(ctx, a, name);
@@ -745,6 +777,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     destroy_plans(ctx);
     if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->splitk) hipFree(ctx->splitk);
     if (ctx->staging) hipHostFree(ctx->staging);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
