@@ -343,10 +343,13 @@ static int gemm_mfma(lh_ctx* ctx, const float* w, const float* x, float* y, cons
 
 // Y[n][M] = X[n][K] . W[M][K]^T (+ resid).  N >= 32: fp32 MFMA GEMM (compute-bound side); smaller N: the weight-streaming
 // kernel with NC activation rows in registers (HBM-bound side, weights read once per NC rows).
+static constexpr uint32_t MFMA_MIN_ROWS = 9;
 int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n,
                  uint32_t ldx, uint32_t ldy, const char* name) {
     if (K % 4) LH_FAIL(ctx, LH_ESHAPE, "gemm %s: K=%u must be a multiple of 4", name, K);
-    if (n >= 32 && K % GBK == 0 && ldx % 4 == 0) return gemm_mfma(ctx, w, x, y, resid, M, K, n, ldx, ldy, name);
+    // from 9 rows on the MFMA GEMM (64-row tiles, split-K) beats two or more passes of the 8-column weight stream (7B, one Eval:
+    // 8 rows 10.0 ms and 16 rows 18.4 ms on the stream; 17 rows 11.1 ms on the MFMA path)
+    if (n >= MFMA_MIN_ROWS && K % GBK == 0 && ldx % 4 == 0) return gemm_mfma(ctx, w, x, y, resid, M, K, n, ldx, ldy, name);
     const uint32_t K4 = K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
     const uint32_t NCmax = ki <= 2 ? 8 : 4;
@@ -658,7 +661,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    if (m.wtype == 7 && (n < 32 || m.d % GBK || m.F % GBK || m.hd % 32)) {
+    if (m.wtype == 7 && (n < MFMA_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
         // On a pipeline stage row i of the received / forwarded residual stream stands in for the token id / the logits row.
@@ -691,7 +694,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
         { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
-        const bool mfma = n >= 32 && d % GBK == 0 && F % GBK == 0;
+        const bool mfma = n >= MFMA_MIN_ROWS && d % GBK == 0 && F % GBK == 0;
         const bool q8 = m.wtype == 7;
         if (q8) {
             const float* ws[3] = {L.wq, L.wk, L.wv};
@@ -709,7 +712,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
                            m.vc + slot, rope, d, m.hd, past); }
-        if (mfma && m.hd % 32 == 0) {
+        if (mfma && n >= 32 && m.hd % 32 == 0) {  // fewer queries: the per-query kernel (no score tensor) is cheaper
             if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
         } else {
             AttnArgs a = {};
