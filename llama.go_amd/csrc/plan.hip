@@ -344,6 +344,9 @@ static int gemm_mfma(lh_ctx* ctx, const float* w, const float* x, float* y, cons
 // Y[n][M] = X[n][K] . W[M][K]^T (+ resid).  N >= 32: fp32 MFMA GEMM (compute-bound side); smaller N: the weight-streaming
 // kernel with NC activation rows in registers (HBM-bound side, weights read once per NC rows).
 static constexpr uint32_t MFMA_MIN_ROWS = 9;
+// block-int8: the dequantising GEMM has neither split-K nor 64-row tiles yet (about 33 ms for any short prompt on 7B); below 17
+// tokens the same number of single-token steps on the int8 stream (2.1 ms each) is faster
+static constexpr uint32_t Q8_GEMM_MIN_ROWS = 17;
 int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n,
                  uint32_t ldx, uint32_t ldy, const char* name) {
     if (K % 4) LH_FAIL(ctx, LH_ESHAPE, "gemm %s: K=%u must be a multiple of 4", name, K);
@@ -661,7 +664,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    if (m.wtype == 7 && (n < MFMA_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
+    if (m.wtype == 7 && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
         // On a pipeline stage row i of the received / forwarded residual stream stands in for the token id / the logits row.
