@@ -384,22 +384,26 @@ __global__ __launch_bounds__(256) void k_gemm_q8(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
     const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
+    const uint32_t splits = a.splits ? a.splits : 1;  // split-K exactly as in k_gemm_glds
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups * splits;
     const int li = lane & 31, lh = lane >> 5, sw = (li >> 1) & 7;
-    const uint32_t nk = a.K / GBK, KB = a.K / 32;
+    const uint32_t nk = a.K / GBK / splits, KB = a.K / 32;
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const uint32_t gran = (uint32_t)((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7));
     const int wrow = tid >> 1, whalf = tid & 1;  // W staging: thread -> (row within a 128-row pass, 16-weight half of the slab)
-  for (uint32_t wi = v0; wi < total; wi += G) {
+  for (uint32_t wv = v0; wv < total; wv += G) {
+    const uint32_t ks = wv % splits, wi = wv / splits;
     const uint32_t g = wi / per_group, t = wi % per_group;
     const uint32_t tm = t / tiles_n, tn = t % tiles_n;
     const uint32_t n0 = tn * BN, m0 = tm * BM;
-    const float* X = a.x;
-    const signed char* Wq = (const signed char*)a.w[g];
-    const float* Ws = a.ws[g];
-    float* Y = a.y[g];
-    const float* R = a.r[g];
+    const uint32_t kbase = ks * nk * GBK;  // first column of this work item's K range
+    const float* X = a.x + kbase;
+    const signed char* Wq = (const signed char*)a.w[g] + kbase;
+    const float* Ws = a.ws[g] + kbase / 32;
+    float* Y = splits > 1 ? a.part + ((size_t)(g * splits + ks) * a.N) * a.M : a.y[g];
+    const float* R = splits > 1 ? nullptr : a.r[g];
+    const uint32_t ldy = splits > 1 ? a.M : a.ldy;
     __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
 
     const float* src[XPW];
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(256) void k_gemm_q8(const GemmArgs a) {
         mfmas(1, 2, 4);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, a.ldy);
+    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, ldy);
   }
 }
 

@@ -243,28 +243,59 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
     GemmArgs a = {};
     a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) { a.w[g] = wq[g]; a.ws[g] = wsc[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }
-    // tile shape by the same balance model as the fp32 GEMM: rounds of the busiest CU x tile width
+    // tile shape by the same balance model as the fp32 GEMM (rounds of the busiest CU x tile width); 64-row tiles up to 64 rows;
+    // split-K when the launch has fewer tiles than CUs (see launch_gemm)
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, tn = (n + 127) / 128;
     auto rounds = [&](uint32_t bm) { return (double)((tn * ((M + bm - 1) / bm) * groups + ncu - 1) / ncu) * bm; };
-    const bool wide = rounds(160) * 1.03 < rounds(128);
+    const int shape = n <= 64 ? 2 : rounds(160) * 1.03 < rounds(128) ? 1 : 0;
+    const uint32_t bm = shape == 1 ? 160 : 128;
+    const uint32_t tiles = tn * ((M + bm - 1) / bm) * groups;
+    if (tiles < ncu && M % 4 == 0 && ldy % 4 == 0 && !getenv("LLAMAHIP_GEMM_NO_SPLITK")) {
+        const uint32_t nkf = K / GBK;
+        double best = (double)(nkf + 8);
+        for (uint32_t s2 = 2; s2 <= 32; s2 *= 2) {
+            if (nkf % s2 || nkf / s2 < 16) break;
+            const double c = (double)(((uint64_t)tiles * s2 + ncu - 1) / ncu) * (nkf / s2 + 8);
+            if (c < best * 0.95) { best = c; a.splits = s2; }
+        }
+        if (a.splits > 1) {
+            const uint64_t need = (uint64_t)groups * a.splits * n * M;
+            if (need > ctx->splitk_floats) {
+                LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
+                ctx->splitk = nullptr; ctx->splitk_floats = 0;
+                LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
+                ctx->splitk_floats = need;
+            }
+            a.part = ctx->splitk;
+        }
+    }
+    const uint32_t items = tiles * (a.splits ? a.splits : 1);
     ProfScope ps(ctx->stream, name, (uint64_t)M * K / 32 * 36 * groups);
     int rc;
-    if (wide) {
+    static bool flags[3][16] = {};
+    if (shape == 1) {
         auto kern = k_gemm_q8<4, 1, 1, 5>;
-        static bool flags[16] = {};
         const size_t lds = std::max<size_t>((size_t)2 * (128 + 160) * 32 * sizeof(float), 82 * 1024);
-        if ((rc = set_lds_once(ctx, kern, lds, flags))) return rc;
+        if ((rc = set_lds_once(ctx, kern, lds, flags[1]))) return rc;
         if (g_prepare_only) return 0;
-        const uint32_t tiles = tn * ((M + 159) / 160) * groups;
-        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(tiles, ncu)), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
+    } else if (shape == 2) {
+        auto kern = k_gemm_q8<2, 2, 1, 2>;
+        const size_t lds = std::max<size_t>((size_t)2 * (64 + 128) * 32 * sizeof(float), 82 * 1024);
+        if ((rc = set_lds_once(ctx, kern, lds, flags[2]))) return rc;
+        if (g_prepare_only) return 0;
+        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
     } else {
         auto kern = k_gemm_q8<2, 2, 2, 2>;
-        static bool flags[16] = {};
         const size_t lds = std::max<size_t>((size_t)2 * (128 + 128) * 32 * sizeof(float), 82 * 1024);
-        if ((rc = set_lds_once(ctx, kern, lds, flags))) return rc;
+        if ((rc = set_lds_once(ctx, kern, lds, flags[0]))) return rc;
         if (g_prepare_only) return 0;
-        const uint32_t tiles = tn * ((M + 127) / 128) * groups;
-        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(tiles, ncu)), dim3(256), lds, ctx->stream, a);
+        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
+    }
+    if (a.splits > 1) {
+        const uint64_t quads = (uint64_t)groups * n * (M / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -344,9 +375,8 @@ static int gemm_mfma(lh_ctx* ctx, const float* w, const float* x, float* y, cons
 // Y[n][M] = X[n][K] . W[M][K]^T (+ resid).  N >= 32: fp32 MFMA GEMM (compute-bound side); smaller N: the weight-streaming
 // kernel with NC activation rows in registers (HBM-bound side, weights read once per NC rows).
 static constexpr uint32_t MFMA_MIN_ROWS = 9;
-// block-int8: the dequantising GEMM has neither split-K nor 64-row tiles yet (about 33 ms for any short prompt on 7B); below 17
-// tokens the same number of single-token steps on the int8 stream (2.1 ms each) is faster
-static constexpr uint32_t Q8_GEMM_MIN_ROWS = 17;
+// block-int8: below this many tokens single-token steps on the int8 stream (2.1 ms each on 7B) beat the dequantising GEMM
+static constexpr uint32_t Q8_GEMM_MIN_ROWS = 9;
 int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const float* resid, uint32_t M, uint32_t K, uint32_t n,
                  uint32_t ldx, uint32_t ldy, const char* name) {
     if (K % 4) LH_FAIL(ctx, LH_ESHAPE, "gemm %s: K=%u must be a multiple of 4", name, K);
