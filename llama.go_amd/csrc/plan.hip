@@ -106,7 +106,8 @@ static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint
 // block-int8 GEMV: pick threads-per-row so the 16-byte chunks of a row fill the lanes (K = 4096 -> 256 threads x 4 rows side by side)
 template <int PRO, int EPI, int MAP>
 static int gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name) {
-    if (a.K % 32 || a.M % 2) LH_FAIL(ctx, LH_ESHAPE, "gemv_q8 %s: K=%u must be a multiple of 32 and M=%u even", name, a.K, a.M);
+    if (a.K % 32 || ((EPI == EPI_QKV_ROPE || EPI == EPI_SILU_MUL) && a.M % 2))
+        LH_FAIL(ctx, LH_ESHAPE, "gemv_q8 %s: K=%u must be a multiple of 32%s", name, a.K, a.M % 2 ? " and the row count even" : "");
     if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv_q8 %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
     const uint32_t K16 = a.K / 16;
     const uint64_t bytes = (uint64_t)a.M * a.K / 32 * 36;
@@ -129,7 +130,10 @@ static int gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, int wtype = 0)
 
 template <int PRO, int EPI, int MAP>
 static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
-    if (a.K % 4 || a.M % 2) LH_FAIL(ctx, LH_ESHAPE, "gemv %s: K=%u must be a multiple of 4 and M=%u even", name, a.K, a.M);
+    // rows are dealt to the workgroups in pairs (the last one takes an odd remainder); only the epilogues that combine two rows
+    // (RoPE pairs, w1|w3 interleave) need an even count
+    if (a.K % 4 || ((EPI == EPI_QKV_ROPE || EPI == EPI_SILU_MUL) && a.M % 2))
+        LH_FAIL(ctx, LH_ESHAPE, "gemv %s: K=%u must be a multiple of 4%s", name, a.K, a.M % 2 ? " and the row count even" : "");
     // one finishing thread per row and rows*16 partial sums in LDS per workgroup
     if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
     const uint32_t K4 = a.K / 4;

@@ -47,6 +47,57 @@ def decode_both(product, oracle, shape, ctx, prompt, n_predict, seed=1234, layer
     return out
 
 
+@pytest.mark.parametrize("kw,ctx,n_prompt", [
+    (dict(vocab=300, embd=384, mult=32, heads=6, layers=2), 96, 40),      # head dim 64, ragged vocabulary, ff = 1024
+    (dict(vocab=1000, embd=256, mult=16, heads=8, layers=3), 300, 70),    # head dim 32, context > 256, ff = 688 (not a tile multiple)
+    (dict(vocab=515, embd=640, mult=8, heads=5, layers=2), 300, 7),       # 5 heads of 128, odd vocabulary, context > 256 (split attention)
+    (dict(vocab=2048, embd=1024, mult=256, heads=8, layers=1), 40, 1),    # single-token prompt
+    (dict(vocab=777, embd=512, mult=64, heads=4, layers=2), 160, 130),    # two row tiles, ragged second one
+])
+def test_odd_shapes_match_oracle(product, oracle, kw, ctx, n_prompt):
+    """Shapes outside the LLaMA family's (head dims 32 / 64, ragged vocabularies and ff sizes, contexts on both sides of the
+    split-attention threshold): prefill (whatever kernel family the shape selects) + decode steps against the checker."""
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(n_prompt + kw["embd"])
+    prompt = [int(t) for t in rng.integers(0, kw["vocab"], n_prompt)]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 99)
+        c = m.NewContext(ctx, 16, False)
+        res[name] = c.GreedyDecode(prompt, 6)
+        c.free()
+        m.free()
+    (th, lh_), (to, lo) = res["hip"], res["orc"]
+    assert rel(lh_, lo) <= TOL
+    if greedy_margin(lo) > 10 * TOL:
+        assert th == to
+
+
+def test_chunked_prefill_all_kernel_families(product, oracle):
+    """One context fed in chunks of 3, 9, 20, 40, 70 and 1 tokens: every Eval continues from a non-empty cache (past > 0) and takes a
+    different kernel family (weight stream with token rows in registers, MFMA GEMM with 64-row tiles + per-query attention, MFMA
+    GEMM + batched-GEMM attention with causal skipping, decode graph)."""
+    kw = dict(SHAPES["small"])
+    kw["layers"] = 2
+    hp = make_hparams(**kw, ctx=160)
+    rng = np.random.default_rng(11)
+    toks = [int(t) for t in rng.integers(0, kw["vocab"], 143)]
+    chunks = [3, 9, 20, 40, 70, 1]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 1234)
+        c = m.NewContext(160, 16, False)
+        out, past = [], 0
+        for n in chunks:
+            out.append(c.Eval(toks[past:past + n], past))
+            past += n
+        c.free()
+        m.free()
+        res[name] = out
+    for a, b in zip(res["hip"], res["orc"]):
+        assert rel(a, b) <= TOL
+
+
 @pytest.mark.parametrize("shape,prompt", [("tiny", [1, 5, 9, 200, 17, 3, 44, 100]), ("tiny", [7]), ("small", [1, 306, 1658, 278, 1593, 310, 834, 338])])
 def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     out = decode_both(product, oracle, shape, 64, prompt, 12)
