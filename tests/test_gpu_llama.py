@@ -73,6 +73,28 @@ def test_odd_shapes_match_oracle(product, oracle, kw, ctx, n_prompt):
         assert th == to
 
 
+@pytest.mark.parametrize("kw,ctx,n_prompt", [
+    (dict(vocab=515, embd=640, mult=32, heads=5, layers=2), 300, 7),      # odd vocabulary, 5 heads, context > 256, decode-path prefill
+    (dict(vocab=300, embd=384, mult=32, heads=6, layers=2), 96, 40),      # head dim 64: per-query attention behind the int8 GEMM
+    (dict(vocab=777, embd=512, mult=64, heads=4, layers=2), 200, 150),    # two row tiles, ragged second one, ragged vocabulary
+])
+def test_odd_shapes_block_int8(product, oracle, kw, ctx, n_prompt):
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(n_prompt + kw["embd"] + 1)
+    prompt = [int(t) for t in rng.integers(0, kw["vocab"], n_prompt)]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 99).QuantizeQ8()
+        c = m.NewContext(ctx, 16, False)
+        res[name] = c.GreedyDecode(prompt, 5)
+        c.free()
+        m.free()
+    (th, lh_), (to, lo) = res["hip"], res["orc"]
+    assert rel(lh_, lo) <= TOL
+    if greedy_margin(lo) > 10 * TOL:
+        assert th == to
+
+
 def test_chunked_prefill_all_kernel_families(product, oracle):
     """One context fed in chunks of 3, 9, 20, 40, 70 and 1 tokens: every Eval continues from a non-empty cache (past > 0) and takes a
     different kernel family (weight stream with token rows in registers, MFMA GEMM with 64-row tiles + per-query attention, MFMA
