@@ -48,7 +48,10 @@ struct GemmArgs {
 };
 
 constexpr int GBK = 32;
-constexpr int GST = 3;  // LDS stages of k_gemm_glds
+#ifndef LH_GST
+#define LH_GST 3
+#endif
+constexpr int GST = LH_GST;  // LDS stages of k_gemm_glds (tools/gemm_probe.hip may override)
 
 // C/D layout (dtype-independent on gfx950): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 // The residual is fetched for a whole 32 x 32 block before any of it is used, through clamped (always valid) addresses: a load

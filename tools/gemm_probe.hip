@@ -11,7 +11,12 @@ template <int WN, int WM, int TN, int TM>
 static void run_glds(const char* name, uint32_t N, uint32_t M, uint32_t K, uint32_t groups, float* x, float* w, float* y) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
     size_t lds = (size_t)GST * (BN + BM) * 32 * sizeof(float);
+#ifdef PROBE_TWO_PER_CU
+    const uint32_t slots = 512;   // two persistent workgroups per CU (needs GST = 2)
+#else
+    const uint32_t slots = 256;
     if (lds < 82 * 1024) lds = 82 * 1024;
+#endif
     auto kern = k_gemm_glds<WN, WM, TN, TM>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     GemmArgs a = {};
@@ -22,7 +27,7 @@ static void run_glds(const char* name, uint32_t N, uint32_t M, uint32_t K, uint3
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    const uint32_t grid = tiles < 256 ? tiles : 256;
+    const uint32_t grid = tiles < slots ? tiles : slots;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a);
     hipDeviceSynchronize();
     const int reps = 5;
