@@ -294,8 +294,8 @@ __global__ __launch_bounds__(TH) void k_gemv_cols(const GemmColsArgs a) {
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float s = wave_sum(acc[u][c]);
-                if (lane == 0) red[((buf * U + u) * NC + c) * NW + wave] = s;
+                const float s = wave_sum_lane63(acc[u][c]);  // 6 DPP adds, total in lane 63 (the U*NC reductions outweigh the FMAs here)
+                if (lane == 63) red[((buf * U + u) * NC + c) * NW + wave] = s;
             }
         __syncthreads();
         if (tid < U * NC) {
