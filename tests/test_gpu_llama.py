@@ -95,6 +95,27 @@ def test_odd_shapes_block_int8(product, oracle, kw, ctx, n_prompt):
         assert th == to
 
 
+@pytest.mark.parametrize("n_prompt", [8, 40, 100, 300])
+def test_results_are_bitwise_reproducible(product, n_prompt):
+    """Fixed reduction orders everywhere (wave trees, split-K partials summed by a second pass, no float atomics): the same Eval
+    twice, on fresh contexts, gives the same bits — for the weight-stream, 64-row-tile, split-K and multi-tile GEMM paths."""
+    kw = dict(SHAPES["small"])
+    kw["layers"] = 2
+    hp = make_hparams(**kw, ctx=320)
+    rng = np.random.default_rng(n_prompt)
+    prompt = [int(t) for t in rng.integers(0, kw["vocab"], n_prompt)]
+    m = product.NewSyntheticModel(hp, 1234)
+    outs = []
+    for _ in range(2):
+        c = m.NewContext(320, 1, False)
+        a = c.Eval(prompt, 0)
+        b = c.Eval([3], n_prompt)
+        outs.append((a, b))
+        c.free()
+    m.free()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_chunked_prefill_all_kernel_families(product, oracle):
     """One context fed in chunks of 3, 9, 20, 40, 70 and 1 tokens: every Eval continues from a non-empty cache (past > 0) and takes a
     different kernel family (weight stream with token rows in registers, MFMA GEMM with 64-row tiles + per-query attention, MFMA
