@@ -77,15 +77,15 @@ static int set_lds_once(lh_ctx* ctx, KernT kern, size_t lds, bool* flags) {
     return 0;
 }
 
-template <int KI, int U, int PRO, int EPI, int MAP>
+template <int KI, int U, int PRO, int EPI, int MAP, int THR = TH>
 static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
-    auto kern = k_gemv<KI, U, TH, PRO, EPI, MAP>;
+    auto kern = k_gemv<KI, U, THR, PRO, EPI, MAP>;
     static bool flags[16] = {};
     int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -134,16 +134,26 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     // (RoPE pairs, w1|w3 interleave) need an even count
     if (a.K % 4 || ((EPI == EPI_QKV_ROPE || EPI == EPI_SILU_MUL) && a.M % 2))
         LH_FAIL(ctx, LH_ESHAPE, "gemv %s: K=%u must be a multiple of 4%s", name, a.K, a.M % 2 ? " and the row count even" : "");
-    // one finishing thread per row and rows*16 partial sums in LDS per workgroup
-    if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
     const uint32_t K4 = a.K / 4;
-    const int ki = (int)((K4 + TH - 1) / TH);
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
-    // rows in flight per wave (U): same-box A/B on the 7B decode loop, tok/s: U = 4 for every K <= 4096 kernel 219.0; U = 2 for wo
-    // only (16 rows per workgroup) 222.2; U = 2 for all of them 222.8-223.6; (U for K = 4096, U for K = 11008) = (1,2) 200.0,
-    // (3,2) 220.8, (2,3) 222.4, (2,1) 224.1: about 32-48 bytes per lane in flight is the sweet spot.  13B decode (K = 5120, two
-    // float4 per thread): U = 4 118.8, U = 2 121.4, U = 1 120.6 tok/s; 65B shard (K = 8192 / 22016): U = 2 vs 1 within noise
-    switch (ki) {
+    const uint32_t rows_wg = a.M / (uint32_t)ctx->ds->num_cu + 4;  // one finishing thread per row, rows * waves partial sums in LDS
+    // Workgroup size and rows in flight per wave (U), same-box A/B on the decode loops (tok/s).  7B, 1024 threads:
+    // U = 4 for the K = 4096 kernels 219.0, U = 2 222.8, (U at K = 4096, U at K = 11008) = (1,2) 200.0, (3,2) 220.8, (2,3) 222.4,
+    // (2,1) 224.1; 512 threads (8 waves, half the per-row reductions and LDS partials), two float4 per thread at K = 4096, six at
+    // K = 11008: (2,1) 226.7, (3,1) 224.5, (4,1) 223.4, (2,2) 226.1, (1,1) 209.8.  About 32-48 KB in flight per CU is the sweet
+    // spot.  13B, 1024 threads, K = 5120: U = 4 118.8, U = 2 121.4, U = 1 120.6.
+    if (K4 <= 6 * 512 && rows_wg <= 512) {
+        switch ((K4 + 511) / 512) {
+            case 1: return launch_gemv<1, 2, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
+            case 2: return launch_gemv<2, 2, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
+            case 3: return launch_gemv<3, 2, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
+            case 4: return launch_gemv<4, 1, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
+            case 5: return launch_gemv<5, 1, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
+            default: return launch_gemv<6, 1, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
+        }
+    }
+    if (rows_wg > (uint32_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
+    switch ((K4 + TH - 1) / TH) {
         case 1: return launch_gemv<1, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 2: return launch_gemv<2, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 3: return launch_gemv<3, 1, PRO, EPI, MAP>(ctx, a, name, bytes);
