@@ -140,8 +140,17 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     // Workgroup size and rows in flight per wave (U), same-box A/B on the decode loops (tok/s).  7B, 1024 threads:
     // U = 4 for the K = 4096 kernels 219.0, U = 2 222.8, (U at K = 4096, U at K = 11008) = (1,2) 200.0, (3,2) 220.8, (2,3) 222.4,
     // (2,1) 224.1; 512 threads (8 waves, half the per-row reductions and LDS partials), two float4 per thread at K = 4096, six at
-    // K = 11008: (2,1) 226.7, (3,1) 224.5, (4,1) 223.4, (2,2) 226.1, (1,1) 209.8.  About 32-48 KB in flight per CU is the sweet
+    // K = 11008: (2,1) 226.7, (3,1) 224.5, (4,1) 223.4, (2,2) 226.1, (1,1) 209.8; 256 threads at K = 4096 (four float4 per thread): U = 2 227.7,
+    // U = 3 227.0.  About 32-48 KB in flight per CU is the sweet
     // spot.  13B, 1024 threads, K = 5120: U = 4 118.8, U = 2 121.4, U = 1 120.6.
+    if (K4 <= 4 * 256 && rows_wg <= 256) {  // K <= 4096: 4 waves (K = 4096: 226.0 -> 227.7 tok/s against 8 waves; no gain at K = 11008)
+        switch ((K4 + 255) / 256) {
+            case 1: return launch_gemv<1, 4, PRO, EPI, MAP, 256>(ctx, a, name, bytes);
+            case 2: return launch_gemv<2, 4, PRO, EPI, MAP, 256>(ctx, a, name, bytes);
+            case 3: return launch_gemv<3, 2, PRO, EPI, MAP, 256>(ctx, a, name, bytes);
+            default: return launch_gemv<4, 2, PRO, EPI, MAP, 256>(ctx, a, name, bytes);
+        }
+    }
     if (K4 <= 6 * 512 && rows_wg <= 512) {
         switch ((K4 + 511) / 512) {
             case 1: return launch_gemv<1, 2, PRO, EPI, MAP, 512>(ctx, a, name, bytes);
