@@ -205,8 +205,9 @@ int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4
     b->device = ctx->device;
     hipError_t e = hipMalloc((void**)&b->dev, b->bytes);
     if (e != hipSuccess) LH_FAIL(ctx, LH_ENOMEM, "lh_tensor_register: hipMalloc(%llu bytes): %s", (unsigned long long)b->bytes, hipGetErrorString(e));
-    if (host) LH_HIP(ctx, hipMemcpy(b->dev, host, b->bytes, hipMemcpyHostToDevice));
-    else LH_HIP(ctx, hipMemset(b->dev, 0, b->bytes));
+    if (host) LH_HIP(ctx, hipMemcpyAsync(b->dev, host, b->bytes, hipMemcpyHostToDevice, ctx->stream));
+    else LH_HIP(ctx, hipMemsetAsync(b->dev, 0, b->bytes, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::lock_guard<std::mutex> lk(ds->mu);
     lh_buf id = ds->next_id++;
     if (key) ds->by_key[key] = id;
@@ -232,7 +233,8 @@ int lh_buf_upload(lh_ctx* ctx, lh_buf buf, uint64_t off, const float* host, uint
     if (b->dtype != 0) LH_FAIL(ctx, LH_EINVAL, "lh_buf_upload: not an f32 buffer");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    LH_HIP(ctx, hipMemcpy(b->dev + off, host, n * 4, hipMemcpyHostToDevice));
+    LH_HIP(ctx, hipMemcpyAsync(b->dev + off, host, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;
 }
 
@@ -244,7 +246,8 @@ int lh_buf_read(lh_ctx* ctx, lh_buf buf, uint64_t off, float* dst, uint64_t n) {
     if (b->dtype == 7) return lh_buf_read_q8(ctx, buf, off, dst, n);
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    LH_HIP(ctx, hipMemcpy(dst, b->dev + off, n * 4, hipMemcpyDeviceToHost));
+    LH_HIP(ctx, hipMemcpyAsync(dst, b->dev + off, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;
 }
 

@@ -473,7 +473,8 @@ int lh_node_read(lh_ctx* ctx, uint32_t index, uint64_t off, float* dst, uint64_t
     if (off > ctx->last_len[index] || n > ctx->last_len[index] - off) LH_FAIL(ctx, LH_EINVAL, "lh_node_read: range outside tensor %u", index);
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    LH_HIP(ctx, hipMemcpy(dst, ctx->last_ptr[index] + off, n * 4, hipMemcpyDeviceToHost));
+    LH_HIP(ctx, hipMemcpyAsync(dst, ctx->last_ptr[index] + off, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;
 }
 

@@ -667,7 +667,10 @@ static int ensure_decode_graph(Plan* p, int adv) {
     int rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
     g_prepare_only = false;
     if (rc) return rc;
-    LH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    // Relaxed: other pods' threads keep allocating / copying while this one captures (server.go:88-101 runs pods concurrently).  The
+    // captured stream is non-blocking and nothing inside the capture touches the legacy stream; in the stricter modes a
+    // synchronous hipMemcpy of ANOTHER thread invalidated this capture (tests/test_gpu_llama.py::test_concurrent_pods_share_one_model).
+    LH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
     rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
     hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc) return rc;

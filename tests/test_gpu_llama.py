@@ -116,6 +116,41 @@ def test_results_are_bitwise_reproducible(product, n_prompt):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_concurrent_pods_share_one_model(product):
+    """The reference serves several pods at once: goroutines with their own llama.Context over ONE shared Model (server.go:45,
+    88-101, 151).  Four Python threads (ctypes releases the GIL during the calls) run the generation loop concurrently on their own
+    contexts and streams; every pod must produce exactly what it produces alone."""
+    import threading
+    kw = dict(SHAPES["small"])
+    hp = make_hparams(**kw, ctx=96)
+    m = product.NewSyntheticModel(hp, 1234)
+    prompts = [[1, 5, 9, 200], [7, 8], [300, 2, 2, 2, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55], [11] * 40]
+    alone = []
+    for pr in prompts:
+        c = m.NewContext(96, 1, False)
+        alone.append(c.GreedyDecode(pr, 24, want_logits=False)[0])
+        c.free()
+    got, errs = [None] * len(prompts), []
+
+    def pod(i):
+        try:
+            c = m.NewContext(96, 1, False)
+            for _ in range(3):
+                got[i] = c.GreedyDecode(prompts[i], 24, want_logits=False)[0]
+            c.free()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=pod, args=(i,)) for i in range(len(prompts))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    m.free()
+    assert not errs, errs
+    assert got == alone
+
+
 def test_chunked_prefill_all_kernel_families(product, oracle):
     """One context fed in chunks of 3, 9, 20, 40, 70 and 1 tokens: every Eval continues from a non-empty cache (past > 0) and takes a
     different kernel family (weight stream with token rows in registers, MFMA GEMM with 64-row tiles + per-query attention, MFMA
