@@ -11,10 +11,14 @@ token ids evaluated as one prefill, then greedy decode at positions P = 8, 9, ..
 (llama.Eval with N = 1: 32 x [rmsnorm, wq|wk|wv, rope, attention, wo, rmsnorm, w1|w3, silu*mul, w2] + lm_head) per stream.
 
 N = 1: one stream; steps run device-resident (argmax on the GPU feeds the next step, hipGraph replay).
-N > 1: layers are sharded in contiguous blocks over the ranks; N independent streams ("pods", server.go:88-101)
-       keep the pipeline full: in one step every stream advances one token, so per-GPU work per step is constant
-       (scaling: weak) and value = N*K tokens / time.  The residual stream [4096 f32] hops rank r -> r+1 with RCCL send/recv;
-       the sampled token id returns from the last rank to rank 0 the same way.
+N > 1: layers are sharded in contiguous blocks over the ranks (SURVEY §8e); `--pods` independent streams (server.go:88-101;
+       default 4 N) keep the pipeline full: in one step every stream advances one token, so per-GPU work per step is constant
+       (scaling: weak) and value = pods*K tokens / time.  The residual stream [4096 f32] hops rank r -> r+1 and the sampled token
+       id returns from the last rank to rank 0 as RCCL send/recv issued by the library itself (lh_pipeline_run: schedule, stages
+       and p2p all below the C-ABI); torch.distributed (gloo) only carries the control plane here: the 128-byte RCCL id, the
+       barriers around the timed region and the max-over-ranks of the time.  `--pods 1` is the single greedy stream walking
+       through the stages (the latency curve of SURVEY §8e).  Started without torch.distributed.run, `--gpus N` spawns its own
+       N ranks.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed live), "cpu_baseline" (oracle on the host cores,
 N = 1 only), "parity" (token ids / logits vs that oracle run).
@@ -60,6 +64,27 @@ def usable_cores():
     return n
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU), relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,10 +94,13 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the bounded CPU-baseline sample")
-    ap.add_argument("--pods", type=int, default=0, help="independent greedy streams in flight for N > 1 (default 4 N; must be >= N)")
+    ap.add_argument("--pods", type=int, default=0, help="independent greedy streams in flight for N > 1 (default 4 N; 1 = the single-stream latency curve)")
     ap.add_argument("--no-prefill", action="store_true", help="skip the config-3 side measurement (13B, one 1024-token Eval)")
     ap.add_argument("--int8", action="store_true", help="BASELINE config 4: block-int8 weight matrices (36 B per 32 weights); not the headline metric")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before any OpenMP runtime loads (CPU baseline threads)
     import numpy as np
@@ -83,10 +111,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # BENCH_SHARED_GPU=1: functional test of the N > 1 path on a box with ONE GPU (all ranks on device 0, p2p staged through
-    # the host over gloo).  Never a measurement: RCCL cannot place two ranks on one device.
+    # the host over gloo by the library's hook transport).  Never a measurement: RCCL cannot place two ranks on one device.
     shared_gpu = os.environ.get("BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
@@ -94,10 +121,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")  # control plane only; the data path is RCCL inside libllamahip.so
 
     import __graft_entry__ as graft
     if rank == 0:
@@ -111,7 +135,7 @@ def main():
     if args.layers:
         kw["layers"] = args.layers
     K, W = args.steps, args.warmup
-    ctx_size = max(128, len(PROMPT) + max(K, W) + 1)
+    ctx_size = max(128, len(PROMPT) + K + W + 1)
     hp = make_hparams(**kw, ctx=ctx_size)
     d, L, V = hp.embdSize, hp.layersCount, hp.vocabSize
     PROMPT = [t % V for t in PROMPT]  # the fixed ids are 7B-vocabulary ids; debug shapes have smaller tables
@@ -287,86 +311,40 @@ def main():
                 result["prefill_13b"] = {"error": str(e)}
         parallelism = "single GPU, device-resident decode loop (hipGraph replay)"
         pods = 1
+        timed_pos0 = P0
     else:
         # ---------------- layer-sharded pipeline over `world` ranks ----------------
         R = world
         # streams in flight: a phase of K steps costs K * pods / R + (R - 1) ticks, so with pods = R and K = 16 pipeline fill + drain
         # alone cap the efficiency at K / (K + R - 1) (70 % for R = 8); 4 R streams amortise it to 4K / (4K + R - 1) (90 %).
-        # The reference's own knob for this is --pods (server.go:88-101).
+        # The reference's own knob for this is --pods (server.go:88-101).  pods = 1: one stream, sequential through the stages.
         pods = args.pods or 4 * R
-        l0, l1 = rank * L // R, (rank + 1) * L // R
-        # ONE explicit stream for everything: torch's copies and (R)CCL work order themselves against torch's CURRENT stream, so the
-        # library must enqueue on that very stream (the default stream's handle is NULL, which the C-ABI reads as "make a private
-        # stream" — a private stream would race with the p2p traffic).
-        tstream = torch.cuda.Stream(device=local_rank)
-        torch.cuda.set_stream(tstream)
-        assert tstream.cuda_stream != 0
-        prod.lib.llamago_SetStream(C.c_void_p(tstream.cuda_stream))
+        from llama_go_amd.mlapi import Pipeline, comm_unique_id
+        from llama_go_amd.pipeline import gloo_comm_hooks, layer_range
+        l0, l1 = layer_range(rank, R, L)
         model = prod.NewSyntheticModel(hp, SEED, l0, l1)
+        if args.int8:
+            model.QuantizeQ8()
         F = model.ffSize
-        ctxs = [model.NewContext(ctx_size, 1) for _ in range(pods)]
-        dev = torch.device("cuda", local_rank)
-        first_stage, last_stage = rank == 0, rank == R - 1
-        xin = [torch.empty(P0 * d, dtype=torch.float32, device=dev) for _ in range(pods)]
-        xout = [torch.empty(P0 * d, dtype=torch.float32, device=dev) for _ in range(pods)]
-        tok_in = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(pods)]     # rank 0: id received from the last rank
-        tok_first = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(pods)]  # rank 0: id produced by the prefill
-        tok_out = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(pods)]    # last rank: argmax of this step
-        produced_dev = torch.zeros((pods, K), dtype=torch.int32, device=dev)
-        prompt_arr = (C.c_uint32 * P0)(*PROMPT)
-
-        def rows_past(step, phase):
-            if phase == "warm":
-                return (P0, 0) if step == 0 else (1, P0 + step - 1)
-            return 1, P0 + step
-
-        def stage_cb(p, step, phase):
-            n, past = rows_past(step, phase)
-            tokens_host, tokens_dev = None, None
-            if first_stage:
-                if n > 1:
-                    tokens_host = prompt_arr
-                else:
-                    src = tok_first[p] if (phase == "timed" and step == 0) else tok_in[p]
-                    tokens_dev = C.c_void_p(src.data_ptr())
-            rc = prod.lib.llamago_Stage(ctxs[p].h, tokens_host, tokens_dev,
-                                        None if first_stage else C.c_void_p(xin[p].data_ptr()),
-                                        None if last_stage else C.c_void_p(xout[p].data_ptr()),
-                                        n, past, None, C.c_void_p(tok_out[p].data_ptr()) if last_stage else None)
-            if rc:
-                raise RuntimeError(prod.last_error())
-            if last_stage and phase == "timed":
-                produced_dev[p, step: step + 1].copy_(tok_out[p], non_blocking=True)
-
-        def send_buf(p, step, phase):
-            n, _ = rows_past(step, phase)
-            return tok_out[p] if last_stage else xout[p][: n * d]
-
-        def recv_buf(p, step, phase):
-            n, _ = rows_past(step, phase)
-            return tok_in[p] if first_stage else xin[p][: n * d]
-
-        def on_recv(p, step, phase):
-            if first_stage and phase == "warm" and step == 0:
-                tok_first[p].copy_(tok_in[p])
-
-        from llama_go_amd.pipeline import PipelineRunner
-        pdist = dist
+        comm_id, hooks = None, None
         if shared_gpu:
-            from llama_go_amd.pipeline import HostStagedDist
-            pdist = HostStagedDist(dist)
-        runner = PipelineRunner(rank, R, pods, pdist, stage_cb, send_buf, recv_buf, on_recv)
-        runner.run_phase(1 + W, "warm")   # prefill + W warm-up decode steps per stream; the pipeline drains at the end
+            hooks = gloo_comm_hooks(dist)
+        else:
+            obj = [comm_unique_id(prod) if rank == 0 else None]   # ncclGetUniqueId on rank 0; any channel may carry the 128 bytes
+            dist.broadcast_object_list(obj, src=0)
+            comm_id = obj[0]
+        pl = Pipeline(model, ctx_size, pods, rank, R, comm_id=comm_id, hooks=hooks)   # ncclCommInitRank + per-stream stages, one HIP stream
+        pl.run([PROMPT] * pods, W)   # prefill + W warm-up decode steps per stream (lh_pipeline_run); the pipeline drains at the end
         sync_all()
         t0 = time.perf_counter()
-        runner.run_phase(K, "timed")      # K decode steps per stream from (first token, P0): includes pipeline fill + drain
+        pl.run(None, K)              # K decode steps per stream, continuing each stream: includes pipeline fill + drain
         sync_all()
         dt = time.perf_counter() - t0
         tokens_total = K * pods
-        tdt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else dev)
+        tdt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
-        prof = profile_decode(ctxs[0], 1, P0, repeats=2)
+        prof = pl.profile_decode(1, P0, repeats=2)
         b2b = {k["name"][:-4]: k for k in prof if k["name"].endswith("/b2b")}
         prof = [k for k in prof if not k["name"].endswith("/b2b")]
         dom = max(prof, key=lambda k: k["avg_us"] * k["launches"])
@@ -375,19 +353,21 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": dom["bytes_per_launch"],
                               "avg_us": round(dom["avg_us"], 2)}
-        if last_stage:
-            produced = produced_dev[0, :K].tolist()
-            obj = [produced]
-        else:
-            obj = [None]
-        dist.broadcast_object_list(obj, src=R - 1)
-        produced = obj[0]
-        parallelism = f"layer-shard pp{R} ({L // R} layers/rank), {pods} independent greedy streams in flight, RCCL send/recv of the residual stream"
-        for c in ctxs:
-            c.free()
+        # ids rank 0 received for stream 0: [prefill argmax, then the id produced at positions P0, P0+1, ...]
+        allt = pl.tokens(0) if rank == 0 else None
+        obj = [allt]
+        dist.broadcast_object_list(obj, src=0)
+        allt = obj[0]
+        assert len(allt) == 1 + W + K, (len(allt), W, K)
+        produced = allt[1:]          # ids produced by the decode steps at positions P0.. (the first W of them by the warm-up)
+        timed_pos0 = P0 + W
+        parallelism = (f"layer-shard pp{R} ({l1 - l0} layers on this rank), {pods} independent greedy stream{'s' if pods > 1 else ''} in flight"
+                       f"{' (single-stream latency curve)' if pods == 1 else ''}, RCCL send/recv of the residual stream issued below the C-ABI (lh_pipeline_run)"
+                       f"{'; SHARED-GPU functional mode (host-staged p2p)' if shared_gpu else ''}")
+        pl.free()
         model.free()
 
-    Tbar = P0 + (K + 1) / 2.0
+    Tbar = timed_pos0 + (K + 1) / 2.0
     wbytes, kvbytes = bytes_per_token(d, L, F, V, Tbar)
     if args.int8:  # matrices at 36/32 B per weight, norms + one embedding row stay f32
         mat = 4 * (L * (4 * d * d + 3 * d * F) + V * d)
@@ -398,7 +378,7 @@ def main():
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if not args.int8 else "f32 activations/accumulation, int8 block-quantised weights", "data": "synthetic (random-init weights, counter-based generator seed 1234; fixed 8-token prompt)",
-        "config": {"workload": f"LLaMA-{args.shape} fp32 greedy decode, context {ctx_size}, positions {P0}..{P0 + K - 1}, batch 1 per stream",
+        "config": {"workload": f"LLaMA-{args.shape} fp32 greedy decode, context {ctx_size}, positions {timed_pos0}..{timed_pos0 + K - 1}, batch 1 per stream",
                    "layers": L, "embd": d, "ff": F, "vocab": V, "streams": pods, "parallelism": parallelism},
         "roofline_token": {
             "bytes_per_token": int(wbytes + kvbytes), "weights_bytes": int(wbytes),

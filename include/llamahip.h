@@ -134,8 +134,6 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
  * argmax to *argmax_dev (both device pointers, optional).  Asynchronous on the context's stream. */
 int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_dev, const float* x_in_dev, float* x_out_dev,
                    uint32_t n, uint32_t past, float* logits_dev, uint32_t* argmax_dev);
-/* Time each kernel class of one decode step with HIP events on the context's stream (eager launches,
- * same kernels as the replayed graph).  Writes up to cap entries; returns the number of classes. */
 /* ---- sampler on the device --------------------------------------------------------------
  * SampleTopPTopK (llama.go:455-707): repeat penalty over the whole lastNTokens ring (llama.go:497-525), sort + topK
  * (llama.go:548-567), softmax with f64 exp (llama.go:581-609), topP cut (llama.go:623-639), then the reference's
@@ -162,6 +160,65 @@ int lh_sample_top_p_top_k(lh_ctx* ctx, const float* logits, uint32_t n_logits, c
 int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t ring_size,
                            const lh_sample_params* sp, uint32_t* out_tokens);
 
+/* ---- multi-GPU: layer shard over RCCL point-to-point ------------------------------------------------
+ * The reference's only parallel dimension is request-level "pods" (pkg/server/server.go:84-106: Engine() starts up to
+ * MaxPods concurrent Do() goroutines; server.go:151: each with its own llama.Context over the shared Model).  Layers
+ * shard in contiguous blocks over one process per GPU; the fp32 residual stream [n x embd] hops rank r -> r+1 and the
+ * sampled token id returns from the last rank to rank 0, both as RCCL send/recv over xGMI, issued HERE (on the context's
+ * stream, grouped) so that a Go host needs no collective library of its own: it only moves the 128-byte unique id from
+ * rank 0 to the other ranks over whatever channel it already has (a file, a socket, its job queue).
+ * librccl.so.1 is loaded on first use (dlopen), so single-GPU hosts never need it. */
+#define LH_COMM_ID_BYTES 128
+typedef struct lh_comm lh_comm;
+int lh_comm_unique_id(lh_ctx* ctx, uint8_t id[LH_COMM_ID_BYTES]);       /* ncclGetUniqueId: call on rank 0, distribute */
+int lh_comm_init(lh_ctx* ctx, int rank, int world, const uint8_t id[LH_COMM_ID_BYTES], lh_comm** out); /* ncclCommInitRank on ctx's device */
+/* Alternative transport for hosts without RCCL peers (tests with several ranks on ONE GPU, which RCCL refuses; TCP):
+ * the library stages the messages through host memory and hands both directions of a tick to ONE call, which must
+ * post the send and the receive together (a ring of blocking sends would wait on itself).  NULL buffers = no message. */
+typedef struct lh_comm_hooks {
+    void* user;
+    int (*exchange)(void* user, const void* send_host, uint64_t send_bytes, int send_peer, void* recv_host, uint64_t recv_bytes, int recv_peer);
+} lh_comm_hooks;
+int lh_comm_init_hooks(lh_ctx* ctx, int rank, int world, const lh_comm_hooks* hooks, lh_comm** out);
+void lh_comm_destroy(lh_comm* comm);
+int lh_comm_rank(const lh_comm* comm);
+int lh_comm_world(const lh_comm* comm);
+/* One grouped send + receive of device buffers, asynchronous on the context's stream (ncclGroupStart / ncclSend /
+ * ncclRecv / ncclGroupEnd).  Either side may be absent (NULL / 0 bytes). */
+int lh_comm_exchange(lh_comm* comm, const void* send_dev, uint64_t send_bytes, int send_peer, void* recv_dev, uint64_t recv_bytes, int recv_peer);
+
+/* Pods as pipeline streams: the schedule that keeps every rank busy lives here, not in the host.
+ * A "unit" is one Eval per stream (the prompt, or one decode step).  With Q = max(pods, world), rank r evaluates stream
+ * p at unit u in tick t = u*Q + p + r; after every tick all ranks exchange once (ring shift): rank r sends what it just
+ * produced to r+1 (the last rank sends the token id to rank 0) and receives what r-1 produced in the same tick.
+ * pods >= world fills the pipeline (aggregate throughput); pods = 1 is the single greedy stream walking through the
+ * stages (latency curve).  lh_pipeline_schedule is the pure function (no GPU): ticks as seen by `rank`, -1 = idle. */
+typedef struct lh_tick { uint32_t t; int32_t stream, unit, recv_stream, recv_unit; } lh_tick;
+int lh_pipeline_schedule(uint32_t rank, uint32_t world, uint32_t pods, uint32_t units, lh_tick* out, uint32_t cap); /* returns the tick count */
+/* The scheduler loop itself with caller-supplied stage / exchange actions (what lh_pipeline_run executes with
+ * lh_llama_stage and lh_comm_exchange plugged in): lets a host, or a CPU test over another transport, drive it. */
+typedef struct lh_pipeline_hooks {
+    void* user;
+    int (*stage)(void* user, uint32_t stream, uint32_t unit);
+    int (*exchange)(void* user, int32_t send_stream, int32_t send_unit, int32_t recv_stream, int32_t recv_unit);
+} lh_pipeline_hooks;
+int lh_pipeline_run_hooks(uint32_t rank, uint32_t world, uint32_t pods, uint32_t units, const lh_pipeline_hooks* hooks);
+
+typedef struct lh_pipeline lh_pipeline;
+/* pods[i]: this rank's stage of stream i (lh_llama_create with the rank's [layer0, layer1) and the stream's own KV
+ * cache), all on `ctx` (one stream orders compute and p2p).  comm may be NULL when the model is not sharded. */
+int lh_pipeline_create(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, lh_pipeline** out);
+void lh_pipeline_destroy(lh_pipeline* pl);
+/* server.Do for every stream at once, greedy: if n_prompt != NULL, unit 0 evaluates prompts[i][0..n_prompt[i]) at
+ * position 0 (prompts is read on rank 0 only; n_prompt on every rank); then `steps` decode units follow, each feeding
+ * the argmax of the previous unit.  State (position, next token) persists across calls, so run(prompts, n, W) followed
+ * by run(NULL, NULL, K) continues the same streams.  Returns after the rank's stream has drained. */
+int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps);
+/* Token ids this rank knows for a stream since creation (rank 0: received from the last rank; last rank: produced). */
+int lh_pipeline_tokens(lh_pipeline* pl, uint32_t pod, uint32_t* out, uint32_t cap);
+
+/* Time each kernel class of one decode step with HIP events on the context's stream (eager launches,
+ * same kernels as the replayed graph).  Writes up to cap entries; returns the number of classes. */
 typedef struct lh_kernel_time { char name[48]; uint32_t launches; float total_ms; uint64_t bytes_per_launch; } lh_kernel_time;
 int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap);
 

@@ -67,12 +67,14 @@ int ensure_staging(lh_ctx* ctx, uint64_t bytes) {
 
 // RoPE table, computed on the host in f64 with the reference's expressions (ml.go:2307-2310):
 //   theta = pow(10000, -i0/dims);  cos(p*theta), sin(p*theta)     for i0 = 0, 2, .., dims-2.
-int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims) {
+int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims, const double2** table) {
     DeviceState* ds = ctx->ds;
+    if (!dims || dims % 2) LH_FAIL(ctx, LH_ESHAPE, "rope: rotation width %u must be even and non-zero", dims);
     std::lock_guard<std::mutex> lk(ds->mu);
-    if (ds->rope_table && ds->rope_dims == dims && ds->rope_positions >= positions) return 0;
+    DeviceState::RopeTable& rt = ds->rope[dims];
+    if (rt.dev && rt.positions >= positions) { *table = rt.dev; return 0; }
     uint32_t npos = positions < 256 ? 256 : positions;
-    if (ds->rope_dims == dims && ds->rope_positions * 2 > npos) npos = ds->rope_positions * 2;
+    if (rt.positions * 2 > npos) npos = rt.positions * 2;
     const uint32_t half = dims / 2;
     std::vector<double2> h((size_t)npos * half);
     for (uint32_t i = 0; i < half; ++i) {
@@ -86,10 +88,9 @@ int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims) {
     double2* dev = nullptr;
     LH_HIP(ctx, hipMalloc((void**)&dev, h.size() * sizeof(double2)));
     LH_HIP(ctx, hipMemcpy(dev, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice));
-    // The old table may still be referenced by captured graphs of other contexts: keep it alive (tables are small).
-    ds->rope_table = dev;
-    ds->rope_positions = npos;
-    ds->rope_dims = dims;
+    rt.dev = dev;  // the previous (smaller) table stays allocated: see DeviceState::rope
+    rt.positions = npos;
+    *table = dev;
     return 0;
 }
 

@@ -52,10 +52,12 @@ struct DeviceState {
     std::unordered_map<lh_buf, std::unique_ptr<Buffer>> bufs;
     std::unordered_map<uint64_t, lh_buf> by_key;
     lh_buf next_id = 1;
-    // RoPE table: [positions][dims/2] of (cos, sin) in f64, built on the host with libm exactly as the
-    // reference computes them per element (ml.go:2307-2310); grown on demand.
-    double2* rope_table = nullptr;
-    uint32_t rope_positions = 0, rope_dims = 0;
+    // RoPE tables, one per rotation width `dims`: [positions][dims/2] of (cos, sin) in f64, built on the host with libm
+    // exactly as the reference computes them per element (ml.go:2307-2310).  A table that has to grow is REPLACED by a larger
+    // one and the old allocation is kept alive (captured graphs and plans of other contexts hold its address; tables are
+    // small), so a pointer handed out by ensure_rope_table stays valid for the positions it was asked for.
+    struct RopeTable { double2* dev = nullptr; uint32_t positions = 0; };
+    std::unordered_map<uint32_t, RopeTable> rope;
 };
 DeviceState* device_state(int device);
 Buffer* find_buffer(DeviceState* ds, lh_buf id);
@@ -90,6 +92,6 @@ struct lh_ctx {
 namespace lh {
 int ensure_arena(lh_ctx* ctx, uint64_t bytes);
 int ensure_staging(lh_ctx* ctx, uint64_t bytes);
-int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims);
+int ensure_rope_table(lh_ctx* ctx, uint32_t positions, uint32_t dims, const double2** table);
 inline int select_device(lh_ctx* ctx) { return hipSetDevice(ctx->device) == hipSuccess ? 0 : LH_EHIP; }
 }  // namespace lh

@@ -347,10 +347,11 @@ static int run_node(lh_ctx* ctx, const lh_tensor* T, const std::vector<float*>& 
             const uint32_t past = (uint32_t)b.host[0], dims = (uint32_t)b.host[1], mode = (uint32_t)b.host[2];
             if (dims == 0 || dims % 2 || dims > t.ne[0]) LH_FAIL(ctx, LH_ESHAPE, "Rope: dims %u not supported", dims);
             const uint32_t maxpos = (mode == 0 ? past : 0) + t.ne[2];
-            int rc = ensure_rope_table(ctx, maxpos + 1, dims);
+            const double2* table = nullptr;
+            int rc = ensure_rope_table(ctx, maxpos + 1, dims, &table);
             if (rc) return rc;
             const uint64_t total = (uint64_t)t.ne[3] * t.ne[2] * t.ne[1] * (dims / 2);
-            hipLaunchKernelGGL(g_rope, grid_for(total), dim3(256), 0, st, V(i), (const double2*)ctx->ds->rope_table, past, dims, mode);
+            hipLaunchKernelGGL(g_rope, grid_for(total), dim3(256), 0, st, V(i), table, past, dims, mode);
             break;
         }
         case OP_MUL_MAT: {

@@ -585,10 +585,13 @@ __global__ void k_set_step(StepParams* sp, uint32_t token, uint32_t past, uint32
 }
 
 // GetRows ml.go:1711-1750 — embedding lookup; token ids from the device step parameters (decode) or a device array.
+// Host-provided ids are validated before launch; an id that arrives through device memory (argmax of the previous step,
+// or received from the last pipeline rank) is clamped so that a corrupted value can never gather outside the table.
 __global__ __launch_bounds__(256) void k_embed(const float* __restrict__ emb, const uint32_t* __restrict__ tokens, const StepParams* sp,
-                                                float* __restrict__ x, uint32_t d) {
+                                                float* __restrict__ x, uint32_t d, uint32_t vocab) {
     const uint32_t row = blockIdx.x;
-    const uint32_t tok = tokens ? tokens[row] : sp->token;
+    uint32_t tok = tokens ? tokens[row] : sp->token;
+    tok = tok < vocab ? tok : vocab - 1;
     const f4* src = (const f4*)(emb + (size_t)tok * d);
     f4* dst = (f4*)(x + (size_t)row * d);
     for (uint32_t i = threadIdx.x; i < d / 4; i += 256) dst[i] = src[i];

@@ -45,6 +45,7 @@ struct Plan {
     float *scores = nullptr, *vt = nullptr;   // large-N prefill attention: S[H][N][Tp], V^T[H][hd][Tp]
     uint64_t scores_cap = 0, vt_cap = 0;
     uint32_t* tokens_dev = nullptr;
+    const double2* rope = nullptr;            // this plan's RoPE table (rotation width hd, >= ctx positions), resolved at plan_create
     // decode graph state
     StepParams* sp_dev = nullptr;
     StepParams* sp_host = nullptr;   // pinned

@@ -507,7 +507,7 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     p->md = md;
     const char* env = getenv("LLAMAHIP_NO_GRAPH");
     p->use_graph = !(env && env[0] == '1');
-    int rc = ensure_rope_table(ctx, md.ctx, md.hd);
+    int rc = ensure_rope_table(ctx, md.ctx, md.hd, &p->rope);
     if (rc) { delete p; return rc; }
     hipError_t e = hipMalloc((void**)&p->sp_dev, sizeof(StepParams) * SP_SLOTS);
     if (e == hipSuccess) e = hipHostMalloc((void**)&p->sp_host, sizeof(StepParams) * SP_SLOTS, hipHostMallocDefault);
@@ -569,14 +569,14 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
                           const uint32_t* tokens_dev = nullptr, uint32_t logits_row = 0) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
-    const double2* rope = ctx->ds->rope_table;
+    const double2* rope = p->rope;
     int rc;
     const float* x = p->xa;
     if (m.first_stage()) {
         if (!g_prepare_only && !g_only) {
             ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
             TraceScope ts_(ctx->stream, "embed1");
-            hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d);
+            hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d, m.V);
             LH_HIP(ctx, hipGetLastError());
         }
     } else {
@@ -710,6 +710,9 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     if (n == 0) LH_FAIL(ctx, LH_EINVAL, "Eval: empty token batch");
     if ((uint64_t)past + n > m.ctx) LH_FAIL(ctx, LH_EINVAL, "Eval: past %u + n %u exceeds the context window of %u", past, n, m.ctx);
     if (m.first_stage() && !tokens_host) LH_FAIL(ctx, LH_EINVAL, "Eval: first stage needs token ids");
+    if (m.first_stage())  // Go panics on tokEmbeddings.Data[id*NE[0]:] past the table (ml.go:1748); the GPU must never gather out of range
+        for (uint32_t i = 0; i < n; ++i)
+            if (tokens_host[i] >= m.V) LH_FAIL(ctx, LH_EINVAL, "Eval: token id %u at index %u outside the vocabulary of %u", tokens_host[i], i, m.V);
     if (!m.first_stage() && !x_in_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: later stage needs the residual stream");
     if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: non-final stage needs an output buffer");
     int rc;
@@ -734,7 +737,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         return 0;
     }
     // ---- prefill, N > 1 rows
-    const double2* rope = ctx->ds->rope_table;
+    const double2* rope = p->rope;
     const float* x = p->xa;
     if (m.first_stage()) {
         if ((rc = ensure_staging(ctx, (uint64_t)n * 4))) return rc;
@@ -742,7 +745,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         memcpy(ctx->staging, tokens_host, (size_t)n * 4);
         LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         TraceScope ts_(ctx->stream, "embedN");
-        hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d);
+        hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
         LH_HIP(ctx, hipGetLastError());
     } else {
         x = x_in_dev;
@@ -939,6 +942,7 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
     LH_HIP(ctx, hipSetDevice(ctx->device));
     if (!md.first_stage() || !md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_greedy needs a whole-model plan");
     if ((uint64_t)past + n_steps > md.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: past %u + %u steps exceed the context window of %u", past, n_steps, md.ctx);
+    if (first_token >= md.V) LH_FAIL(ctx, LH_EINVAL, "decode: token id %u outside the vocabulary of %u", first_token, md.V);
     int rc;
     if ((rc = ensure_out_tokens(p, n_steps))) return rc;
     if (p->use_graph && (rc = ensure_decode_graph(p, true))) return rc;
@@ -1025,6 +1029,7 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
         if ((uint64_t)past + 1 > md.ctx) LH_FAIL(ctx, LH_EINVAL, "stage: position %u outside the context window", past);
         const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if (md.first_stage() && !tokens && !tokens_dev) LH_FAIL(ctx, LH_EINVAL, "stage: first stage needs a token id (host or device)");
+        if (md.first_stage() && tokens && tokens[0] >= md.V) LH_FAIL(ctx, LH_EINVAL, "stage: token id %u outside the vocabulary of %u", tokens[0], md.V);
         if ((rc = upload_step_params(p, slot, tokens ? tokens[0] : 0, past, 0))) return rc;
         if ((rc = enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, md.last_stage() ? argmax_dev : nullptr, tokens ? nullptr : tokens_dev))) return rc;
     } else {

@@ -724,9 +724,7 @@ int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prom
 }
 
 // ---- product extensions: device-resident decode loop, kernel timing, pipeline stage -----------------------
-static lh_llama* resident(llama_context* c) {
-    if (c->resident) return c->resident;
-    llama_model* m = c->model;
+static lh_llama* make_stage(llama_model* m, lh_ctx* hip, lh_buf k_cache, lh_buf v_cache, uint32_t ctxSize) {
     std::vector<lh_llama_layer> ls(m->hp.layersCount);
     for (uint32_t i = m->layer0; i < m->layer1; i++) {
         llama_layer& l = m->layers[i];
@@ -734,15 +732,20 @@ static lh_llama* resident(llama_context* c) {
     }
     lh_llama_desc d;
     memset(&d, 0, sizeof d);
-    d.vocab = m->hp.vocabSize; d.embd = m->hp.embdSize; d.heads = m->hp.headsCount; d.layers = m->hp.layersCount; d.ff = m->ffSize; d.ctx = c->ctxSize;
+    d.vocab = m->hp.vocabSize; d.embd = m->hp.embdSize; d.heads = m->hp.headsCount; d.layers = m->hp.layersCount; d.ff = m->ffSize; d.ctx = ctxSize;
     d.layer0 = m->layer0; d.layer1 = m->layer1;
     d.tok_embeddings = m->tokEmbeddings ? m->tokEmbeddings->buf : 0;
     d.norm = m->norm ? m->norm->buf : 0;
     d.output = m->output ? m->output->buf : 0;
     d.layer = ls.data();
-    d.k_cache = c->K->buf; d.v_cache = c->V->buf;
+    d.k_cache = k_cache; d.v_cache = v_cache;
     d.weight_dtype = m->wtype;
-    if (lh_llama_create(c->mlctx->hip, &d, &c->resident)) { g_err = lh_last_error(c->mlctx->hip); return nullptr; }
+    lh_llama* out = nullptr;
+    if (lh_llama_create(hip, &d, &out)) { g_err = lh_last_error(hip); return nullptr; }
+    return out;
+}
+static lh_llama* resident(llama_context* c) {
+    if (!c->resident) c->resident = make_stage(c->model, c->mlctx->hip, c->K->buf, c->V->buf, c->ctxSize);
     return c->resident;
 }
 // ---- sampler (llama.go:455-707) on the device ----------------------------------------------------------------
@@ -760,7 +763,6 @@ int llama_SampleTopPTopK(ml_context* ctx, const float* logits, uint32_t logitsCo
                          float temp, float repeatPenalty, uint64_t seed, uint64_t draw, uint32_t* token) {
     return llamago_SampleDebug(ctx, logits, logitsCount, lastNTokens, lastNTokensSize, topK, topP, temp, repeatPenalty, seed, draw, token, nullptr, nullptr, nullptr);
 }
-static lh_llama* resident(llama_context* c);
 int llama_SampleDecode(llama_context* c, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t topK, float topP, float temp,
                        float repeatPenalty, uint64_t seed, uint32_t* out_tokens) {  // server.go:127-217, resident on the device
     if (!c || c->model != m) { g_err = "llama_SampleDecode: context does not belong to this model"; return 1; }
@@ -792,6 +794,80 @@ int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_d
         return halt_rc(lh_last_error(c->mlctx->hip));
     return 0;
 }
+// ---- pods as pipeline streams over a layer-sharded model (server.go:84-106, 151) ----------------------
+// One ml.Context (= one HIP stream) per rank carries every pod's stage and the RCCL p2p; each pod owns its KV cache like a
+// llama.Context does (llama.go:91-98).  All scheduling happens below the C-ABI (lh_pipeline_run).
+struct llama_pipeline {
+    ml_context* mlctx = nullptr;
+    llama_model* model = nullptr;
+    lh_comm* comm = nullptr;
+    lh_pipeline* pl = nullptr;
+    std::vector<ml_tensor*> K, V;
+    std::vector<lh_llama*> pods;
+};
+int llamago_CommUniqueId(uint8_t* id) {
+    lh_ctx* h = model_ctx();
+    if (!h) return 1;
+    if (lh_comm_unique_id(h, id)) return halt_rc(lh_last_error(h));
+    return 0;
+}
+void llamago_FreePipeline(llama_pipeline* p) {
+    if (!p) return;
+    if (p->pl) lh_pipeline_destroy(p->pl);
+    for (lh_llama* m : p->pods) lh_llama_destroy(m);
+    if (p->comm) lh_comm_destroy(p->comm);
+    if (p->mlctx) lh_ctx_sync(p->mlctx->hip);
+    for (ml_tensor* t : p->K) free_tensor(t);
+    for (ml_tensor* t : p->V) free_tensor(t);
+    ml_ReleaseContext(p->mlctx);
+    delete p;
+}
+// id: the 128-byte RCCL unique id from rank 0 (llamago_CommUniqueId), or NULL with hooks (host-staged transport), or both NULL
+// for an unsharded model (world must be 1).
+llama_pipeline* llamago_NewPipeline(llama_model* m, uint32_t ctxSize, uint32_t pods, int rank, int world, const uint8_t* id, const lh_comm_hooks* hooks) {
+    g_err.clear();
+    if (!m || !pods || world < 1 || rank < 0 || rank >= world) return (llama_pipeline*)halt("llamago_NewPipeline: bad arguments");
+    const uint64_t nlayers = m->layer1 - m->layer0, size = (uint64_t)m->hp.embdSize * nlayers * ctxSize;
+    if (size > 0xFFFFFFFFull) return (llama_pipeline*)halt("[HALT] KV cache exceeds uint32 element count (ml.Tensor.NE is uint32)");
+    llama_pipeline* p = new llama_pipeline();
+    p->model = m;
+    p->mlctx = ml_NewContext(1, 0, 0);
+    if (!p->mlctx) { delete p; return nullptr; }
+    lh_ctx* hip = p->mlctx->hip;
+    int rc = 0;
+    if (id) rc = lh_comm_init(hip, rank, world, id, &p->comm);
+    else if (hooks) rc = lh_comm_init_hooks(hip, rank, world, hooks, &p->comm);
+    else if (world != 1) { llamago_FreePipeline(p); return (llama_pipeline*)halt("llamago_NewPipeline: a sharded model needs a communicator id or transport hooks"); }
+    if (rc) { g_err = lh_last_error(hip); llamago_FreePipeline(p); return nullptr; }
+    for (uint32_t i = 0; i < pods; i++) {
+        ml_tensor* k = new_weight(1, (uint32_t)size, 1);
+        ml_tensor* v = new_weight(1, (uint32_t)size, 1);
+        if (k) p->K.push_back(k);
+        if (v) p->V.push_back(v);
+        if (!k || !v) { llamago_FreePipeline(p); return nullptr; }
+        lh_llama* st = make_stage(m, hip, k->buf, v->buf, ctxSize);
+        if (!st) { llamago_FreePipeline(p); return nullptr; }
+        p->pods.push_back(st);
+    }
+    if (lh_pipeline_create(hip, p->comm, p->pods.data(), pods, &p->pl)) { g_err = lh_last_error(hip); llamago_FreePipeline(p); return nullptr; }
+    return p;
+}
+int llamago_PipelineRun(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps) {
+    if (lh_pipeline_run(p->pl, prompts, n_prompt, steps)) return halt_rc(lh_last_error(p->mlctx->hip));
+    return 0;
+}
+int llamago_PipelineTokens(llama_pipeline* p, uint32_t pod, uint32_t* out, uint32_t cap) {
+    const int n = lh_pipeline_tokens(p->pl, pod, out, cap);
+    if (n < 0) g_err = lh_last_error(p->mlctx->hip);
+    return n;
+}
+int llamago_PipelineProfileDecode(llama_pipeline* p, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap) {
+    const int n = lh_llama_profile_decode(p->pods[0], token, past, repeats, out, cap);
+    if (n < 0) g_err = lh_last_error(p->mlctx->hip);
+    return n;
+}
+int llamago_PipelineSync(llama_pipeline* p) { return lh_ctx_sync(p->mlctx->hip) ? halt_rc(lh_last_error(p->mlctx->hip)) : 0; }
+
 // Block-int8 (format in csrc/kernels_q8.h): quantise every weight MATRIX of the model in HBM
 // (norm vectors and the embedding table, which is only gathered from, stay f32) and release the f32 copies.
 int llamago_QuantizeModelQ8(llama_model* m) {

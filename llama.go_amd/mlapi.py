@@ -339,7 +339,79 @@ def _bind_extensions(ml):
     L.llamago_LastGraphFused.argtypes = [VP]
     L.llamago_GraphComputeNoFusion.restype = C.c_int
     L.llamago_GraphComputeNoFusion.argtypes = [VP, VP]
+    L.llamago_CommUniqueId.restype = C.c_int
+    L.llamago_CommUniqueId.argtypes = [C.POINTER(C.c_uint8)]
+    L.llamago_NewPipeline.restype = VP
+    L.llamago_NewPipeline.argtypes = [VP, c_u32, c_u32, C.c_int, C.c_int, C.POINTER(C.c_uint8), VP]
+    L.llamago_FreePipeline.restype = None
+    L.llamago_FreePipeline.argtypes = [VP]
+    L.llamago_PipelineRun.restype = C.c_int
+    L.llamago_PipelineRun.argtypes = [VP, C.POINTER(c_u32p), c_u32p, c_u32]
+    L.llamago_PipelineTokens.restype = C.c_int
+    L.llamago_PipelineTokens.argtypes = [VP, c_u32, c_u32p, c_u32]
+    L.llamago_PipelineProfileDecode.restype = C.c_int
+    L.llamago_PipelineProfileDecode.argtypes = [VP, c_u32, c_u32, c_u32, C.POINTER(KernelTime), c_u32]
+    L.llamago_PipelineSync.restype = C.c_int
+    L.llamago_PipelineSync.argtypes = [VP]
     ml.has_extensions = True
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id(ml):
+    """lh_comm_unique_id on this process's device: 128 bytes rank 0 hands to every other rank (any channel)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    if ml.lib.llamago_CommUniqueId(buf):
+        raise MLError(f"llamago_CommUniqueId: {ml.last_error()}")
+    return bytes(buf)
+
+
+class Pipeline:
+    """Pods as pipeline streams over a layer-sharded model (server.go:84-106, 151): this rank's stages of `pods` independent
+    greedy streams, scheduled below the C-ABI (lh_pipeline_run) with RCCL send/recv of the residual stream.
+    comm_id: bytes from comm_unique_id (RCCL), or None with `hooks` (an lh_comm_hooks ctypes struct: host-staged
+    transport), or both None for world == 1."""
+
+    def __init__(self, model, ctxSize, pods, rank=0, world=1, comm_id=None, hooks=None):
+        self.model, self.ml, self.pods, self.rank, self.world = model, model.ml, pods, rank, world
+        idbuf = (C.c_uint8 * COMM_ID_BYTES)(*comm_id) if comm_id is not None else None
+        self._hooks = hooks  # keep the callbacks alive
+        h = self.ml.lib.llamago_NewPipeline(model.h, ctxSize, pods, rank, world, idbuf, C.byref(hooks) if hooks is not None else None)
+        self.h = self.ml._chk(h, "llamago_NewPipeline")
+
+    def run(self, prompts=None, steps=0):
+        """prompts: list of per-stream token lists (every rank passes them: the lengths shape the messages) or None to continue."""
+        if prompts is not None:
+            assert len(prompts) == self.pods
+            arrs = [(c_u32 * len(p))(*[int(t) for t in p]) for p in prompts]
+            pp = (c_u32p * self.pods)(*[C.cast(a, c_u32p) for a in arrs])
+            nn = (c_u32 * self.pods)(*[len(p) for p in prompts])
+            rc = self.ml.lib.llamago_PipelineRun(self.h, pp, nn, steps)
+        else:
+            rc = self.ml.lib.llamago_PipelineRun(self.h, None, None, steps)
+        if rc:
+            raise MLError(f"llamago_PipelineRun: {self.ml.last_error()}")
+
+    def tokens(self, pod):
+        cap = 1 << 16
+        out = (c_u32 * cap)()
+        n = self.ml.lib.llamago_PipelineTokens(self.h, pod, out, cap)
+        if n < 0:
+            raise MLError(f"llamago_PipelineTokens: {self.ml.last_error()}")
+        return list(out[:n])
+
+    def profile_decode(self, token, past, repeats=2):
+        arr = (KernelTime * 32)()
+        n = self.ml.lib.llamago_PipelineProfileDecode(self.h, token, past, repeats, arr, 32)
+        if n < 0:
+            raise MLError(f"llamago_PipelineProfileDecode: {self.ml.last_error()}")
+        return _kernel_times(arr, n)
+
+    def free(self):
+        if self.h:
+            self.ml.lib.llamago_FreePipeline(self.h)
+            self.h = None
 
 
 def decode_greedy_resident(ctx, first_token, past, n_steps, want_logits=False):
@@ -359,6 +431,10 @@ def profile_decode(ctx, token, past, repeats=3):
     n = ml.lib.llamago_ProfileDecode(ctx.h, token, past, repeats, arr, 32)
     if n < 0:
         raise MLError(f"llamago_ProfileDecode: {ml.last_error()}")
+    return _kernel_times(arr, n)
+
+
+def _kernel_times(arr, n):
     res = []
     for i in range(n):
         k = arr[i]

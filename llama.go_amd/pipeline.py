@@ -1,29 +1,37 @@
-"""Layer-sharded pipeline driver: one process per GPU, contiguous blocks of layers per rank, the fp32
-residual stream [n x embd] hops rank r -> r+1 over RCCL point-to-point (xGMI), the sampled token id returns from the
-last rank to rank 0.  No all-reduce: a pure layer shard has exactly one exchange per stage boundary.
+"""Layer-sharded pipeline — thin Python side.
 
-The reference's only data-parallel dimension is request-level "pods" (pkg/server/server.go:88-101: up to MaxPods
-concurrent Do() goroutines, each with its own llama.Context over the shared Model).  Pods are what fills a pipeline:
-with P >= R independent greedy streams in flight every rank is busy every tick.
+The schedule and its driver live BELOW the C-ABI (csrc/comm.hip: lh_pipeline_schedule / lh_pipeline_run_hooks /
+lh_pipeline_run, RCCL send/recv in lh_comm_exchange), so that the Go host of the reference can run a layer-sharded model
+through the shim (pkg/server/server.go:84-106 Engine + :151 one llama.Context per pod).  What is left here:
 
-Schedule ("tick" = one stage evaluation per rank):
-    rank r evaluates stream p = (t - r) mod P at its step s = (t - r) div P           for 0 <= t - r < P * S
-after every tick all ranks exchange in ONE grouped p2p batch (ring shift): rank r sends what it just produced to r+1
-(the last rank sends the token id to rank 0) and receives what r-1 produced in the same tick.  Grouping the send and
-the receive removes the circular wait a ring of blocking sends would have (RCCL send may block until the matching
-receive is posted).  With P == R the token of stream p / step s reaches rank 0 exactly one tick before it is needed.
+  schedule(...)        ctypes view of lh_pipeline_schedule (the pure function; no GPU needed)
+  run_hooks(...)       lh_pipeline_run_hooks with Python stage/exchange callbacks: the C scheduler loop over any transport
+                       (tests/test_pipeline_gloo.py drives it over gloo on CPU)
+  layer_range(...)     contiguous block of layers per rank
+  gloo_comm_hooks(...) an lh_comm_hooks transport over torch.distributed(gloo) host buffers, for FUNCTIONAL runs of the
+                       real stages with several ranks on one GPU (RCCL refuses two ranks on one device); never a measurement.
 
-This module is transport-agnostic: `PipelineRunner` takes the stage function and tensors; bench.py binds it to
-lh_llama_stage + torch.distributed(nccl == RCCL); tests/test_pipeline_gloo.py runs the same code over gloo on CPU.
+Schedule: with Q = max(pods, world), rank r evaluates stream p at unit u in tick t = u*Q + p + r; after every tick all ranks
+exchange once in ONE grouped p2p (ring shift): rank r sends what it just produced to r+1 (the last rank sends the token id to
+rank 0) and receives what r-1 produced in the same tick.  pods >= world keeps every rank busy every tick (the reference's
+request-level parallelism fills the pipeline); pods = 1 is the single greedy stream walking through the stages.
 """
+import ctypes as C
 from dataclasses import dataclass
-from typing import Callable, List, Optional
+from typing import Callable, List
+
+from . import LIBLLAMAHIP
+
+
+class _Tick(C.Structure):
+    """lh_tick (include/llamahip.h)."""
+    _fields_ = [("t", C.c_uint32), ("stream", C.c_int32), ("unit", C.c_int32), ("recv_stream", C.c_int32), ("recv_unit", C.c_int32)]
 
 
 @dataclass
 class Tick:
     t: int
-    active: bool          # this rank evaluates a stage in this tick
+    active: bool               # this rank evaluates a stage in this tick
     stream: int = -1
     step: int = -1
     recv_after: bool = False   # the previous rank was active in this tick -> a message arrives after it
@@ -31,59 +39,78 @@ class Tick:
     recv_step: int = -1
 
 
+STAGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32)
+
+
+class _PipelineHooks(C.Structure):
+    """lh_pipeline_hooks."""
+    _fields_ = [("user", C.c_void_p), ("stage", STAGE_FN), ("exchange", EXCHANGE_FN)]
+
+
+COMM_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_int)
+
+
+class CommHooks(C.Structure):
+    """lh_comm_hooks."""
+    _fields_ = [("user", C.c_void_p), ("exchange", COMM_EXCHANGE_FN)]
+
+
+_lib = None
+
+
+def _hip():
+    """libllamahip.so (loads without a GPU; the schedule functions touch no device)."""
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(LIBLLAMAHIP, mode=C.RTLD_GLOBAL)
+        _lib.lh_pipeline_schedule.restype = C.c_int
+        _lib.lh_pipeline_schedule.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_Tick), C.c_uint32]
+        _lib.lh_pipeline_run_hooks.restype = C.c_int
+        _lib.lh_pipeline_run_hooks.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_PipelineHooks)]
+    return _lib
+
+
 def schedule(rank: int, world: int, pods: int, steps: int) -> List[Tick]:
-    """Ticks of one phase (S steps for each of P streams) as seen by `rank`."""
-    if pods < world:
-        raise ValueError(f"pods ({pods}) must be >= ranks ({world}): a stream's next token is only known after {world} ticks")
-    total = pods * steps + world - 1
-    out = []
-    prev = (rank - 1) % world
-    for t in range(total):
-        k = t - rank
-        tk = Tick(t=t, active=0 <= k < pods * steps)
-        if tk.active:
-            tk.stream, tk.step = k % pods, k // pods
-        kp = t - prev
-        if 0 <= kp < pods * steps:
-            tk.recv_after, tk.recv_stream, tk.recv_step = True, kp % pods, kp // pods
-        out.append(tk)
-    return out
+    """Ticks of one run (`steps` units for each of `pods` streams) as seen by `rank` — lh_pipeline_schedule."""
+    lib = _hip()
+    n = lib.lh_pipeline_schedule(rank, world, pods, steps, None, 0)
+    if n < 0:
+        raise ValueError(f"lh_pipeline_schedule({rank}, {world}, {pods}, {steps}) = {n}")
+    arr = (_Tick * max(n, 1))()
+    lib.lh_pipeline_schedule(rank, world, pods, steps, arr, n)
+    return [Tick(t=k.t, active=k.stream >= 0, stream=k.stream, step=k.unit, recv_after=k.recv_stream >= 0, recv_stream=k.recv_stream, recv_step=k.recv_unit)
+            for k in arr[:n]]
 
 
-class PipelineRunner:
-    """Runs phases of the schedule.  Callbacks:
-        stage(stream, step, phase)         evaluate this rank's layers for (stream, step); inputs/outputs live in the
-                                           per-stream buffers the callbacks below hand out
-        send_buf(stream, step, phase)      tensor this rank sends after evaluating (x_out, or the token id on the last rank)
-        recv_buf(stream, step, phase)      tensor that receives what the previous rank produced for (stream, step)
-        on_recv(stream, step, phase)       optional hook after a message has been posted (e.g. keep a copy)
-    `dist` is torch.distributed (or None for world == 1)."""
+def run_hooks(rank: int, world: int, pods: int, steps: int, stage: Callable[[int, int], None],
+              exchange: Callable[[int, int, int, int], None]):
+    """The C scheduler loop (lh_pipeline_run_hooks) with Python actions: stage(stream, unit) and
+    exchange(send_stream, send_unit, recv_stream, recv_unit) with -1 for an absent side."""
+    errs = []
 
-    def __init__(self, rank: int, world: int, pods: int, dist, stage: Callable, send_buf: Callable, recv_buf: Callable,
-                 on_recv: Optional[Callable] = None):
-        self.rank, self.world, self.pods, self.dist = rank, world, pods, dist
-        self.stage, self.send_buf, self.recv_buf, self.on_recv = stage, send_buf, recv_buf, on_recv
-        self.next, self.prev = (rank + 1) % world, (rank - 1) % world
+    def _stage(_u, s, u):
+        try:
+            stage(s, u)
+            return 0
+        except BaseException as e:  # an exception must not unwind through the C frames
+            errs.append(e)
+            return -1
 
-    def run_phase(self, steps: int, phase: str):
-        d = self.dist
-        for tk in schedule(self.rank, self.world, self.pods, steps):
-            if tk.active:
-                self.stage(tk.stream, tk.step, phase)
-            if self.world == 1:
-                if tk.active and self.on_recv:
-                    self.on_recv(tk.stream, tk.step, phase)
-                continue
-            ops = []
-            if tk.active:
-                ops.append(d.P2POp(d.isend, self.send_buf(tk.stream, tk.step, phase), self.next))
-            if tk.recv_after:
-                ops.append(d.P2POp(d.irecv, self.recv_buf(tk.recv_stream, tk.recv_step, phase), self.prev))
-            if ops:
-                for req in d.batch_isend_irecv(ops):
-                    req.wait()
-            if tk.recv_after and self.on_recv:
-                self.on_recv(tk.recv_stream, tk.recv_step, phase)
+    def _exchange(_u, s, u, rs, ru):
+        try:
+            exchange(s, u, rs, ru)
+            return 0
+        except BaseException as e:
+            errs.append(e)
+            return -1
+
+    hooks = _PipelineHooks(None, STAGE_FN(_stage), EXCHANGE_FN(_exchange))
+    rc = _hip().lh_pipeline_run_hooks(rank, world, pods, steps, C.byref(hooks))
+    if errs:
+        raise errs[0]
+    if rc:
+        raise RuntimeError(f"lh_pipeline_run_hooks returned {rc}")
 
 
 def layer_range(rank: int, world: int, layers: int):
@@ -91,42 +118,32 @@ def layer_range(rank: int, world: int, layers: int):
     return rank * layers // world, (rank + 1) * layers // world
 
 
-class HostStagedDist:
-    """torch.distributed look-alike for FUNCTIONAL testing of the N > 1 path when every rank shares one GPU (RCCL refuses two
-    ranks on one device): device tensors are bounced through host memory and exchanged over gloo.  Not a performance path."""
+def gloo_comm_hooks(dist):
+    """lh_comm_hooks over torch.distributed (gloo): the library stages each message through pinned host memory and calls
+    exchange() once per tick with both directions; isend + irecv are posted together, then both are waited for."""
+    import torch
 
-    class P2POp:
-        def __init__(self, op, tensor, peer):
-            self.op, self.tensor, self.peer = op, tensor, peer
+    def _exchange(_user, send_p, send_n, send_peer, recv_p, recv_n, recv_peer):
+        try:
+            reqs, keep = [], []
+            if send_p and send_n:
+                src = (C.c_uint8 * send_n).from_address(send_p)
+                t = torch.frombuffer(src, dtype=torch.uint8).clone()
+                keep.append(t)
+                reqs.append(dist.isend(t, send_peer))
+            rt = None
+            if recv_p and recv_n:
+                rt = torch.empty(recv_n, dtype=torch.uint8)
+                reqs.append(dist.irecv(rt, recv_peer))
+            for r in reqs:
+                r.wait()
+            if rt is not None:
+                C.memmove(recv_p, rt.data_ptr(), recv_n)
+            return 0
+        except BaseException as e:
+            import sys
+            print(f"gloo transport failed: {e!r}", file=sys.stderr, flush=True)
+            return -1
 
-    def __init__(self, dist):
-        self.d = dist
-        self.isend, self.irecv = "isend", "irecv"
-
-    def batch_isend_irecv(self, ops):
-        reqs, post = [], []
-        for o in ops:
-            if o.op == "isend":
-                host = o.tensor.detach().cpu()
-                post.append((None, host))  # keep the host copy alive until the send completed
-                reqs.append(self.d.isend(host, o.peer))
-            else:
-                host = o.tensor.detach().cpu()
-                reqs.append(self.d.irecv(host, o.peer))
-                post.append((o.tensor, host))
-
-        class _Done:
-            def __init__(self, reqs, post):
-                self.reqs, self.post, self.done = reqs, post, False
-
-            def wait(self):
-                if self.done:
-                    return
-                for r in self.reqs:
-                    r.wait()
-                for dev, host in self.post:
-                    if dev is not None:
-                        dev.copy_(host)
-                self.done = True
-
-        return [_Done(reqs, post)]
+    hooks = CommHooks(None, COMM_EXCHANGE_FN(_exchange))
+    return hooks

@@ -1,6 +1,9 @@
-"""-m gpu: the N > 1 layer-shard pipeline of bench.py, end to end on ONE GPU: two ranks share device 0 (p2p bounced through the
-host over gloo — RCCL cannot place two ranks on one device), each owning half of the layers, the residual stream and the sampled
-token ids hopping between them through lh_llama_stage.  The streams must reproduce exactly the token ids of the single-process run."""
+"""-m gpu: the N > 1 layer-shard pipeline, end to end on ONE GPU, scheduled below the C-ABI (lh_pipeline_run).
+ - two / three ranks share device 0 (p2p through the library's host-staged hook transport over gloo — RCCL cannot place two ranks
+   on one device), each owning a block of layers, the residual stream and the token ids hopping between them.  Every stream must
+   reproduce exactly the token ids of the single-process run, with the pipeline full (pods >= ranks) and as a single stream.
+ - the RCCL transport itself (dlopen, ncclCommInitRank, grouped ncclSend/ncclRecv on the context's stream) runs with a world of
+   one rank: the token id travels last stage -> first stage through RCCL on the one GPU a test box has."""
 import json
 import os
 import socket
@@ -41,3 +44,88 @@ def test_two_rank_pipeline_reproduces_single_process_tokens(product):
     assert two["n_gpus"] == 2 and two["config"]["streams"] == 8   # default: 4 streams per rank in flight
     assert two["tokens_stream0"] == one["tokens_stream0"], (one["tokens_stream0"], two["tokens_stream0"])
     assert len(one["tokens_stream0"]) == 6
+
+
+def _bench(args, env, nranks, launcher):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(nranks)] + args
+    else:  # bench.py spawns its own ranks
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks)] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return last_json(r.stdout)
+
+
+def test_single_stream_and_self_spawned_ranks(product):
+    """`bench.py --gpus 3 --pods 1` without a launcher: one greedy stream walking through three stages (SURVEY §8e single-stream
+    curve), ids equal to the 1-GPU run; and block-int8 weights through the same pipeline."""
+    args = ["--shape", "small", "--steps", "5", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = _bench(args, env, 1, "self")
+    env2 = dict(env, BENCH_SHARED_GPU="1")
+    three = _bench(args + ["--pods", "1"], env2, 3, "self")
+    assert three["n_gpus"] == 3 and three["config"]["streams"] == 1
+    assert three["tokens_stream0"][:5] == one["tokens_stream0"][:5]
+    q1 = _bench(args + ["--int8"], env, 1, "self")
+    q2 = _bench(args + ["--int8", "--pods", "2"], env2, 2, "self")
+    assert q2["tokens_stream0"][:5] == q1["tokens_stream0"][:5]
+
+
+def test_rccl_transport_world_of_one(product, oracle):
+    """lh_comm_unique_id / lh_comm_init / lh_comm_exchange on real RCCL with the one GPU of the box: a world of one rank sends the
+    produced token id to itself (grouped ncclSend + ncclRecv on the context's stream).  Streams must equal the checker's greedy ids."""
+    from llama_go_amd.mlapi import Pipeline, comm_unique_id, make_hparams, SHAPES
+    hp = make_hparams(**SHAPES["tiny"], ctx=48)
+    prompts = [[1, 5, 9, 200], [7, 3], [100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110]]
+    m = product.NewSyntheticModel(hp, 77)
+    cid = comm_unique_id(product)
+    assert len(cid) == 128 and any(cid)
+    pl = Pipeline(m, 48, len(prompts), 0, 1, comm_id=cid)
+    pl.run(prompts, 3)
+    pl.run(None, 4)
+    got = [pl.tokens(i) for i in range(len(prompts))]
+    pl.free()
+    # the same streams without any communicator (direct device copy of the id)
+    pl2 = Pipeline(m, 48, len(prompts), 0, 1)
+    pl2.run(prompts, 7)
+    got2 = [pl2.tokens(i) for i in range(len(prompts))]
+    pl2.free()
+    m.free()
+    om = oracle.NewSyntheticModel(hp, 77)
+    for i, pr in enumerate(prompts):
+        oc = om.NewContext(48, 4, False)
+        want, _ = oc.GreedyDecode(pr, 8, want_logits=False)
+        oc.free()
+        assert got[i] == want, (i, got[i], want)
+        assert got2[i] == want
+    om.free()
+
+
+def test_pipeline_argument_errors(product):
+    from llama_go_amd.mlapi import Pipeline, MLError, make_hparams, SHAPES
+    hp = make_hparams(**SHAPES["tiny"], ctx=32)
+    m = product.NewSyntheticModel(hp, 5)
+    with pytest.raises(MLError):
+        Pipeline(m, 32, 2, 0, 2)           # sharded world without a communicator
+    pl = Pipeline(m, 32, 2, 0, 1)
+    with pytest.raises(MLError):
+        pl.run(None, 2)                    # nothing to continue from
+    with pytest.raises(MLError):
+        pl.run([[1, 2], [9999]], 1)        # token id outside the vocabulary
+    with pytest.raises(MLError):
+        pl.run([[1, 2], [3]], 40)          # leaves the context window
+    pl.run([[1, 2], [3]], 2)
+    assert len(pl.tokens(0)) == 3 and len(pl.tokens(1)) == 3
+    pl.free()
+    half = product.NewSyntheticModel(hp, 5, 0, 1)
+    with pytest.raises(MLError):
+        Pipeline(half, 32, 1, 0, 1)        # half of the layers is not rank 0 of a world of one
+    half.free()
+    m.free()

@@ -1,7 +1,8 @@
-"""not-gpu: the layer-shard pipeline schedule (llama.go_amd/pipeline.py) over world_size-2/3 gloo on CPU.
-The stage arithmetic is a stand-in (the HIP stage needs a GPU); what is verified is the N > 1 machinery bench.py relies on:
-routing of the residual stream rank r -> r+1, return of the token id to rank 0, per-stream state, no deadlock, and that the
-tokens equal a single-process evaluation of the same recurrence."""
+"""not-gpu: the layer-shard pipeline scheduler of the C-ABI (csrc/comm.hip: lh_pipeline_schedule, lh_pipeline_run_hooks) over
+world_size-2/3 gloo on CPU.  The stage arithmetic is a stand-in (the HIP stage needs a GPU); what is verified is the N > 1
+machinery bench.py relies on, driven by the SAME C loop lh_pipeline_run executes: routing of the residual stream rank r -> r+1,
+return of the token id to rank 0, per-stream state, no deadlock (also with fewer streams than ranks: the single-stream curve),
+and that the tokens equal a single-process evaluation of the same recurrence."""
 import os
 import subprocess
 import sys
@@ -14,14 +15,16 @@ from llama_go_amd.pipeline import layer_range, schedule
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_schedule_is_consistent_across_ranks():
-    for world, pods, steps in [(1, 1, 3), (2, 2, 4), (2, 3, 2), (4, 4, 3), (8, 8, 2), (8, 11, 2)]:
+def test_schedule_is_consistent_across_ranks(built):
+    for world, pods, steps in [(1, 1, 3), (2, 2, 4), (2, 3, 2), (4, 4, 3), (8, 8, 2), (8, 11, 2), (4, 1, 3), (8, 1, 4), (4, 2, 3), (8, 3, 2), (3, 5, 0)]:
         sched = [schedule(r, world, pods, steps) for r in range(world)]
-        nticks = pods * steps + world - 1
+        Q = max(pods, world)
+        nticks = (Q * (steps - 1) + pods + world - 1) if steps else 0
         assert all(len(s) == nticks for s in sched)
         for t in range(nticks):
             for r in range(world):
                 me, nxt = sched[r][t], sched[(r + 1) % world][t]
+                assert me.t == t
                 # what r sends after tick t is exactly what r+1 expects to receive after tick t
                 assert me.active == nxt.recv_after
                 if me.active:
@@ -30,13 +33,19 @@ def test_schedule_is_consistent_across_ranks():
         for r in range(world):
             seen = [(tk.stream, tk.step) for tk in sched[r] if tk.active]
             assert sorted(seen) == sorted((p, s) for p in range(pods) for s in range(steps))
-        # rank 0 evaluates (p, s+1) strictly after the last rank produced (p, s)
-        last = {(tk.stream, tk.step): tk.t for tk in sched[world - 1] if tk.active}
-        for tk in sched[0]:
-            if tk.active and tk.step > 0:
-                assert last[(tk.stream, tk.step - 1)] < tk.t
-    with pytest.raises(ValueError):
-        schedule(0, 4, 2, 1)
+        # rank r+1 evaluates (p, s) exactly one tick after rank r; rank 0 evaluates (p, s+1) strictly after the last rank produced (p, s)
+        when = [{(tk.stream, tk.step): tk.t for tk in sched[r] if tk.active} for r in range(world)]
+        for r in range(world - 1):
+            for key, t in when[r].items():
+                assert when[r + 1][key] == t + 1
+        for (p, s_), t in when[0].items():
+            if s_ > 0:
+                assert when[world - 1][(p, s_ - 1)] < t
+        # with at least as many streams as ranks nobody idles between its first and last active tick
+        if pods >= world and steps:
+            for r in range(world):
+                act = [tk.t for tk in sched[r] if tk.active]
+                assert act == list(range(act[0], act[-1] + 1))
 
 
 def test_layer_ranges_partition_the_model():
@@ -52,15 +61,16 @@ WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, {root!r})
     import torch, torch.distributed as dist
-    from llama_go_amd.pipeline import PipelineRunner
+    from llama_go_amd.pipeline import run_hooks
     rank, world, pods, steps = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), {pods}, {steps}
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     D = 8
     first, last = rank == 0, rank == world - 1
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
     xin = [torch.zeros(D) for _ in range(pods)]; xout = [torch.zeros(D) for _ in range(pods)]
     tok_in = [torch.zeros(1, dtype=torch.int32) for _ in range(pods)]; tok_out = [torch.zeros(1, dtype=torch.int32) for _ in range(pods)]
     produced = [[] for _ in range(pods)]
-    def stage(p, s, phase):
+    def stage(p, s):
         if first:
             tok = (p + 1) if s == 0 else int(tok_in[p][0])
             x = torch.arange(D, dtype=torch.float32) * 0.5 + tok + 0.25 * s
@@ -72,10 +82,15 @@ WORKER = textwrap.dedent("""
             produced[p].append(int(tok_out[p][0]))
         else:
             xout[p].copy_(x)
-    runner = PipelineRunner(rank, world, pods, dist, stage,
-                            lambda p, s, ph: tok_out[p] if last else xout[p],
-                            lambda p, s, ph: tok_in[p] if first else xin[p])
-    runner.run_phase(steps, "x")
+    def exchange(s, u, rs, ru):           # one grouped p2p per tick: post both sides, then wait
+        reqs = []
+        if s >= 0:
+            reqs.append(dist.isend((tok_out[s] if last else xout[s]).clone(), nxt))
+        if rs >= 0:
+            reqs.append(dist.irecv(tok_in[rs] if first else xin[rs], prv))
+        for r in reqs:
+            r.wait()
+    run_hooks(rank, world, pods, steps, stage, exchange)   # the C scheduler loop (lh_pipeline_run_hooks)
     dist.barrier()
     if last:
         print("RESULT " + json.dumps(produced), flush=True)
@@ -98,8 +113,8 @@ def reference_tokens(world, pods, steps):
     return out
 
 
-@pytest.mark.parametrize("world,pods,steps", [(2, 2, 4), (3, 4, 3)])
-def test_pipeline_over_gloo_matches_single_process(tmp_path, world, pods, steps):
+@pytest.mark.parametrize("world,pods,steps", [(2, 2, 4), (3, 4, 3), (3, 1, 4)])
+def test_pipeline_over_gloo_matches_single_process(built, tmp_path, world, pods, steps):
     import json
     import socket
     s = socket.socket()
