@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--shape", default="7B")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4, help="decode steps of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="decode steps of the CPU baseline / parity legs (default: all --steps, BASELINE.md §3)")
     ap.add_argument("--pods", type=int, default=0, help="independent greedy streams in flight for N > 1 (default 4 N; 1 = the single-stream latency curve)")
     ap.add_argument("--no-prefill", action="store_true", help="skip the config-3 side measurement (13B, one 1024-token Eval)")
     ap.add_argument("--int8", action="store_true", help="BASELINE config 4: block-int8 weight matrices (36 B per 32 weights); not the headline metric")
@@ -230,14 +230,16 @@ def main():
             if args.int8:
                 om.QuantizeQ8()
             t_gen = time.perf_counter() - t_gen
-            nsteps = max(1, min(args.cpu_steps, K))
+            nsteps = max(1, min(args.cpu_steps or K, K))
             # (B) "--avx-equivalent": the reference's own vdot (oracle/_ref), rows over all host cores
             oc = om.NewContext(ctx_size, ncpu, True)
             lg = oc.Eval(PROMPT, 0)
             tok = int(np.argmax(lg))
+            avx_logits = [lg]
             t1 = time.perf_counter()
             for s in range(nsteps):
                 lg = oc.Eval([tok], P0 + s)
+                avx_logits.append(lg)
                 tok = int(np.argmax(lg))
             avx_dt = (time.perf_counter() - t1) / nsteps
             oc.free()
@@ -245,8 +247,13 @@ def main():
             oc = om.NewContext(ctx_size, ncpu, False)
             otoks, ologits = oc.GreedyDecode(PROMPT, nsteps + 1)
             oc.free()
+            # (C) float64-accumulation truth leg: the yardstick for (A), (B) and the GPU's tree order
+            oc = om.NewContext(ctx_size, ncpu, 2)
+            ftoks, flogits = oc.GreedyDecode(PROMPT, nsteps + 1)
+            oc.free()
             oc = om.NewContext(ctx_size, ncpu, False)
-            osampled = oc.SampleDecode(PROMPT, nsteps + 1, **SMP)
+            osampled = oc.SampleDecode(PROMPT, min(nsteps, 4) + 1, **SMP)
+            oc.free()
             # one scalar step on ONE thread for the 1-thread figure of BASELINE.md row A
             oc1 = om.NewContext(ctx_size, 1, False)
             t2 = time.perf_counter()
@@ -256,14 +263,14 @@ def main():
             om.free()
             result["cpu_baseline"] = {
                 "value": round(1.0 / avx_dt, 3), "unit": "tokens/s", "cores": ncpu, "kind": "port",
-                "sample": f"oracle Eval schedule with the reference's own utils/floats_avx.c vdot (oracle/_ref) = '--avx' path; full {args.shape} model, "
+                "sample": f"checker's restatement of the Eval schedule (OpenMP static row split per MulMat, not the reference's goroutine chunking ml.go:2010-2013) "
+                          f"calling the reference's own utils/floats_avx.c vdot (oracle/_ref) = '--avx' path; full {args.shape} model, "
                           f"{nsteps} decode steps at P={P0}.. after an {P0}-token prefill; rows split over {ncpu} host threads",
                 "ms_per_token": round(avx_dt * 1e3, 1),
                 "pure_go_scalar_1thread_ms_per_token": round(scalar1_dt * 1e3, 1),
                 "weights_gen_s": round(t_gen, 1), "host_logical_cpus": os.cpu_count(),
             }
-            # parity: GPU ids/logits vs the scalar-order oracle on the overlapping steps
-            gl = [logits0]
+            # parity: GPU ids/logits (llama.Eval per token through ml_GraphCompute) vs the scalar-order checker on ALL compared steps
             c2 = model.NewContext(ctx_size, 1)
             c2.Eval(PROMPT, 0)
             gt, glog = [first], []
@@ -272,14 +279,20 @@ def main():
                 glog.append(l2)
                 gt.append(int(np.argmax(l2)))
             c2.free()
-            rel0 = float(np.abs(logits0 - ologits[0]).max() / np.abs(ologits[0]).max())
-            rels = [float(np.abs(glog[s] - ologits[s + 1]).max() / np.abs(ologits[s + 1]).max()) for s in range(nsteps)]
+            gl_all = np.stack([logits0] + glog)
+
+            def relerr(a, b):  # max over steps of max|a-b| / max|b|
+                return float((np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max(axis=-1) / np.abs(b).max(axis=-1)).max())
+
             srt = np.sort(ologits, axis=-1)
             result["parity"] = {
                 "token_ids_match": gt[: nsteps + 1] == list(otoks[: nsteps + 1]) and gt[1: nsteps + 1] == produced[:nsteps],
-                "max_rel_logit_err": max([rel0] + rels), "tolerance": 1e-4, "steps_compared": nsteps + 1,
+                "max_rel_logit_err": relerr(gl_all, ologits), "tolerance": 1e-4, "steps_compared": nsteps + 1,
                 "min_top2_margin_rel": float(((srt[:, -1] - srt[:, -2]) / np.abs(ologits).max(axis=-1)).min()),
-                "sampled_token_ids_match": list(sampled[: nsteps + 1]) == list(osampled),
+                "sampled_token_ids_match": list(sampled[: len(osampled)]) == list(osampled),
+                "f64_leg": {"token_ids_match_gpu": gt[: nsteps + 1] == list(ftoks), "gpu_vs_f64": relerr(gl_all, flogits),
+                            "scalar_go_order_vs_f64": relerr(ologits, flogits), "avx_order_vs_f64": relerr(np.stack(avx_logits), flogits),
+                            "note": "float64-accumulated dot products, one rounding (checker mode useAVX=2); max over steps of max|delta|/max|truth|"},
             }
         ctx.free()
         model.free()

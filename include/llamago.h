@@ -42,8 +42,10 @@ enum { ML_OP_NONE = 0, ML_OP_DUP, ML_OP_ADD, ML_OP_SUB, ML_OP_MUL, ML_OP_DIV, ML
        ML_OP_FLASH_ATTN, ML_OP_FLASH_FF, ML_OP_COUNT };
 
 /* ---- context ---------------------------------------------------------------------------------- */
-/* ml.NewContext ml.go:59-74.  useAVX/useNEON follow the reference's flags (the oracle switches its
- * dot-product summation order on useAVX; the product ignores both: it always runs the HIP path). */
+/* ml.NewContext ml.go:59-74.  useAVX/useNEON follow the reference's flags: the checker switches its dot-product
+ * summation order on them (useAVX 1: utils/floats_avx.c 8-lane order; useNEON: utils/floats_neon.c 4-lane order;
+ * neither: the scalar pure-Go order; useAVX 2, checker only: float64 accumulation, the truth leg of BASELINE.md §3).
+ * The product ignores both: it always runs the HIP path. */
 ml_context* ml_NewContext(int maxThreads, int useAVX, int useNEON);
 void ml_ReleaseContext(ml_context* ctx); /* ml.go:77-80 */
 const char* ml_LastError(void);          /* last "[HALT]"-class message of this thread, "" if none */

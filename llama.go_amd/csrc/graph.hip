@@ -42,7 +42,19 @@ struct Matcher {
     int tokens_leaf = -1;
     std::vector<uint32_t> tokens;
 
-    bool is(int i, int op) const { return i >= 0 && (uint32_t)i < total && T[i].op == op; }
+    // Every node the pattern walks over is marked; the match only holds if ALL nodes of the graph were claimed (extra outputs or
+    // side-effect copies expanded into the same graph would otherwise be silently skipped by the fused plan).
+    mutable std::vector<uint8_t> claimed;
+    bool is(int i, int op) const {
+        if (i < 0 || (uint32_t)i >= total || T[i].op != op) return false;
+        claimed[i] = 1;
+        return true;
+    }
+    // shape + byte strides of a (permuted) view
+    bool view_is(int i, uint32_t n0, uint32_t n1, uint32_t n2, uint64_t b0, uint64_t b1, uint64_t b2) const {
+        const lh_tensor& t = T[i];
+        return t.ne[0] == n0 && t.ne[1] == n1 && t.ne[2] == n2 && t.ne[3] == 1 && t.nb[0] == b0 && t.nb[1] == b1 && t.nb[2] == b2;
+    }
     int s0(int i) const { return T[i].src0; }
     int s1(int i) const { return T[i].src1; }
     // persistent weight leaf with the expected shape -> device pointer.  Matrices may be f32 or block-int8 (all the same
@@ -160,6 +172,13 @@ struct Matcher {
         if ((uint32_t)kpar[0] != p || (uint32_t)*pastp != p) return false;
         if ((uint32_t)qpar[1] != hd || (uint32_t)kpar[1] != hd || (uint32_t)qpar[2] != 0 || (uint32_t)kpar[2] != 1) return false;
         if (kT != p + n || vT != p + n) return false;
+        // the views must be the reference's permutations, not look-alikes: Q/K Permute(0,2,1,3) of [hd,H,*] (llama.go:288, 297),
+        // V Permute(1,2,0,3) (llama.go:319), KQV [hd,N,H] merged back with Permute(0,2,1,3) (llama.go:328); all K-contiguous copies
+        const uint64_t e4 = 4, dB = (uint64_t)d * 4, hB = (uint64_t)hd * 4;
+        if (!view_is(Qp, hd, n, H, e4, dB, hB) || !view_is(Kp, hd, p + n, H, e4, dB, hB)) return false;
+        if (!view_is(s0(vt), p + n, hd, H, dB, e4, hB)) return false;
+        if (!view_is(kqv, hd, n, H, e4, hB, hB * n) || !view_is(s0(A), hd, H, n, e4, hB * n, hB)) return false;
+        if (!view_is(kq, p + n, n, H, e4, (uint64_t)(p + n) * 4, (uint64_t)(p + n) * n * 4)) return false;
         if (il + 1 == md.L) { N = n; past = p; kc_owner = ko; vc_owner = vo; }
         else if (N != n || past != p || kc_owner != ko || vc_owner != vo) return false;
         if (koff != (uint64_t)il * md.ctx * d || voff != koff) return false;
@@ -176,8 +195,8 @@ struct Matcher {
             const float* wsc = nullptr;
             const float* w = weight(s0(src), d, d, &wsc, true);
             if (!w) continue;
-            if (own == ko && !gotk) { L.wk = w; L.s_wk = wsc; gotk = true; }
-            else if (own == vo && !gotv) { L.wv = w; L.s_wv = wsc; gotv = true; }
+            if (own == ko && !gotk) { L.wk = w; L.s_wk = wsc; gotk = true; claimed[i] = 1; }
+            else if (own == vo && !gotv) { L.wv = w; L.s_wv = wsc; gotv = true; claimed[i] = 1; }
         }
         if (!gotk || !gotv) return false;
         *x_in = inpSA;
@@ -185,6 +204,13 @@ struct Matcher {
     }
 
     bool run() {
+        claimed.assign(total, 0);
+        if (!run_pattern()) return false;
+        for (uint32_t i = n_leafs; i < total; ++i)
+            if (!claimed[i]) return false;  // a node outside the Eval pattern: run the graph node by node
+        return true;
+    }
+    bool run_pattern() {
         const int fin = (int)total - 1;
         if (!is(fin, OP_MUL_MAT)) return false;
         const lh_tensor& ft = T[fin];
@@ -406,13 +432,19 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
         if (m.run()) {
             int rc = 0;
             Plan* p = plan_find_or_create(ctx, m.md, &rc);
-            if (!p) return rc;
-            if ((rc = plan_eval(p, m.tokens.data(), nullptr, nullptr, m.N, m.past, (flags & LH_GRAPH_LAST_ROW_LOGITS) != 0))) return rc;
+            if (p) rc = plan_eval(p, m.tokens.data(), nullptr, nullptr, m.N, m.past, (flags & LH_GRAPH_LAST_ROW_LOGITS) != 0);
+            if (!rc) {
+                LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ctx->last_ptr[total - 1] = p->logits;  // [N][V], the final node's layout (ne0 = V, ne1 = N)
+                ctx->last_len[total - 1] = (uint64_t)m.N * m.md.V;
+                ctx->last_fused = 1;
+                return LH_OK;
+            }
+            // Shapes outside what the fused kernels are built for (more rows per workgroup than threads, K beyond the register tile,
+            // head widths the attention kernel cannot tile) are not an error of the caller: the reference's generic MulMat has no such
+            // limits (ml.go:1976-2098), so the graph runs node by node instead.  It recomputes everything, cache writes included.
+            if (rc != LH_EUNSUPPORTED && rc != LH_ESHAPE) return rc;
             LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->last_ptr[total - 1] = p->logits;  // [N][V], the final node's layout (ne0 = V, ne1 = N)
-            ctx->last_len[total - 1] = (uint64_t)m.N * m.md.V;
-            ctx->last_fused = 1;
-            return LH_OK;
         }
     }
 

@@ -69,7 +69,8 @@ struct ml_tensor {  // ml.Tensor ml.go:180-203
     ml_context* last_ctx = nullptr;
     uint64_t last_gen = 0;
     uint32_t last_index = 0;
-    ml_tensor* gc_next = nullptr;
+    ml_tensor *gc_next = nullptr, *gc_prev = nullptr;  // per-thread list of constructor-made tensors (see ml_FreeGraph)
+    bool gc_owned = false;
     // scratch marks of graph construction / flattening (valid when the generation matches): no hash containers on the Eval path
     uint64_t visit_gen = 0, flat_gen = 0;
     int flat_idx = 0;
@@ -115,8 +116,14 @@ static ml_tensor* new_tensor(int dt, uint32_t dims, uint32_t ne0, uint32_t ne1, 
             t->owns = true;
         }
     }
-    if (g_gc_enabled) { t->gc_next = g_gc_head; g_gc_head = t; }
+    if (g_gc_enabled) { t->gc_owned = true; t->gc_next = g_gc_head; if (g_gc_head) g_gc_head->gc_prev = t; g_gc_head = t; }
     return t;
+}
+static void gc_unlink(ml_tensor* t) {
+    if (!t->gc_owned) return;
+    if (t->gc_prev) t->gc_prev->gc_next = t->gc_next; else if (g_gc_head == t) g_gc_head = t->gc_next;
+    if (t->gc_next) t->gc_next->gc_prev = t->gc_prev;
+    t->gc_owned = false; t->gc_next = t->gc_prev = nullptr;
 }
 static ml_tensor* new_leaf(int dt, uint32_t dims, uint32_t ne0, uint32_t ne1, uint32_t ne2, bool alloc_host = true) {
     const bool save = g_gc_enabled;
@@ -232,12 +239,22 @@ ml_tensor* ml_Silu(ml_context*, ml_tensor* a) { return node2(dup_tensor(a), ML_O
 
 // ---- graph  ml.go:619-697 ------------------------------------------------------------------------------
 ml_graph* ml_NewGraph(void) { ml_graph* g = new ml_graph(); g->gen = next_mark(); g->nodes.reserve(2048); g->leafs.reserve(1024); return g; }
+// Go's GC reclaims the per-Eval tensors; here a graph owns what it REACHED: its nodes, and the leafs the operator constructors made
+// on the way (Rope / DiagMaskInf parameters, Copy destinations).  Leafs made with ml_NewTensor* belong to the caller, weights and KV
+// caches to their model / context.  Tensors of OTHER graphs built on the same thread are left alone (a node shared by two graphs goes
+// with the first one freed).  Constructor-made tensors that never reached a graph stay on the thread's list until
+// llamago_CollectGarbage (the runtime.GC() of llama.go:423) or the failure path of llama_Eval releases them.
+static void free_owned(ml_tensor* t) { if (t->gc_owned) { gc_unlink(t); free_tensor(t); } }
 void ml_FreeGraph(ml_graph* g) {
-    ml_tensor* t = g_gc_head;
-    while (t) { ml_tensor* n = t->gc_next; free_tensor(t); t = n; }
-    g_gc_head = nullptr;
+    if (!g) return;
+    for (ml_tensor* t : g->nodes) free_owned(t);
+    for (ml_tensor* t : g->leafs) free_owned(t);
     delete g;
 }
+static void gc_free_down_to(ml_tensor* mark) {  // everything this thread's constructors made after `mark` was the list head
+    while (g_gc_head && g_gc_head != mark) { ml_tensor* t = g_gc_head; gc_unlink(t); free_tensor(t); }
+}
+void llamago_CollectGarbage(void) { gc_free_down_to(nullptr); }
 static int visit_parents(ml_graph* g, ml_tensor* node) {  // ml.go:647-697
     if (node->persistent) {
         if (!g->seen_shared.insert(node).second) return 0;
@@ -335,7 +352,19 @@ struct llama_model {  // llama.go:181-193
     ml_tensor *tokEmbeddings = nullptr, *norm = nullptr, *output = nullptr;
     std::vector<llama_layer> layers;
     uint32_t layer0, layer1;
+    // contexts / pipelines alive on this model: their plans hold raw device addresses of the weights, so the weights may neither be
+    // re-quantised nor released under them (Go keeps the Model reachable through every Context)
+    std::mutex mu;
+    int users = 0;
+    bool release_pending = false;
 };
+static void free_model_now(llama_model* m);
+static void model_acquire(llama_model* m) { std::lock_guard<std::mutex> lk(m->mu); m->users++; }
+static void model_release(llama_model* m) {
+    bool last;
+    { std::lock_guard<std::mutex> lk(m->mu); last = --m->users == 0 && m->release_pending; }
+    if (last) free_model_now(m);
+}
 struct llama_context {  // llama.go:83-88
     ml_tensor *K, *V;
     std::vector<float> logits;
@@ -343,6 +372,7 @@ struct llama_context {  // llama.go:83-88
     llama_model* model;
     uint32_t ctxSize;
     lh_llama* resident = nullptr;  // plan handle for the device-resident loop / stages (created on demand)
+    bool holds_model = false;
 };
 
 static uint32_t ff_size(uint32_t embd, uint32_t mult) { return ((2 * (4 * embd) / 3 + mult - 1) / mult) * mult; }  // llama.go:761
@@ -448,6 +478,14 @@ llama_model* llama_NewSyntheticModel(const llama_hparams* hp, uint64_t seed, uin
 
 void llama_FreeModel(llama_model* m) {
     if (!m) return;
+    {   // contexts still alive (their plans address these buffers): the last one to go releases the model
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (m->users > 0) { m->release_pending = true; return; }
+    }
+    free_model_now(m);
+}
+}  // extern "C"
+static void free_model_now(llama_model* m) {
     free_tensor(m->tokEmbeddings); free_tensor(m->norm); free_tensor(m->output);
     for (llama_layer& l : m->layers) {
         free_tensor(l.attentionNorm); free_tensor(l.wq); free_tensor(l.wk); free_tensor(l.wv); free_tensor(l.wo);
@@ -455,6 +493,7 @@ void llama_FreeModel(llama_model* m) {
     }
     delete m;
 }
+extern "C" {
 void llama_ModelHParams(const llama_model* m, llama_hparams* out) { *out = m->hp; }
 uint32_t llama_ModelFFSize(const llama_model* m) { return m->ffSize; }
 
@@ -600,23 +639,89 @@ llama_context* llama_NewContext(llama_model* m, uint32_t ctxSize, int maxThreads
     c->V = new_weight(1, (uint32_t)size, 1);
     if (!c->K || !c->V) { llama_ReleaseContext(c); return nullptr; }
     c->logits.assign(m->hp.vocabSize, 0.f);
+    model_acquire(m);
+    c->holds_model = true;
     return c;
 }
 void llama_ReleaseContext(llama_context* c) {  // llama.go:105-113
     if (!c) return;
     if (c->resident) lh_llama_destroy(c->resident);
     if (c->mlctx) lh_ctx_sync(c->mlctx->hip);
-    free_tensor(c->K); free_tensor(c->V);
+    free_tensor(c->K); free_tensor(c->V);   // per-pod KV caches go with their context (device memory returns to the pool)
     ml_ReleaseContext(c->mlctx);
+    if (c->holds_model) model_release(c->model);
     delete c;
 }
 const float* llama_Logits(const llama_context* c) { return c->logits.data(); }
 ml_context* llama_MLContext(llama_context* c) { return c->mlctx; }
 
+}  // extern "C"
+// The graph of llama.Eval (llama.go:232-387) over `model`, the KV tensors kK / kV and N token ids at position pastCount: expanded into
+// `graph`, returns the logits node (NULL on a "[HALT]" condition).  One builder serves llama_Eval and llamago_DescribeEvalGraph.
+static ml_tensor* build_eval_graph(ml_context* ctx0, llama_model* model, ml_tensor* kK, ml_tensor* kV, uint32_t ctxSize, const uint32_t* tokens, uint32_t N,
+                                   uint32_t pastCount, ml_graph* graph) {
+    const uint32_t embdSize = model->hp.embdSize, layersCount = model->hp.layersCount;
+    const uint32_t headsCount = model->hp.headsCount, rotCount = embdSize / headsCount;
+    ml_tensor* embd = new_tensor(ML_TYPE_F32, 1, N, 1, 1, 1, nullptr, 0);  // :239-242 token ids as fp32
+    for (uint32_t i = 0; i < N; i++) embd->data[i] = (float)tokens[i];
+    ml_tensor* inpL = ml_GetRows(ctx0, model->tokEmbeddings, embd);         // :244
+    for (uint32_t il = 0; il < layersCount; il++) {
+        llama_layer& L = model->layers[il];
+        ml_tensor* inpSA = inpL;
+        ml_tensor* cur = ml_RMSNorm(ctx0, inpL);                              // :255
+        cur = ml_Mul(ctx0, ml_Repeat(ctx0, L.attentionNorm, cur), cur);       // :258-259
+        ml_tensor* Qcur = ml_MulMat(ctx0, L.wq, cur);                         // :263-265
+        ml_tensor* Kcur = ml_MulMat(ctx0, L.wk, cur);
+        ml_tensor* Vcur = ml_MulMat(ctx0, L.wv, cur);
+        {                                                                     // :268-279
+            ml_tensor* k = ml_View1D(ctx0, kK, N * embdSize, embdSize * (il * ctxSize + pastCount));
+            ml_tensor* v = ml_View1D(ctx0, kV, N * embdSize, embdSize * (il * ctxSize + pastCount));
+            if (!k || !v) return nullptr;
+            if (ml_BuildForwardExpand(graph, ml_Copy(ctx0, Kcur, k)) || ml_BuildForwardExpand(graph, ml_Copy(ctx0, Vcur, v))) return nullptr;
+        }
+        ml_tensor* Q = ml_Permute(ctx0,                                       // :281-288
+            ml_Rope(ctx0, ml_Copy(ctx0, Qcur, new_tensor(ML_TYPE_F32, 3, embdSize / headsCount, headsCount, N, 1, nullptr, 0, false)), pastCount, rotCount, 0),
+            0, 2, 1, 3);
+        ml_tensor* K = ml_Permute(ctx0,                                       // :290-297
+            ml_Rope(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, kK, (pastCount + N) * embdSize, il * ctxSize * embdSize),
+                                       embdSize / headsCount, headsCount, pastCount + N), pastCount, rotCount, 1),
+            0, 2, 1, 3);
+        ml_tensor* KQ = ml_MulMat(ctx0, K, Q);                                // :300
+        ml_tensor* sc = new_tensor(ML_TYPE_F32, 1, 1, 1, 1, 1, nullptr, 0);   // :303-307
+        sc->data[0] = (float)(1.0 / sqrt((double)embdSize / (double)headsCount));
+        ml_tensor* KQScaled = ml_Scale(ctx0, KQ, sc);
+        ml_tensor* KQMasked = ml_DiagMaskInf(ctx0, KQScaled, pastCount);      // :310
+        ml_tensor* KQSoftMax = ml_SoftMax(ctx0, KQMasked);                    // :313
+        ml_tensor* VTrans = ml_Copy(ctx0,                                     // :315-322
+            ml_Permute(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, kV, (pastCount + N) * embdSize, il * ctxSize * embdSize),
+                                          embdSize / headsCount, headsCount, pastCount + N), 1, 2, 0, 3),
+            new_tensor(ML_TYPE_F32, 3, pastCount + N, embdSize / headsCount, headsCount, 1, nullptr, 0, false));
+        ml_tensor* KQV = ml_MulMat(ctx0, VTrans, KQSoftMax);                  // :325
+        ml_tensor* KQVMerged = ml_Permute(ctx0, KQV, 0, 2, 1, 3);             // :328
+        cur = ml_Copy(ctx0, KQVMerged, new_tensor(ML_TYPE_F32, 2, embdSize, N, 1, 1, nullptr, 0, false));  // :331-333
+        cur = ml_MulMat(ctx0, L.wo, cur);                                     // :336
+        ml_tensor* inpFF = ml_Add(ctx0, cur, inpSA);                          // :340
+        cur = ml_RMSNorm(ctx0, inpFF);                                        // :346
+        cur = ml_Mul(ctx0, ml_Repeat(ctx0, L.ffn_norm, cur), cur);            // :349-351
+        ml_tensor* tmp = ml_MulMat(ctx0, L.w3, cur);                          // :354
+        cur = ml_MulMat(ctx0, L.w1, cur);                                     // :356
+        cur = ml_Silu(ctx0, cur);                                             // :359
+        cur = ml_Mul(ctx0, cur, tmp);                                         // :361
+        cur = ml_MulMat(ctx0, L.w2, cur);                                     // :363
+        cur = ml_Add(ctx0, cur, inpFF);                                       // :366
+        inpL = cur;
+    }
+    inpL = ml_RMSNorm(ctx0, inpL);                                            // :374
+    inpL = ml_Mul(ctx0, ml_Repeat(ctx0, model->norm, inpL), inpL);            // :377-379
+    inpL = ml_MulMat(ctx0, model->output, inpL);                              // :384
+    if (ml_BuildForwardExpand(graph, inpL)) return nullptr;                   // :387
+    return inpL;
+}
+extern "C" {
+
 int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, uint32_t N, uint32_t pastCount) {  // llama.go:211-426
-    if (model->layer0 != 0 || model->layer1 != model->hp.layersCount) return halt_rc("llama_Eval: layer-sharded model, use llamago_Stage");
-    const uint32_t embdSize = model->hp.embdSize, layersCount = model->hp.layersCount, ctxSize = lctx->ctxSize;
-    const uint32_t headsCount = model->hp.headsCount, vocabSize = model->hp.vocabSize, rotCount = embdSize / headsCount;
+    if (model->layer0 != 0 || model->layer1 != model->hp.layersCount) return halt_rc("llama_Eval: layer-sharded model, use llamago_NewPipeline");
+    const uint32_t ctxSize = lctx->ctxSize, vocabSize = model->hp.vocabSize;
     if (N == 0 || (uint64_t)pastCount + N > ctxSize) return halt_rc("llama_Eval: token window outside the context (the reference would index past the KV slice, llama.go:274)");
     ml_context* ctx0 = lctx->mlctx;
     static const bool timing = getenv("LLAMAGO_TIMING") != nullptr;  // stderr: host-side phases of one Eval in microseconds
@@ -626,63 +731,10 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
     int rc = 1;
     const bool save = g_gc_enabled;
     g_gc_enabled = true;
-    ml_tensor* inpL = nullptr;
+    ml_tensor* const gc_mark = g_gc_head;
     do {
-        ml_tensor* embd = new_tensor(ML_TYPE_F32, 1, N, 1, 1, 1, nullptr, 0);  // :239-242 token ids as fp32
-        for (uint32_t i = 0; i < N; i++) embd->data[i] = (float)tokens[i];
-        inpL = ml_GetRows(ctx0, model->tokEmbeddings, embd);                     // :244
-        bool fail = false;
-        for (uint32_t il = 0; il < layersCount && !fail; il++) {
-            llama_layer& L = model->layers[il];
-            ml_tensor* inpSA = inpL;
-            ml_tensor* cur = ml_RMSNorm(ctx0, inpL);                              // :255
-            cur = ml_Mul(ctx0, ml_Repeat(ctx0, L.attentionNorm, cur), cur);       // :258-259
-            ml_tensor* Qcur = ml_MulMat(ctx0, L.wq, cur);                         // :263-265
-            ml_tensor* Kcur = ml_MulMat(ctx0, L.wk, cur);
-            ml_tensor* Vcur = ml_MulMat(ctx0, L.wv, cur);
-            {                                                                     // :268-279
-                ml_tensor* k = ml_View1D(ctx0, lctx->K, N * embdSize, embdSize * (il * ctxSize + pastCount));
-                ml_tensor* v = ml_View1D(ctx0, lctx->V, N * embdSize, embdSize * (il * ctxSize + pastCount));
-                if (!k || !v) { fail = true; break; }
-                if (ml_BuildForwardExpand(graph, ml_Copy(ctx0, Kcur, k)) || ml_BuildForwardExpand(graph, ml_Copy(ctx0, Vcur, v))) { fail = true; break; }
-            }
-            ml_tensor* Q = ml_Permute(ctx0,                                       // :281-288
-                ml_Rope(ctx0, ml_Copy(ctx0, Qcur, new_tensor(ML_TYPE_F32, 3, embdSize / headsCount, headsCount, N, 1, nullptr, 0, false)), pastCount, rotCount, 0),
-                0, 2, 1, 3);
-            ml_tensor* K = ml_Permute(ctx0,                                       // :290-297
-                ml_Rope(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, lctx->K, (pastCount + N) * embdSize, il * ctxSize * embdSize),
-                                           embdSize / headsCount, headsCount, pastCount + N), pastCount, rotCount, 1),
-                0, 2, 1, 3);
-            ml_tensor* KQ = ml_MulMat(ctx0, K, Q);                                // :300
-            ml_tensor* sc = new_tensor(ML_TYPE_F32, 1, 1, 1, 1, 1, nullptr, 0);   // :303-307
-            sc->data[0] = (float)(1.0 / sqrt((double)embdSize / (double)headsCount));
-            ml_tensor* KQScaled = ml_Scale(ctx0, KQ, sc);
-            ml_tensor* KQMasked = ml_DiagMaskInf(ctx0, KQScaled, pastCount);      // :310
-            ml_tensor* KQSoftMax = ml_SoftMax(ctx0, KQMasked);                    // :313
-            ml_tensor* VTrans = ml_Copy(ctx0,                                     // :315-322
-                ml_Permute(ctx0, ml_Reshape3D(ctx0, ml_View1D(ctx0, lctx->V, (pastCount + N) * embdSize, il * ctxSize * embdSize),
-                                              embdSize / headsCount, headsCount, pastCount + N), 1, 2, 0, 3),
-                new_tensor(ML_TYPE_F32, 3, pastCount + N, embdSize / headsCount, headsCount, 1, nullptr, 0, false));
-            ml_tensor* KQV = ml_MulMat(ctx0, VTrans, KQSoftMax);                  // :325
-            ml_tensor* KQVMerged = ml_Permute(ctx0, KQV, 0, 2, 1, 3);             // :328
-            cur = ml_Copy(ctx0, KQVMerged, new_tensor(ML_TYPE_F32, 2, embdSize, N, 1, 1, nullptr, 0, false));  // :331-333
-            cur = ml_MulMat(ctx0, L.wo, cur);                                     // :336
-            ml_tensor* inpFF = ml_Add(ctx0, cur, inpSA);                          // :340
-            cur = ml_RMSNorm(ctx0, inpFF);                                        // :346
-            cur = ml_Mul(ctx0, ml_Repeat(ctx0, L.ffn_norm, cur), cur);            // :349-351
-            ml_tensor* tmp = ml_MulMat(ctx0, L.w3, cur);                          // :354
-            cur = ml_MulMat(ctx0, L.w1, cur);                                     // :356
-            cur = ml_Silu(ctx0, cur);                                             // :359
-            cur = ml_Mul(ctx0, cur, tmp);                                         // :361
-            cur = ml_MulMat(ctx0, L.w2, cur);                                     // :363
-            cur = ml_Add(ctx0, cur, inpFF);                                       // :366
-            inpL = cur;
-        }
-        if (fail) break;
-        inpL = ml_RMSNorm(ctx0, inpL);                                            // :374
-        inpL = ml_Mul(ctx0, ml_Repeat(ctx0, model->norm, inpL), inpL);            // :377-379
-        inpL = ml_MulMat(ctx0, model->output, inpL);                              // :384
-        if (ml_BuildForwardExpand(graph, inpL)) break;                            // :387
+        ml_tensor* inpL = build_eval_graph(ctx0, model, lctx->K, lctx->V, ctxSize, tokens, N, pastCount, graph);
+        if (!inpL) break;
         const long t_build = us_since(tp0);
         const auto tp1 = std::chrono::steady_clock::now();
         {   // :389 — this caller reads only row N-1 of the result (:394-401) and says so
@@ -697,8 +749,62 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
         rc = 0;
     } while (0);
     ml_FreeGraph(graph);
+    if (rc) gc_free_down_to(gc_mark);  // a halted build leaves constructor-made tensors that never reached the graph
     g_gc_enabled = save;
     return rc;
+}
+
+// Harness extension (no counterpart in the reference; needs no GPU): the graph llama.Eval builds for a model of shape `hp`, as numbers.
+// Per tensor 11 int32: op, ne[4], nb[4], src0, src1 — sources are indices into this same list (leafs first, then nodes, the order
+// ml_GraphCompute walks), -1 = nil.  The checker library exports the same function over its own builders: tests compare the two
+// lists so that the product's host mirror and the checker cannot drift apart unnoticed.  Returns the number of tensors.
+int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_t N, uint32_t pastCount, int32_t* out, uint32_t cap_tensors, uint32_t* n_leafs) {
+    g_err.clear();
+    if (!hp || !N || (uint64_t)pastCount + N > ctxSize) return -1;
+    llama_model m;
+    m.hp = *hp;
+    m.ffSize = ff_size(hp->embdSize, hp->multSize);
+    m.layer0 = 0; m.layer1 = hp->layersCount;
+    const uint32_t d = hp->embdSize, V = hp->vocabSize, F = m.ffSize;
+    std::vector<ml_tensor*> mine;
+    auto shape_leaf = [&](uint32_t dims, uint32_t ne0, uint32_t ne1) { ml_tensor* t = new_leaf(ML_TYPE_F32, dims, ne0, ne1, 1, false); mine.push_back(t); return t; };
+    m.tokEmbeddings = shape_leaf(2, d, V); m.norm = shape_leaf(1, d, 1); m.output = shape_leaf(2, d, V);
+    m.layers.assign(hp->layersCount, llama_layer{});
+    for (llama_layer& l : m.layers) {
+        l.attentionNorm = shape_leaf(1, d, 1); l.wq = shape_leaf(2, d, d); l.wk = shape_leaf(2, d, d); l.wv = shape_leaf(2, d, d); l.wo = shape_leaf(2, d, d);
+        l.ffn_norm = shape_leaf(1, d, 1); l.w1 = shape_leaf(2, d, F); l.w2 = shape_leaf(2, F, d); l.w3 = shape_leaf(2, d, F);
+    }
+    const uint32_t kvn = d * hp->layersCount * ctxSize;
+    ml_tensor *kK = shape_leaf(1, kvn, 1), *kV = shape_leaf(1, kvn, 1);
+    std::vector<uint32_t> tokens(N, 1u);
+    ml_graph* g = ml_NewGraph();
+    const bool save = g_gc_enabled;
+    g_gc_enabled = true;
+    ml_tensor* const gc_mark = g_gc_head;
+    int count = -1;
+    if (build_eval_graph(nullptr, &m, kK, kV, ctxSize, tokens.data(), N, pastCount, g)) {
+        std::unordered_map<const ml_tensor*, int> idx;
+        std::vector<ml_tensor*> all(g->leafs);
+        all.insert(all.end(), g->nodes.begin(), g->nodes.end());
+        for (size_t i = 0; i < all.size(); ++i) idx[all[i]] = (int)i;
+        count = (int)all.size();
+        if (n_leafs) *n_leafs = (uint32_t)g->leafs.size();
+        for (size_t i = 0; i < all.size() && i < cap_tensors && out; ++i) {
+            const ml_tensor* t = all[i];
+            int32_t* o = out + i * 11;
+            o[0] = t->op;
+            for (int k = 0; k < 4; ++k) { o[1 + k] = (int32_t)t->ne[k]; o[5 + k] = (int32_t)t->nb[k]; }
+            o[9] = t->src0 ? idx.at(t->src0) : -1;
+            o[10] = t->src1 ? idx.at(t->src1) : -1;
+        }
+    }
+    ml_FreeGraph(g);
+    gc_free_down_to(gc_mark);
+    g_gc_enabled = save;
+    for (ml_tensor* t : mine) free_tensor(t);
+    m.tokEmbeddings = m.norm = m.output = nullptr;
+    m.layers.clear();
+    return count;
 }
 
 static uint32_t argmax_f32(const float* x, uint32_t n) {  // strict >, lowest index wins ties
@@ -804,6 +910,7 @@ struct llama_pipeline {
     lh_pipeline* pl = nullptr;
     std::vector<ml_tensor*> K, V;
     std::vector<lh_llama*> pods;
+    bool holds_model = false;
 };
 int llamago_CommUniqueId(uint8_t* id) {
     lh_ctx* h = model_ctx();
@@ -820,6 +927,7 @@ void llamago_FreePipeline(llama_pipeline* p) {
     for (ml_tensor* t : p->K) free_tensor(t);
     for (ml_tensor* t : p->V) free_tensor(t);
     ml_ReleaseContext(p->mlctx);
+    if (p->holds_model) model_release(p->model);
     delete p;
 }
 // id: the 128-byte RCCL unique id from rank 0 (llamago_CommUniqueId), or NULL with hooks (host-staged transport), or both NULL
@@ -833,6 +941,8 @@ llama_pipeline* llamago_NewPipeline(llama_model* m, uint32_t ctxSize, uint32_t p
     p->model = m;
     p->mlctx = ml_NewContext(1, 0, 0);
     if (!p->mlctx) { delete p; return nullptr; }
+    model_acquire(m);
+    p->holds_model = true;
     lh_ctx* hip = p->mlctx->hip;
     int rc = 0;
     if (id) rc = lh_comm_init(hip, rank, world, id, &p->comm);
@@ -872,6 +982,8 @@ int llamago_PipelineSync(llama_pipeline* p) { return lh_ctx_sync(p->mlctx->hip) 
 // (norm vectors and the embedding table, which is only gathered from, stay f32) and release the f32 copies.
 int llamago_QuantizeModelQ8(llama_model* m) {
     if (m->wtype == ML_TYPE_Q8_0) return 0;
+    { std::lock_guard<std::mutex> lk(m->mu);
+      if (m->users > 0) return halt_rc("llamago_QuantizeModelQ8: contexts of this model are alive (their plans address the f32 weights); quantise before creating contexts"); }
     lh_ctx* h = model_ctx();
     if (!h) return 1;
     auto q = [&](ml_tensor* t) -> int {

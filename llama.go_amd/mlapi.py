@@ -316,6 +316,19 @@ class Context:
             self.h = None
 
 
+def usable_threads():
+    """Host threads a harness may use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256 logical CPUs under a
+    16-CPU quota; oversubscribing the checker's OpenMP loops there is catastrophic)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 class KernelTime(C.Structure):
     """lh_kernel_time (include/llamahip.h)."""
     _fields_ = [("name", C.c_char * 48), ("launches", c_u32), ("total_ms", C.c_float), ("bytes_per_launch", c_u64)]

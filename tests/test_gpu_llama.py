@@ -151,6 +151,56 @@ def test_concurrent_pods_share_one_model(product):
     assert got == alone
 
 
+def test_pods_come_and_go_without_leaking_hbm(product):
+    """server.Do creates a llama.Context per job and drops it (server.go:151): context create / use / release in a loop — also from
+    concurrent threads, also the resident plans and pipelines — must hand every byte of device memory back (KV caches registered per
+    pod are freed with the pod: the Go shim's ReleaseContextHIP, mirrored by llama_ReleaseContext here).  And the model may neither be
+    re-quantised nor released under live contexts."""
+    import threading
+    import torch
+    from llama_go_amd.mlapi import MLError, Pipeline, decode_greedy_resident
+    hp = make_hparams(**SHAPES["small"], ctx=256)
+    m = product.NewSyntheticModel(hp, 1234)
+
+    def job(n_ctx=256):
+        c = m.NewContext(n_ctx, 1, False)
+        toks = c.GreedyDecode([1, 5, 9, 200], 4, want_logits=False)[0]
+        decode_greedy_resident(c, toks[-1], 8, 3)          # resident plan + captured graph on this context
+        c.SampleDecode([1, 5, 9], 3, seed=1)
+        c.free()
+
+    job()                                                   # warm-up: module load, code objects, first-use pools
+    pl = Pipeline(m, 256, 2)
+    pl.run([[1, 2, 3], [4]], 2)
+    pl.free()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(6):
+        job()
+    ths = [threading.Thread(target=job) for _ in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    pl = Pipeline(m, 256, 3)
+    pl.run([[1, 2, 3], [4], [5, 6]], 2)
+    pl.free()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 <= 4 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of HBM not returned after the pods ended"
+    # live context: quantising would free the f32 weights its plans address
+    c = m.NewContext(64, 1, False)
+    c.Eval([1, 2], 0)
+    with pytest.raises(MLError):
+        m.QuantizeQ8()
+    m.free()                                                # deferred: the context still holds the model
+    assert int(np.argmax(c.Eval([3], 2))) >= 0              # ... and keeps working
+    c.free()                                                # last user gone: the model is released now
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free2 > free1
+
+
 def test_chunked_prefill_all_kernel_families(product, oracle):
     """One context fed in chunks of 3, 9, 20, 40, 70 and 1 tokens: every Eval continues from a non-empty cache (past > 0) and takes a
     different kernel family (weight stream with token rows in registers, MFMA GEMM with 64-row tiles + per-query attention, MFMA
@@ -319,6 +369,45 @@ def test_ggjt_roundtrip_through_hbm(product, oracle, tmp_path):
     mo.free()
 
 
+def test_product_loader_reads_the_reference_converter_files(product, oracle):
+    """The ggjt files the REFERENCE's converter wrote (tests/golden/make_ggjt_from_reference.py: f32 one part, f16 two parts) through
+    the product loader into HBM: weights bit-identical to the fixture state dict, greedy ids and logits equal to the checker's load
+    of the same file, and to the independent numpy float64 forward."""
+    import test_ggjt_reference_fixture as fxt
+    from test_oracle import np_eval, np_weights
+    models = fxt._check_loaded_model(product)       # hparams + every tensor, read back from HBM, == numpy rebuild of the state dict
+    prompt = [1, 70, 261, 5, 280, 33, 9]
+    for (mp, hp), fname in zip(models, fxt.FILES):
+        mo = oracle.LoadModel(os.path.join(fxt.GOLDEN, fname), 32)
+        cp, co = mp.NewContext(32, 1), mo.NewContext(32, 2, False)
+        tp, lp = cp.GreedyDecode(prompt, 6)
+        to, lo = co.GreedyDecode(prompt, 6)
+        assert tp == to
+        assert rel(lp, lo) <= TOL
+        W = np_weights(oracle, mo)
+        L, d, H = hp.layersCount, hp.embdSize, hp.headsCount
+        kc, vc = np.zeros((L, 32, H, d // H)), np.zeros((L, 32, H, d // H))
+        want = np_eval(W, hp, prompt, 0, kc, vc)
+        assert np.abs(lp[0] - want).max() / np.abs(want).max() < 1e-5
+        cp.free(); co.free(); mp.free(); mo.free()
+
+
+def test_committed_golden_vectors_on_the_gpu(product):
+    """tests/golden/tiny_eval.npz (committed KAT of the checker: ids + logits of 8 greedy steps) reproduced by the HIP path without the
+    checker in the loop: a drifted checker and a drifted product cannot agree with a committed file by accident."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_eval.npz"))
+    hp = make_hparams(**SHAPES["tiny"], ctx=int(g["ctx"]))
+    m = product.NewSyntheticModel(hp, int(g["seed"]))
+    w2 = product.read(None, m.tensor("layers.1.feed_forward.w2.weight")).reshape(-1)[:64]
+    assert np.array_equal(w2, g["w2_head"])
+    c = m.NewContext(int(g["ctx"]), 1)
+    toks, lg = c.GreedyDecode([int(t) for t in g["prompt"]], len(g["tokens"]))
+    assert toks == [int(t) for t in g["tokens"]]
+    assert rel(lg, g["logits"]) <= TOL
+    c.free()
+    m.free()
+
+
 def test_out_of_range_token_is_an_error_not_a_gpu_fault(product):
     """A token id >= vocab makes Go panic on the embedding slice (ml.go:1748); here it must come back as an error."""
     hp = make_hparams(**SHAPES["tiny"], ctx=8)
@@ -434,3 +523,32 @@ def test_long_context_split_attention_matches_oracle(product, oracle):
     assert out["fused"] == 1
     assert rel(lg_h, lg_o) <= TOL
     assert toks_h == toks_o
+
+
+@pytest.mark.parametrize("shape,layers", [("13B", 2), ("65B", 1)])
+def test_config3_prefill_1024_tokens_matches_oracle(product, oracle, shape, layers):
+    """BASELINE.json configs[2] at its stated size: 13B shape, 2-layer slice, ONE Eval of N = 1024 tokens at
+    past = 0, context 1024 — the run `bench.py`'s prefill_13b object times — plus a 65B-shape 1-layer slice.  Checker: the
+    restatement with the reference's own AVX dot product over 16 host threads (the 1.1 TMAC scalar order would take minutes; both
+    orders sit within 1e-5 of the float64 leg, tests/test_oracle.py).  Then one decode step on the cache the prefill wrote."""
+    from llama_go_amd.mlapi import usable_threads
+    kw = dict(SHAPES[shape])
+    kw["layers"] = layers
+    hp = make_hparams(**kw, ctx=1024)
+    toks = [int(t) for t in np.random.default_rng(0).integers(0, kw["vocab"], 1023)]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 1234)
+        c = m.NewContext(1024, usable_threads(), True)
+        a = c.Eval(toks, 0)
+        b = c.Eval([int(np.argmax(a))], 1023)
+        res[name] = (a, b)
+        if name == "hip":
+            product.lib.llamago_LastGraphFused.restype = C.c_int
+            product.lib.llamago_LastGraphFused.argtypes = [C.c_void_p]
+            assert product.lib.llamago_LastGraphFused(product.lib.llama_MLContext(c.h)) == 1
+        c.free()
+        m.free()
+    for a, b in zip(res["hip"], res["orc"]):
+        assert rel(a, b) <= TOL
+        assert int(np.argmax(a)) == int(np.argmax(b))
