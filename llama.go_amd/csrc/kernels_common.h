@@ -61,6 +61,15 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// A pointer pinned into a scalar register pair and made opaque to the optimiser.
+__device__ __forceinline__ const char* sgpr_ptr(const void* p) {
+    uint32_t lo = (uint32_t)(uintptr_t)p, hi = (uint32_t)((uintptr_t)p >> 32);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (const char*)(((uintptr_t)hi << 32) | lo);
+}
+
 // fp32 helpers with the reference's rounding sequence (no contraction):
 //   SiLU  ml.go:2587-2589   x / float32(1 + exp(float64(-x)))
 __device__ __forceinline__ float silu_ref(float x) {

@@ -226,6 +226,98 @@ __global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_gemv with SCALAR row addressing.  In k_gemv above every weight load takes a per-lane 64-bit pointer that is selected
+// (v_cndmask x2), offset (v_lshl_add_u64) and, for grouped matrices, rebuilt from a pointer fetched out of the kernel arguments
+// per row: ~24 VALU instructions per row pair next to 32 FMAs, and the compiler parks all refills behind them at the end of
+// the iteration.  Here the row base is a wave-uniform (SGPR) pointer — matrix bases hoisted into registers once, row index
+// scalar, out-of-range rows redirected to the cache-resident activation vector by a scalar select — and the lane contributes a
+// constant 32-bit byte offset: a load is `global_load_dwordx4 v, v_off, s[base]` with no vector address arithmetic at all.
+// Same arithmetic, same summation order, same results bit for bit as k_gemv.
+// ---------------------------------------------------------------------------------------------------
+template <int MAP>
+__device__ __forceinline__ const char* gemv_row_base(const char* w0, const char* w1, const char* w2, uint32_t rows_per_mat, uint32_t v, uint64_t row_bytes) {
+    if (MAP == MAP_SINGLE) return w0 + (uint64_t)v * row_bytes;
+    if (MAP == MAP_BLOCK) {
+        const uint32_t m = (v >= rows_per_mat ? 1u : 0u) + (v >= 2u * rows_per_mat ? 1u : 0u);
+        const char* b = m == 0 ? w0 : (m == 1 ? w1 : w2);
+        return b + (uint64_t)(v - m * rows_per_mat) * row_bytes;
+    }
+    return ((v & 1u) ? w1 : w0) + (uint64_t)(v >> 1) * row_bytes;
+}
+
+template <int KI, int U, int TH, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = TH / 64;
+    double* sred = (double*)smem_raw;                // [NW]
+    float* red = (float*)(smem_raw + NW * 8);        // [rows of this workgroup][NW] per-wave partial dot products
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t K4 = a.K >> 2;
+    const uint32_t nwg = gridDim.x;
+    const uint32_t npairs = a.M >> 1;
+    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
+    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    const char *w0 = (const char*)a.w[0], *w1 = (const char*)a.w[1], *w2 = (const char*)a.w[2];
+    const char* xdummy = (const char*)a.x;           // K floats = exactly one row's extent: any lane offset stays inside it
+    const uint32_t rpm = a.rows_per_mat;
+    const uint64_t row_bytes = (uint64_t)a.K * 4;
+
+    f4 xr[KI];
+    f4 gr[KI];
+    bool act[KI];
+    uint32_t loff[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        act[j] = (uint32_t)(tid + j * TH) < K4;
+        loff[j] = act[j] ? (uint32_t)(tid + j * TH) * 16u : 0u;
+        xr[j] = act[j] ? ((const f4*)a.x)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+        if (PRO == PRO_RMSNORM) gr[j] = act[j] ? ((const f4*)a.gamma)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    float resid_pre;
+    double2 cs_pre;
+    uint32_t past_pre;
+    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
+    f4 w[U][KI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const char* p = (r0 + u < r1) ? gemv_row_base<MAP>(w0, w1, w2, rpm, r0 + u, row_bytes) : xdummy;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((const f4*)(p + loff[j]));
+    }
+    if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, gr, a.K, sred);
+    // inactive lanes (K not a multiple of 4*TH) multiply whatever they loaded by x = 0
+    for (uint32_t r = r0; r < r1; r += U) {
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t nr = r + U + u;
+            const char* p = nr < r1 ? gemv_row_base<MAP>(w0, w1, w2, rpm, nr, row_bytes) : xdummy;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const f4 c = w[u][j];
+                s = fmaf(c.x, xr[j].x, s);
+                s = fmaf(c.y, xr[j].y, s);
+                s = fmaf(c.z, xr[j].z, s);
+                s = fmaf(c.w, xr[j].w, s);
+                w[u][j] = ld_nt((const f4*)(p + loff[j]));
+            }
+            acc[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (r + u < r1) red[(r - r0 + u) * NW + wave] = acc[u];
+        }
+    }
+    __syncthreads();
+    gemv_finish<EPI, NW>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Multi-column variant for small-N prefill (N <= NC per launch): the weight row is still streamed
 // once, NC activation columns live in registers.  Y[c][v] (+ resid) row-major [N][M].
 // ---------------------------------------------------------------------------------------------------

@@ -168,4 +168,149 @@ __global__ __launch_bounds__(1024) void k_gemv_q8(const GemvArgs a) {
     gemv_finish<EPI, NWR>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_gemv_q8s — the same stream with SCALAR row addressing and an explicit two-set software pipeline.
+// What the first kernel's ISA showed (round 2): because `a.w[v & 1]` / `a.ws[m]` index the kernel-argument arrays with a per-lane
+// value, every batch began with global_load_dwordx2 of the matrix POINTERS, an s_waitcnt that also drained the weight loads still in
+// flight (vmcnt counts in order), ~40 VALU instructions of 64-bit address arithmetic and selects, and six v_mov to rotate the
+// register sets: only one batch was ever in flight per wave and the kernel sat at ~5 TB/s with the VALU half idle.  Here:
+//   - a row group is a whole number of waves (TPR >= 64), so its row index is made wave-uniform with readfirstlane; matrix bases are
+//     hoisted into scalar registers; a load is `global_load_dwordx4 v, v_off, s[row]` with a constant per-lane byte offset;
+//   - rows beyond the workgroup's range are redirected (scalar select) to the cache-resident activation vector instead of branching;
+//   - the loop is unrolled over two register sets (A consumed while B is in flight, then B while A), so no register is copied.
+// Arithmetic and summation order are those of k_gemv_q8: results are bit-identical.
+// ---------------------------------------------------------------------------------------------------
+template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(1024) void k_gemv_q8s(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TH = 1024, G = TH / TPR, NWR = TPR / 64;
+    static_assert(TPR % 64 == 0, "a row group must be a whole number of waves");
+    double* sred = (double*)smem_raw;            // [16]
+    float* red = (float*)(smem_raw + 16 * 8);    // [rows of this workgroup][NWR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tr = tid % TPR, wr = wave % NWR;
+    const uint32_t grp = (uint32_t)__builtin_amdgcn_readfirstlane(tid / TPR);   // uniform within a wave
+    const uint32_t K = a.K, K16 = K >> 4;
+    const uint32_t nwg = gridDim.x;
+    const uint32_t npairs = a.M >> 1;
+    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
+    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    // Matrix bases as scalar integers: base of matrix 0 plus the DISTANCES to matrices 1 and 2, so that choosing a matrix is
+    // `base + (m >= 1 ? d1 : 0) + (m == 2 ? d2 : 0)` — selects against the constant 0.  (A select among three pointer variables is
+    // folded by the compiler into an indexed read of a table it builds in scratch memory, which vectorises the whole address path:
+    // seen in the ISA, 2x slower.)
+    const uint64_t q0 = (uint64_t)sgpr_ptr(a.w[0]), s0 = (uint64_t)sgpr_ptr(a.ws[0]);
+    const uint64_t dq1 = MAP == MAP_SINGLE ? 0 : (uint64_t)sgpr_ptr(a.w[1]) - q0, ds1 = MAP == MAP_SINGLE ? 0 : (uint64_t)sgpr_ptr(a.ws[1]) - s0;
+    const uint64_t dq2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.w[2]) - q0 - dq1 : 0, ds2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.ws[2]) - s0 - ds1 : 0;
+    const uint64_t xdummy = (uint64_t)sgpr_ptr(a.x);   // 4K bytes: covers a quant row (K bytes) and a scale row (K/8 bytes)
+    const uint32_t rpm = a.rows_per_mat;
+    f4 xr[KI][4];
+    bool act[KI];
+    uint32_t qoff[KI], soff[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        const uint32_t c = tr + j * TPR;
+        act[j] = c < K16;
+        qoff[j] = act[j] ? c * 16u : 0u;
+        soff[j] = act[j] ? (c >> 1) * 4u : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xr[j][k] = act[j] ? ((const f4*)a.x)[c * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    float resid_pre;
+    double2 cs_pre;
+    uint32_t past_pre;
+    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
+
+    // slot u of this group holds row rb + G*u
+    auto fetch = [&](u4 (&wd)[U][KI], float (&sd)[U][KI], uint32_t row_base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t row = row_base + G * u;
+            uint64_t qb = xdummy, sb = xdummy;
+            if (row < r1) {   // scalar condition: s_cselect on the two addresses, no exec masking
+                uint32_t m = 0, r = row;
+                if (MAP == MAP_BLOCK) { m = (row >= rpm ? 1u : 0u) + (row >= 2u * rpm ? 1u : 0u); r = row - m * rpm; }
+                if (MAP == MAP_PAIR) { m = row & 1u; r = row >> 1; }
+                qb = q0 + (m >= 1u ? dq1 : 0) + (m == 2u ? dq2 : 0) + (uint64_t)r * K;
+                sb = s0 + (m >= 1u ? ds1 : 0) + (m == 2u ? ds2 : 0) + (uint64_t)r * (K >> 5) * 4u;
+            }
+            // addresses rebuilt from integers: say that they are GLOBAL memory, or the loads become flat_load (counted on both wait counters)
+            typedef const u4 __attribute__((address_space(1))) gu4;
+            typedef const float __attribute__((address_space(1))) gf32;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                wd[u][j] = __builtin_nontemporal_load((gu4*)(qb + qoff[j]));
+                sd[u][j] = *(gf32*)(sb + soff[j]);
+            }
+        }
+    };
+    u4 wA[U][KI], wB[U][KI];
+    float scA[U][KI], scB[U][KI];
+    fetch(wA, scA, r0 + grp);
+
+    if (PRO == PRO_RMSNORM) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (act[j]) {
+                    s += (double)__fmul_rn(xr[j][k].x, xr[j][k].x);
+                    s += (double)__fmul_rn(xr[j][k].y, xr[j][k].y);
+                    s += (double)__fmul_rn(xr[j][k].z, xr[j][k].z);
+                    s += (double)__fmul_rn(xr[j][k].w, xr[j][k].w);
+                }
+            }
+        s = wave_sum_f64(s);
+        if (lane == 0) sred[wave] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) tot += sred[grp * NWR + k];
+        const float scale = (float)(1.0 / sqrt(tot / (double)K + 1e-5));
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (act[j]) {
+                    const f4 g = ((const f4*)a.gamma)[(tr + j * TPR) * 4 + k];
+                    xr[j][k].x = __fmul_rn(g.x, __fmul_rn(xr[j][k].x, scale));
+                    xr[j][k].y = __fmul_rn(g.y, __fmul_rn(xr[j][k].y, scale));
+                    xr[j][k].z = __fmul_rn(g.z, __fmul_rn(xr[j][k].z, scale));
+                    xr[j][k].w = __fmul_rn(g.w, __fmul_rn(xr[j][k].w, scale));
+                }
+            }
+    }
+
+    auto consume = [&](const u4 (&wd)[U][KI], const float (&sd)[U][KI], uint32_t rb) {
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) s = fmaf(sd[u][j], dot16_q8(wd[u][j], xr[j]), s);
+            acc[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = wave_sum_lane63(acc[u]);
+        if (lane == 63) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t row = rb + G * u;
+                if (row < r1) red[(row - r0) * NWR + wr] = acc[u];
+            }
+        }
+    };
+    constexpr uint32_t STEP = G * U;
+    for (uint32_t rb = r0 + grp; rb < r1; rb += 2 * STEP) {
+        fetch(wB, scB, rb + STEP);
+        consume(wA, scA, rb);
+        fetch(wA, scA, rb + 2 * STEP);
+        consume(wB, scB, rb + STEP);   // rows >= r1: loaded from the dummy, results dropped by the row test
+    }
+    __syncthreads();
+    gemv_finish<EPI, NWR>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
+}
+
 }  // namespace lh

@@ -44,6 +44,8 @@ struct Plan {
     float* attn_part = nullptr;               // split-T decode attention partials [H][chunks][hd + 2] (plans with ctx > 256)
     float *scores = nullptr, *vt = nullptr;   // large-N prefill attention: S[H][N][Tp], V^T[H][hd][Tp]
     uint64_t scores_cap = 0, vt_cap = 0;
+    float* part = nullptr;                    // raw partial sums between the K-chunk launches of the short-prompt kernel [8][rows]
+    uint64_t part_cap = 0;
     uint32_t* tokens_dev = nullptr;
     const double2* rope = nullptr;            // this plan's RoPE table (rotation width hd, >= ctx positions), resolved at plan_create
     // decode graph state

@@ -5,6 +5,7 @@
 #include "kernels_llama.h"
 #include "kernels_gemm.h"
 #include "kernels_q8.h"
+#include "kernels_skinny.h"
 #include "kernels_sample.h"
 #include <math.h>
 #include <algorithm>
@@ -77,28 +78,45 @@ static int set_lds_once(lh_ctx* ctx, KernT kern, size_t lds, bool* flags) {
     return 0;
 }
 
+// A/B switches (read once): LLAMAHIP_GEMV_SA=0 -> vector-addressed fp32 GEMV (k_gemv) instead of the scalar-addressed k_gemv_sa;
+// LLAMAHIP_Q8_KERNEL=0 -> first block-int8 kernel (k_gemv_q8) instead of k_gemv_q8s; LLAMAHIP_Q8_WGPCU=2 -> two int8 workgroups
+// (8 waves per SIMD) per CU.
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+static bool gemv_sa_on() { static const int v = env_int("LLAMAHIP_GEMV_SA", 1); return v != 0; }
+static bool q8_new_on() { static const int v = env_int("LLAMAHIP_Q8_KERNEL", 1); return v != 0; }
+static int q8_wg_per_cu() { static const int v = env_int("LLAMAHIP_Q8_WGPCU", 1); return v == 2 ? 2 : 1; }
+
 template <int KI, int U, int PRO, int EPI, int MAP, int THR = TH>
 static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
-    auto kern = k_gemv<KI, U, THR, PRO, EPI, MAP>;
-    static bool flags[16] = {};
-    int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
+    static bool flags[2][16] = {};
+    const bool sa = gemv_sa_on();
+    int rc = sa ? set_lds_once(ctx, k_gemv_sa<KI, U, THR, PRO, EPI, MAP>, FAT_LDS, flags[1]) : set_lds_once(ctx, k_gemv<KI, U, THR, PRO, EPI, MAP>, FAT_LDS, flags[0]);
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    if (sa) hipLaunchKernelGGL((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    else hipLaunchKernelGGL((k_gemv<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
 
 template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
 static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
-    auto kern = k_gemv_q8<KI, U, TPR, PRO, EPI, MAP>;
-    static bool flags[16] = {};
-    int rc = set_lds_once(ctx, kern, FAT_LDS, flags);
+    static bool flags[2][2][16] = {};
+    const bool nw = q8_new_on();
+    const int wgpcu = q8_wg_per_cu();
+    // one fat workgroup per CU (LDS request > 80 KiB), or two (64 KiB each: a third does not fit into 160 KiB)
+    const size_t lds = wgpcu == 2 ? 64 * 1024 : FAT_LDS;
+    int rc = nw ? set_lds_once(ctx, k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>, FAT_LDS, flags[1][0]) : set_lds_once(ctx, k_gemv_q8<KI, U, TPR, PRO, EPI, MAP>, FAT_LDS, flags[0][0]);
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    const dim3 grid((unsigned)(ctx->ds->num_cu * wgpcu));
+    if (nw) hipLaunchKernelGGL((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>), grid, dim3(TH), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k_gemv_q8<KI, U, TPR, PRO, EPI, MAP>), grid, dim3(TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -428,6 +446,50 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
     return 0;
 }
 
+// ---- short prompts (2..8 token rows, fp32 weights): one fused pass over the weights per matrix group (kernels_skinny.h) -------
+static constexpr uint32_t SKINNY_NP = 8, SKINNY_KC_MAX = 4096;
+static bool skinny_on() { static const int v = env_int("LLAMAHIP_SKINNY", 1); return v != 0; }
+// shapes the kernel is built for: every contraction length a multiple of 128 (4 waves x 32-float k-blocks), row pairs
+static bool skinny_ok(const ModelDesc& m, uint32_t n) {
+    return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 2 == 0 && m.d % 2 == 0 && m.F % 2 == 0;
+}
+template <int PRO, int EPI, int MAP>
+static int launch_skinny(Plan* p, SkinnyArgs a, const char* name) {
+    lh_ctx* ctx = p->ctx;
+    auto kern = k_skinny<SKINNY_NP, PRO, EPI, MAP>;
+    // K-chunks: the staged activation tile is at most 8 x 4096 floats; chunks are multiples of 128 of nearly equal length
+    const uint32_t nchunks = (a.K + SKINNY_KC_MAX - 1) / SKINNY_KC_MAX;
+    const uint32_t kc_max = ((a.K / 128 + nchunks - 1) / nchunks) * 128;
+    const size_t lds = ((size_t)SKINNY_NP * (kc_max + 4) + 2 * SK_NW * 256) * 4 + SK_NW * 8 + 64;
+    static bool flags[16] = {};
+    int rc0 = set_lds_once(ctx, kern, 160 * 1024, flags);
+    if (rc0) return rc0;
+    if (g_prepare_only) return 0;
+    if (nchunks > 1) {
+        const uint64_t need = (uint64_t)a.n * a.M;
+        if (need > p->part_cap) {
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (p->part) LH_HIP(ctx, hipFree(p->part));
+            p->part = nullptr; p->part_cap = 0;
+            LH_HIP(ctx, hipMalloc((void**)&p->part, (size_t)SKINNY_NP * a.M * 4));
+            p->part_cap = (uint64_t)SKINNY_NP * a.M;
+        }
+    }
+    ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4);
+    uint32_t k0 = 0;
+    for (uint32_t ch = 0; ch < nchunks; ++ch) {
+        const uint32_t kc = std::min(kc_max, a.K - k0);
+        SkinnyArgs b = a;
+        b.k0 = k0; b.kc = kc;
+        b.part_in = ch > 0 ? p->part : nullptr;
+        b.part_out = ch + 1 < nchunks ? p->part : nullptr;
+        hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(SK_TH), lds, ctx->stream, b);
+        k0 += kc;
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
     if (a.hd > ATT_TH || ATT_TH % a.hd || a.hd % 4) LH_FAIL(ctx, LH_EUNSUPPORTED, "attention: head dim %u unsupported (needs to divide %d)", a.hd, ATT_TH);
     const size_t lds = (2 * (size_t)((max_T + 63) & ~63u) + ATT_TH) * 4;
@@ -538,7 +600,7 @@ void plan_destroy(Plan* p) {
     if (p->ring_dev) hipFree(p->ring_dev);
     if (p->graph_step) hipGraphDestroy(p->graph_step);
     if (p->graph_step_adv) hipGraphDestroy(p->graph_step_adv);
-    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt};
+    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part};
     for (float* b : bufs) if (b) hipFree(b);
     if (p->tokens_dev) hipFree(p->tokens_dev);
     if (p->sp_dev) hipFree(p->sp_dev);
@@ -734,6 +796,69 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                                      nullptr, nullptr, i)))
                 return rc;
         }
+        return 0;
+    }
+    if (skinny_ok(m, n)) {
+        // ---- short prompt: 4 fused weight passes per layer + the per-query attention kernel (like the decode step, n rows wide)
+        const float* x = p->xa;
+        if (m.first_stage()) {
+            if ((rc = ensure_staging(ctx, (uint64_t)n * 4))) return rc;
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
+            memcpy(ctx->staging, tokens_host, (size_t)n * 4);
+            LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
+            LH_HIP(ctx, hipGetLastError());
+        } else {
+            x = x_in_dev;
+        }
+        const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
+        const uint32_t d = m.d, F = m.F;
+        for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+            const LayerW& L = m.layers[il];
+            const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
+            {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K rows) -> K,V appended   (llama.go:255-297)
+                SkinnyArgs a = {};
+                a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.rows_per_mat = d; a.M = 3 * d; a.K = d; a.x = x; a.ldx = d; a.n = n; a.gamma = L.attn_norm;
+                a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.rope = p->rope; a.hd = m.hd; a.d = d; a.past = past;
+                if ((rc = launch_skinny<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(p, a, "skinny_qkv_rope"))) return rc;
+            }
+            {
+                AttnArgs a = {};
+                a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
+                if ((rc = launch_attention(ctx, a, past + n))) return rc;
+            }
+            {   // wo + residual   (llama.go:336-340)
+                SkinnyArgs a = {};
+                a.w[0] = L.wo; a.M = d; a.K = d; a.x = p->attn; a.ldx = d; a.n = n; a.y = p->xb; a.resid = x; a.ldy = d;
+                if ((rc = launch_skinny<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(p, a, "skinny_wo_resid"))) return rc;
+            }
+            {   // RMSNorm*gamma -> w1|w3 -> silu(w1 h) * (w3 h)   (llama.go:346-361)
+                SkinnyArgs a = {};
+                a.w[0] = L.w1; a.w[1] = L.w3; a.M = 2 * F; a.K = d; a.x = p->xb; a.ldx = d; a.n = n; a.gamma = L.ffn_norm; a.y = p->g; a.ldy = F;
+                if ((rc = launch_skinny<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(p, a, "skinny_w1w3_silu"))) return rc;
+            }
+            {   // w2 + residual   (llama.go:363-366)
+                const bool last = il + 1 == m.layer1;
+                SkinnyArgs a = {};
+                a.w[0] = L.w2; a.M = d; a.K = F; a.x = p->g; a.ldx = F; a.n = n; a.resid = p->xb; a.ldy = d;
+                a.y = (last && !m.last_stage()) ? x_out_dev : p->xa;
+                if ((rc = launch_skinny<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(p, a, "skinny_w2_resid"))) return rc;
+            }
+            x = p->xa;
+        }
+        if (m.last_stage()) {   // final RMSNorm*gamma -> lm_head: the rows the caller reads (llama.go:372-384, 394-401)
+            const uint32_t r0 = last_row_only ? n - 1 : 0;
+            if (n - r0 == 1) {
+                GemvArgs a = {};
+                a.w[0] = m.output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V;
+                if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", 0))) return rc;
+            } else {
+                SkinnyArgs a = {};
+                a.w[0] = m.output; a.M = m.V; a.K = d; a.x = x; a.ldx = d; a.n = n; a.gamma = m.norm; a.y = p->logits; a.ldy = m.V;
+                if ((rc = launch_skinny<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(p, a, "skinny_lmhead"))) return rc;
+            }
+        }
+        LH_HIP(ctx, hipGetLastError());
         return 0;
     }
     // ---- prefill, N > 1 rows

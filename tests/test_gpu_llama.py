@@ -193,9 +193,10 @@ def test_pods_come_and_go_without_leaking_hbm(product):
     c.Eval([1, 2], 0)
     with pytest.raises(MLError):
         m.QuantizeQ8()
-    m.free()                                                # deferred: the context still holds the model
+    product.lib.llama_FreeModel(m.h)                        # deferred: the context still holds the model (Go: the Context keeps it reachable)
     assert int(np.argmax(c.Eval([3], 2))) >= 0              # ... and keeps working
     c.free()                                                # last user gone: the model is released now
+    m.h = None
     torch.cuda.synchronize()
     free2, _ = torch.cuda.mem_get_info()
     assert free2 > free1
