@@ -152,6 +152,7 @@ def main():
         if args.int8:
             model.QuantizeQ8()
         F = model.ffSize
+        wbytes_f32 = bytes_per_token(d, L, F, V, 0)[0]
         ctx = model.NewContext(ctx_size, 1)
         logits0 = ctx.Eval(PROMPT, 0)  # prefill through ml.GraphCompute (fused plan)
         first = int(np.argmax(logits0))
@@ -322,6 +323,41 @@ def main():
                 m13.free()
             except Exception as e:  # a side measurement must never take the headline line down
                 result["prefill_13b"] = {"error": str(e)}
+        # ---- side objects the driver should see on the default line (not `value`): time to first token for the 8-token prompt, and
+        # BASELINE config 4 (block-int8 weights) through the same resident decode loop
+        if args.shape == "7B" and not args.layers and not args.int8 and not args.no_prefill:
+            try:
+                mt = prod.NewSyntheticModel(hp, SEED)
+                ct = mt.NewContext(ctx_size, 1)
+                ct.Eval(PROMPT, 0)
+                tt = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t_p = time.perf_counter()
+                    ct.Eval(PROMPT, 0)
+                    tt.append(time.perf_counter() - t_p)
+                result["prompt_8_tokens"] = {"ms": round(min(tt) * 1e3, 3), "floor_ms_weight_stream_at_8TBps": round(wbytes_f32 / 8e12 * 1e3, 2),
+                                             "note": "one llama.Eval of the 8-token prompt at past = 0 (server.go:185-192), host graph build + logits D2H included"}
+                ct.free()
+                mt.QuantizeQ8()
+                cq = mt.NewContext(ctx_size, 1)
+                fq = int(np.argmax(cq.Eval(PROMPT, 0)))
+                decode_greedy_resident(cq, fq, P0, W or 1)
+                torch.cuda.synchronize()
+                t_q = time.perf_counter()
+                tq, _ = decode_greedy_resident(cq, fq, P0, K)
+                torch.cuda.synchronize()
+                dq = time.perf_counter() - t_q
+                mat = 4 * (L * (4 * d * d + 3 * d * F) + V * d)
+                qbytes = (wbytes_f32 - mat) + mat * 36 // 128
+                result["int8_decode"] = {"tokens_per_s": round(K / dq, 2), "ms_per_token": round(dq / K * 1e3, 4), "bytes_per_token": int(qbytes),
+                                         "frac_of_hbm_roofline": round(K / dq * qbytes / (HBM_PEAK_GBPS * 1e9), 4), "tokens": tq[: min(K, 16)],
+                                         "note": "BASELINE config 4: block-int8 weight matrices (36 B per 32 weights, format ours), same resident loop; "
+                                                 "parity vs the dequantise-then-fp32 checker is a pytest (tests/test_gpu_llama.py), not re-run here"}
+                cq.free()
+                mt.free()
+            except Exception as e:  # a side measurement must never take the headline line down
+                result["int8_decode"] = {"error": str(e)}
         parallelism = "single GPU, device-resident decode loop (hipGraph replay)"
         pods = 1
         timed_pos0 = P0

@@ -1,0 +1,211 @@
+// csrc/kernels_attn.h — single-pass causal attention for prefill (SURVEY App. B `attn_prefill`).
+//
+// Reference shape: pkg/llama/llama.go:300-333 builds KQ = MulMat(K, Q) for the FULL T x N block, Scale, DiagMaskInf, SoftMax, a
+// transposed copy of V, KQV = MulMat(VTrans, KQSoftMax), and a merge copy.  Round 1 mirrored that as four kernels around a
+// materialised score tensor S[H][N][T] and a V^T copy: 13B, N = 1024 spent 315 us per layer there and moved 168 MB of scores.
+// Here one kernel walks the keys once per query block with an online softmax: no S tensor, no V^T copy, no second pass.
+//
+// Mapping onto v_mfma_f32_32x32x2_f32 (exact f32 fma chains, like every matrix-core path of this backend):
+//   S^T[key][query] = K[key][c] . Q[query][c]      A = K tile rows (from LDS), B = Q fragment (registers, loaded once per block)
+//   O^T[c][query]  += V^T[c][key] . P^T[key][query] A = V tile (from LDS),      B = P^T — which IS the accumulator layout of S^T:
+// lane l owns query column l % 32 in both products, so the probabilities never move between lanes, the running max / sum / rescale
+// are per-lane scalars, and the only cross-lane traffic of the softmax is one exchange between the two half-waves per tile.
+//
+// Work item = (head, block of 64 queries); a workgroup has two wave PAIRS: the pair splits the 64 queries (interleaved, so both
+// waves see the same causal extent), and the two pairs take the even / odd 32-key tiles with their own (m, l, O) state, merged
+// once per item through LDS — a 64-query item costs at most ceil(T / 64) steps, short enough to balance 640 items over 256 CUs
+// (items are dealt heaviest first).  K and V tiles travel global -> LDS by LDS-DMA (no staging registers); K rows are XOR-swizzled
+// on the source side so that 32 lanes reading the same 16-byte granule of 32 different rows hit 32 different slots.
+// The K tiles of step s+1 are requested while step s multiplies P.V, the V tiles while step s+1 multiplies K.Q.
+//
+// Rounding: s = fl32(dot) * fl32(1/sqrt(hd)) as in ml.go:2371; p = exp(fl32(s - m)) with m the RUNNING maximum, evaluated by the fp32
+// library exponential (<= 1 ulp; the reference rounds a float64 exp, ml.go:2472-2492 — sixteen float64 exponentials per lane and tile
+// cost half of the matrix-pipe time and 120 registers here), and the normalisation by the fp32 sum happens once at the end (the
+// reference normalises p before the P.V product and sums in key order): the same value up to a few fp32 roundings per output
+// (~1e-6 relative against the checker, tolerance 1e-4).  Masked keys contribute exactly 0 (ml.go:2476-2477).
+#pragma once
+#include "kernels_llama.h"
+
+namespace lh {
+
+typedef float f16acc __attribute__((ext_vector_type(16)));
+
+struct FlashArgs {
+    const float* q;        // [n][d] roped queries (row stride d)
+    const float* k_cache;  // this layer's K slot [ctx][d] (post-RoPE keys)
+    const float* v_cache;
+    float* out;            // [n][d] merged heads
+    uint32_t d, H, n, past;
+    float scale;           // fl32(1/sqrt(hd)) llama.go:306
+    uint32_t nqb;          // query blocks of FA_BQ
+};
+
+constexpr int FA_BQ = 64, FA_TH = 256, FA_HD = 128;
+constexpr size_t FA_LDS_BYTES = (size_t)4 * 32 * FA_HD * 4;   // K tiles of the two pairs + V tiles of the two pairs = 64 KiB
+
+__global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attn_flash(const FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float fa_smem[];
+    float* Ksm = fa_smem;                     // [2][32][128], granule g of row r stored at slot g ^ r
+    float* Vsm = fa_smem + 2 * 32 * FA_HD;    // [2][32][128], plain
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = wave >> 1, qhalf = wave & 1;
+    const int lj = lane & 31, lh2 = lane >> 5;
+    const uint32_t d = a.d, T = a.past + a.n;
+    const uint32_t items = a.nqb * a.H;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        // heaviest first: the last query blocks see the most keys
+        const uint32_t qb = a.nqb - 1 - item / a.H, h = item % a.H;
+        const uint32_t q0 = qb * FA_BQ;
+        const uint32_t qend = q0 + FA_BQ < a.n ? q0 + FA_BQ : a.n;
+        const uint32_t Tb = a.past + qend;                 // keys any query of this block can see: 0 .. Tb - 1
+        const uint32_t NT = (Tb + 31) / 32, nsteps = (NT + 1) / 2;
+        const uint32_t qi = q0 + 2 * (uint32_t)lj + (uint32_t)qhalf;   // this lane's query (both half-waves hold it)
+        const bool qok = qi < a.n;
+        const uint32_t qlim = a.past + qi;                 // last visible key of the query
+        const float* Kh = a.k_cache + (size_t)h * FA_HD;
+        const float* Vh = a.v_cache + (size_t)h * FA_HD;
+
+        // ---- LDS-DMA: per step 4 tile images (K even, K odd, V even, V odd) of 16 KiB; a wave-instruction moves 1 KiB = 2 tile rows;
+        // each wave moves 8 pieces of K and 8 of V per step: piece pc of wave w covers image (pc / 4 of its operand), rows 8 (pc % 4)...
+        auto dma = [&](bool isK, uint32_t st) {
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) {
+                const int img = pc >> 2;                                          // pair whose tile this is
+                const uint32_t row = (uint32_t)((pc & 3) * 8 + wave * 2 + lh2);  // tile row written by this half-wave (0..31)
+                uint32_t key = (2 * st + (uint32_t)img) * 32 + row;
+                key = key < T ? key : T - 1;                                      // beyond the cache extent: a valid row, masked later
+                const uint32_t gran = isK ? ((uint32_t)lj ^ row) : (uint32_t)lj;  // source-side swizzle for K
+                const float* src = (isK ? Kh : Vh) + (size_t)key * d + 4 * gran;
+                float* dst = (isK ? Ksm : Vsm) + img * (32 * FA_HD) + ((pc & 3) * 8 + wave * 2) * FA_HD;   // wave-uniform base, lanes write linearly
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        };
+        __builtin_amdgcn_s_barrier();   // everybody is done with the previous item's LDS (tiles and merge area)
+        dma(true, 0);
+        dma(false, 0);
+
+        // ---- Q fragment: granule 2g + h of the query row, g = 0..15 (B operand of the 4 MFMAs of granule g)
+        f4 qf[16];
+        {
+            const float* qp = a.q + (size_t)(qok ? qi : a.n - 1) * d + (size_t)h * FA_HD + 4 * lh2;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) qf[g] = *(const f4*)(qp + 8 * g);
+        }
+        f16acc o[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
+        float m = -INFINITY, l = 0.f;
+
+        for (uint32_t st = 0; st < nsteps; ++st) {
+            const uint32_t kt = 2 * st + (uint32_t)pair;       // this pair's key tile
+            const bool live = kt < NT;                         // (an odd tile count leaves pair 1 idle in the last step)
+            // K(st) landed: my 8 newer V pieces may still be in flight
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            f16acc s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            if (live) {
+                const float* Kt = Ksm + pair * (32 * FA_HD) + lj * FA_HD;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const f4 kf = *(const f4*)(Kt + (((2 * g + lh2) ^ lj) << 2));
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g].x, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g].y, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g].z, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g].w, s, 0, 0, 0);
+                }
+            }
+            // ---- online softmax on this lane's 16 keys of the tile: key of accumulator entry e = 32 kt + 8 (e / 4) + 4 h + e % 4
+            float p[16];
+            float mx = -INFINITY;
+            const uint32_t kbase = kt * 32 + 4 * (uint32_t)lh2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t key = kbase + 8 * (e >> 2) + (e & 3);
+                const bool vis = live && qok && key <= qlim;   // DiagMaskInf: key > past + query is masked (ml.go:2401-2404)
+                p[e] = vis ? __fmul_rn(s[e], a.scale) : -INFINITY;   // Scale ml.go:2331-2374
+                mx = fmaxf(mx, p[e]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));            // the other half-wave holds the other 16 keys of this query
+            const float mn = fmaxf(m, mx);
+            float alpha = 1.f, psum = 0.f;
+            if (mn != -INFINITY) {                             // at least one visible key so far
+                alpha = m == -INFINITY ? 0.f : expf(__fsub_rn(m, mn));
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    p[e] = p[e] == -INFINITY ? 0.f : expf(__fsub_rn(p[e], mn));   // ml.go:2472-2492
+                    psum += p[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) p[e] = 0.f;
+            }
+            l = fmaf(l, alpha, psum);
+            m = mn;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[ct][e] *= alpha;
+            }
+            // V(st) landed, and every wave is done reading K(st): the K tiles of the next step may come in under P.V
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma(true, st + 1 < nsteps ? st + 1 : st);          // past the end: a harmless reload (keeps the counts uniform)
+            if (live) {
+                const float* Vt = Vsm + pair * (32 * FA_HD) + 4 * lj;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = 8 * (e >> 2) + 4 * lh2 + (e & 3);   // tile row of the key this half-wave supplies in step e
+                    const f4 vf = *(const f4*)(Vt + rr * FA_HD);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, p[e], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, p[e], o[1], 0, 0, 0);
+                    o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, p[e], o[2], 0, 0, 0);
+                    o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, p[e], o[3], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_barrier();                       // every wave is done reading V(st)
+            dma(false, st + 1 < nsteps ? st + 1 : st);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the redundant tail DMA
+        __builtin_amdgcn_s_barrier();
+
+        // ---- merge the two pairs (even / odd key tiles) through LDS: pair 1 publishes (m, l, O), pair 0 combines and stores
+        l += __shfl_xor(l, 32, 64);                             // both half-waves now hold the query's whole partial sum
+        float* mo = fa_smem + qhalf * (64 * 66);                // [lane][66]: 64 O values + m + l   (2 x 16.5 KiB, the tiles are dead)
+        if (pair == 1) {
+            float* dst = mo + lane * 66;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[ct * 16 + e] = o[ct][e];
+            dst[64] = m;
+            dst[65] = l;
+        }
+        __syncthreads();
+        if (pair == 0 && qok) {
+            const float* src = mo + lane * 66;
+            const float m1 = src[64], l1 = src[65];
+            const float M = fmaxf(m, m1);                       // finite: key 0 is visible to every query and lives in an even tile
+            const float a0 = m == -INFINITY ? 0.f : expf(__fsub_rn(m, M));
+            const float a1 = m1 == -INFINITY ? 0.f : expf(__fsub_rn(m1, M));
+            const float inv = __fdiv_rn(1.0f, fmaf(l1, a1, __fmul_rn(l, a0)));   // ml.go:2496-2499: p *= 1/sum
+            float* orow = a.out + (size_t)qi * d + (size_t)h * FA_HD;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c4 = 4 * (8 * (e >> 2) + 4 * lh2 + (e & 3));   // accumulator entry e of O^T tile ct = output column c4 + ct
+                f4 r;
+                r.x = __fmul_rn(fmaf(src[0 * 16 + e], a1, __fmul_rn(o[0][e], a0)), inv);
+                r.y = __fmul_rn(fmaf(src[1 * 16 + e], a1, __fmul_rn(o[1][e], a0)), inv);
+                r.z = __fmul_rn(fmaf(src[2 * 16 + e], a1, __fmul_rn(o[2][e], a0)), inv);
+                r.w = __fmul_rn(fmaf(src[3 * 16 + e], a1, __fmul_rn(o[3][e], a0)), inv);
+                *(f4*)(orow + c4) = r;
+            }
+        }
+    }
+}
+
+}  // namespace lh

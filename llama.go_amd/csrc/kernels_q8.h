@@ -216,6 +216,15 @@ __global__ __launch_bounds__(1024) void k_gemv_q8s(const GemvArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) xr[j][k] = act[j] ? ((const f4*)a.x)[c * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
     }
+    // norm weights requested together with x (the first kernel fetched them AFTER the norm's barrier: one more L2 round trip on the
+    // critical path of a 15-25 us kernel)
+    f4 gr[PRO == PRO_RMSNORM ? KI : 1][4];
+    if (PRO == PRO_RMSNORM) {
+#pragma unroll
+        for (int j = 0; j < KI; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gr[j][k] = act[j] ? ((const f4*)a.gamma)[(tr + j * TPR) * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+    }
     const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
     float resid_pre;
     double2 cs_pre;
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(1024) void k_gemv_q8s(const GemvArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (act[j]) {
-                    const f4 g = ((const f4*)a.gamma)[(tr + j * TPR) * 4 + k];
+                    const f4 g = gr[j][k];
                     xr[j][k].x = __fmul_rn(g.x, __fmul_rn(xr[j][k].x, scale));
                     xr[j][k].y = __fmul_rn(g.y, __fmul_rn(xr[j][k].y, scale));
                     xr[j][k].z = __fmul_rn(g.z, __fmul_rn(xr[j][k].z, scale));

@@ -6,6 +6,7 @@
 #include "kernels_gemm.h"
 #include "kernels_q8.h"
 #include "kernels_skinny.h"
+#include "kernels_attn.h"
 #include "kernels_sample.h"
 #include <math.h>
 #include <algorithm>
@@ -129,9 +130,12 @@ static int gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     if ((uint64_t)a.M / ctx->ds->num_cu + 4 > (uint64_t)TH) LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv_q8 %s: M=%u exceeds %d rows per workgroup", name, a.M, TH - 4);
     const uint32_t K16 = a.K / 16;
     const uint64_t bytes = (uint64_t)a.M * a.K / 32 * 36;
-    // U = 2 (x2 register sets): tools/kernel_ablate ABL_Q8 — short batches interleave the waves' arithmetic and memory phases
-    // best (5.4 TB/s at U = 2 vs 4.4 at U = 8 on 22016 x 4096)
-    if (K16 <= 256) return launch_gemv_q8<1, 2, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
+    // Rows in flight per row group (x2 register sets), tools/kernel_ablate ABL_Q8S on the scalar-addressed kernel (profiles/r02_q8s_ablation.txt):
+    // 22016 x 4096: U = 1 / 2 / 3 / 4 / 6 -> 21.6 / 22.2 / 21.9 / 21.3 / 21.7 us back to back, but inside the decode graph U = 4 lost to U = 2
+    // (501 vs 513 tok/s same-day); 4096 x 4096: U = 1 / 2 / 4 -> 5.8 / 6.0 / 7.6 us (16 rows per CU:
+    // deeper batches only add dummy loads); K = 11008: one row across the whole workgroup, U = 2 (U = 4: 13.0 vs 11.6 us)
+    const uint32_t rows_wg = a.M / (uint32_t)ctx->ds->num_cu;
+    if (K16 <= 256) return rows_wg >= 32 ? launch_gemv_q8<1, 2, 256, PRO, EPI, MAP>(ctx, a, name, bytes) : launch_gemv_q8<1, 1, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
     if (K16 <= 512) return launch_gemv_q8<2, 2, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
     if (K16 <= 1024) return launch_gemv_q8<1, 2, 1024, PRO, EPI, MAP>(ctx, a, name, bytes);
     if (K16 <= 2048) return launch_gemv_q8<2, 2, 1024, PRO, EPI, MAP>(ctx, a, name, bytes);
@@ -388,6 +392,25 @@ static int attention_gemm(Plan* p, const float* q, const float* kc, const float*
     return 0;
 }
 
+// Single-pass causal prefill attention (kernels_attn.h): one kernel per layer, no score tensor, no V^T copy.  hd = 128 (every LLaMA size).
+static bool flash_on() { static const int v = env_int("LLAMAHIP_FLASH", 1); return v != 0; }
+static int attention_flash(Plan* p, const float* q, const float* kc, const float* vc, float* out, uint32_t n, uint32_t past, float scale) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    FlashArgs a = {};
+    a.q = q; a.k_cache = kc; a.v_cache = vc; a.out = out; a.d = m.d; a.H = m.H; a.n = n; a.past = past; a.scale = scale;
+    a.nqb = (n + FA_BQ - 1) / FA_BQ;
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, k_attn_flash, FA_LDS_BYTES, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    const uint32_t items = a.nqb * m.H, grid = std::min<uint32_t>(items, 2u * (uint32_t)ctx->ds->num_cu);   // 64 KiB of LDS each: two per CU
+    ProfScope ps(ctx->stream, "attn_flash", (uint64_t)2 * (past + n) * m.d * 4);
+    hipLaunchKernelGGL(k_attn_flash, dim3(grid), dim3(FA_TH), FA_LDS_BYTES, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // groups (<= 3) weight matrices of equal shape multiplied with the same X in ONE launch (wq|wk|wv, w1|w3): more tiles per
 // launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
 int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
@@ -449,30 +472,34 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
 // ---- short prompts (2..8 token rows, fp32 weights): one fused pass over the weights per matrix group (kernels_skinny.h) -------
 static constexpr uint32_t SKINNY_NP = 8, SKINNY_KC_MAX = 4096;
 static bool skinny_on() { static const int v = env_int("LLAMAHIP_SKINNY", 1); return v != 0; }
-// shapes the kernel is built for: every contraction length a multiple of 128 (4 waves x 32-float k-blocks), row pairs
+// shapes the kernel is built for: every contraction length a whole number of ring groups (256 floats), RoPE pairs inside a head
 static bool skinny_ok(const ModelDesc& m, uint32_t n) {
-    return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 2 == 0 && m.d % 2 == 0 && m.F % 2 == 0;
+    return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % (SK_RING * SK_KB) == 0 && m.F % (SK_RING * SK_KB) == 0 && m.hd % 2 == 0;
 }
 template <int PRO, int EPI, int MAP>
 static int launch_skinny(Plan* p, SkinnyArgs a, const char* name) {
     lh_ctx* ctx = p->ctx;
     auto kern = k_skinny<SKINNY_NP, PRO, EPI, MAP>;
-    // K-chunks: the staged activation tile is at most 8 x 4096 floats; chunks are multiples of 128 of nearly equal length
+    // K-chunks: the staged activation tile is at most 8 x 4096 floats; chunks are whole ring groups (256 floats) of nearly equal length
+    constexpr uint32_t GR = SK_RING * SK_KB;
     const uint32_t nchunks = (a.K + SKINNY_KC_MAX - 1) / SKINNY_KC_MAX;
-    const uint32_t kc_max = ((a.K / 128 + nchunks - 1) / nchunks) * 128;
-    const size_t lds = ((size_t)SKINNY_NP * (kc_max + 4) + 2 * SK_NW * 256) * 4 + SK_NW * 8 + 64;
+    const uint32_t kc_max = ((a.K / GR + nchunks - 1) / nchunks) * GR;
+    const uint32_t nwg = (uint32_t)ctx->ds->num_cu, npairs = a.M / 2;
+    a.rows_cap = 2 * ((npairs + nwg - 1) / nwg) + 2;
+    const size_t lds = skinny_lds_bytes(SKINNY_NP, kc_max, a.rows_cap, a.hd, EPI == EPI_RESID, nchunks > 1, EPI == EPI_QKV_ROPE);
+    if (lds > 160 * 1024) LH_FAIL(ctx, LH_EUNSUPPORTED, "skinny %s: %zu bytes of LDS needed", name, lds);
     static bool flags[16] = {};
     int rc0 = set_lds_once(ctx, kern, 160 * 1024, flags);
     if (rc0) return rc0;
     if (g_prepare_only) return 0;
     if (nchunks > 1) {
-        const uint64_t need = (uint64_t)a.n * a.M;
+        const uint64_t need = (uint64_t)SKINNY_NP * a.M;
         if (need > p->part_cap) {
             LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (p->part) LH_HIP(ctx, hipFree(p->part));
             p->part = nullptr; p->part_cap = 0;
-            LH_HIP(ctx, hipMalloc((void**)&p->part, (size_t)SKINNY_NP * a.M * 4));
-            p->part_cap = (uint64_t)SKINNY_NP * a.M;
+            LH_HIP(ctx, hipMalloc((void**)&p->part, need * 4));
+            p->part_cap = need;
         }
     }
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4);
@@ -483,7 +510,7 @@ static int launch_skinny(Plan* p, SkinnyArgs a, const char* name) {
         b.k0 = k0; b.kc = kc;
         b.part_in = ch > 0 ? p->part : nullptr;
         b.part_out = ch + 1 < nchunks ? p->part : nullptr;
-        hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(SK_TH), lds, ctx->stream, b);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(SK_TH), lds, ctx->stream, b);
         k0 += kc;
     }
     LH_HIP(ctx, hipGetLastError());
@@ -899,7 +926,9 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
                            m.vc + slot, rope, d, m.hd, past); }
-        if (mfma && n >= 32 && m.hd % 32 == 0) {  // fewer queries: the per-query kernel (no score tensor) is cheaper
+        if (mfma && n >= 32 && m.hd == FA_HD && flash_on()) {   // single pass, online softmax
+            if ((rc = attention_flash(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
+        } else if (mfma && n >= 32 && m.hd % 32 == 0) {  // fewer queries: the per-query kernel (no score tensor) is cheaper
             if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
         } else {
             AttnArgs a = {};

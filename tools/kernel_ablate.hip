@@ -78,6 +78,62 @@ int main() {
         printf("done\n");
         return 0;
     }
+    if (getenv("ABL_Q8S")) {   // round 2: the scalar-addressed two-set kernel (k_gemv_q8s): rows in flight, waves per row, workgroups per CU
+        struct Shape { const char* name; uint32_t M, K; int pair; } shapes[] = {{"w1w3 22016x4096", 2 * F, d, 1}, {"wo 4096x4096", d, d, 0}, {"w2 4096x11008", d, F, 0}};
+        for (const Shape& sh : shapes) {
+            printf("[q8s %s, 36/32 B per weight]\n", sh.name);
+            GemvArgs a = base(sh.M, sh.K);
+            const size_t QB = (size_t)sh.M * sh.K, B = QB / 32 * 36;
+            auto runq = [&](const char* label, auto kern, int wgpcu, int threads) {
+                const size_t lds = wgpcu == 2 ? 64 * 1024 : 96 * 1024;
+                CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                const size_t slot = (B + (1 << 20)) & ~(size_t)4095;
+                size_t nmat = POOL / slot; int iters = 80;
+                auto launch = [&](int i) {
+                    GemvArgs b = a; const char* bs = (const char*)pool + (size_t)(i % nmat) * slot;
+                    b.w[0] = (const float*)bs; b.ws[0] = (const float*)(bs + QB);
+                    if (sh.pair) { b.w[1] = (const float*)(bs + QB / 2); b.ws[1] = (const float*)(bs + QB + QB / 32 * 4 / 2); }
+                    hipLaunchKernelGGL(kern, dim3(nCU * wgpcu), dim3(threads), lds, st, b); };
+                for (int i = 0; i < 3; ++i) launch(i);
+                CK(hipStreamSynchronize(st)); CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; ++i) launch(i);
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); double us = ms * 1e3 / iters;
+                printf("  %-58s %8.2f us  %7.1f GB/s\n", label, us, B / us / 1e3); CK(hipGetLastError());
+            };
+            if (sh.K == d && sh.pair) {
+                runq("old k_gemv_q8 TPR256 U2 rmsnorm/silu/pair", k_gemv_q8<1, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U1 rmsnorm/silu/pair", k_gemv_q8s<1, 1, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U2 rmsnorm/silu/pair", k_gemv_q8s<1, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U3 rmsnorm/silu/pair", k_gemv_q8s<1, 3, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U4 rmsnorm/silu/pair", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U6 rmsnorm/silu/pair", k_gemv_q8s<1, 6, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR128 KI2 U2 rmsnorm/silu/pair", k_gemv_q8s<2, 2, 128, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR128 KI2 U4 rmsnorm/silu/pair", k_gemv_q8s<2, 4, 128, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR64 KI4 U2 rmsnorm/silu/pair", k_gemv_q8s<4, 2, 64, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR64 KI4 U4 rmsnorm/silu/pair", k_gemv_q8s<4, 4, 64, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U2 plain/store/pair (bare stream)", k_gemv_q8s<1, 2, 256, PRO_PLAIN, EPI_STORE, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U4 plain/store/pair (bare stream)", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_STORE, MAP_PAIR>, 1, 1024);
+                runq("q8s TPR256 U2 rmsnorm/silu/pair, 2 wg/CU", k_gemv_q8s<1, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 2, 1024);
+                runq("q8s TPR256 U4 rmsnorm/silu/pair, 2 wg/CU", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, 2, 1024);
+            } else if (sh.K == d) {
+                runq("old k_gemv_q8 TPR256 U2 plain/resid", k_gemv_q8<1, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR256 U1 plain/resid", k_gemv_q8s<1, 1, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR256 U2 plain/resid", k_gemv_q8s<1, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR256 U4 plain/resid", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR64 KI4 U1 plain/resid", k_gemv_q8s<4, 1, 64, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+            } else {
+                runq("old k_gemv_q8 TPR1024 KI1 U2 plain/resid", k_gemv_q8<1, 2, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR1024 KI1 U2 plain/resid", k_gemv_q8s<1, 2, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR1024 KI1 U4 plain/resid", k_gemv_q8s<1, 4, 1024, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR256 KI3 U2 plain/resid", k_gemv_q8s<3, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR256 KI3 U4 plain/resid", k_gemv_q8s<3, 4, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+                runq("q8s TPR512 KI2 U2 plain/resid", k_gemv_q8s<2, 2, 512, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, 1, 1024);
+            }
+        }
+        printf("done\n");
+        return 0;
+    }
     printf("[w1w3 2x11008x4096]\n");
     { GemvArgs a = base(2 * F, d); size_t B = (size_t)2 * F * d * 4;
       run("U4 plain/store/single (bare stream)", k_gemv<1, 4, 1024, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, a, B, 0);

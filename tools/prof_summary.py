@@ -9,11 +9,17 @@ import sys
 def short(n):
     n = re.sub(r'void lh::', '', n)
     n = re.sub(r'\(.*$', '', n)
-    m = re.match(r'k_gemv<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
+    pros = {"0": "plain", "1": "rmsnorm"}
+    epis = {"0": "store", "1": "resid", "2": "qkv_rope", "3": "silu_mul"}
+    m = re.match(r'(k_gemv|k_gemv_sa)<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
     if m:
-        pro = {"0": "plain", "1": "rmsnorm"}[m[4]]
-        epi = {"0": "store", "1": "resid", "2": "qkv_rope", "3": "silu_mul"}[m[5]]
-        return f"k_gemv<KI{m[1]},U{m[2]},TH{m[3]},{pro},{epi}>"
+        return f"{m[1]}<KI{m[2]},U{m[3]},TH{m[4]},{pros[m[5]]},{epis[m[6]]}>"
+    m = re.match(r'(k_gemv_q8|k_gemv_q8s)<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>', n)
+    if m:
+        return f"{m[1]}<KI{m[2]},U{m[3]},TPR{m[4]},{pros[m[5]]},{epis[m[6]]}>"
+    m = re.match(r'k_skinny<(\d+), (\d+), (\d+), (\d+)>', n)
+    if m:
+        return f"k_skinny<NP{m[1]},{pros[m[2]]},{epis[m[3]]},map{m[4]}>"
     return n[:70]
 
 
