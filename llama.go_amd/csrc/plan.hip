@@ -474,14 +474,14 @@ static constexpr uint32_t SKINNY_NP = 8, SKINNY_KC_MAX = 4096;
 static bool skinny_on() { static const int v = env_int("LLAMAHIP_SKINNY", 1); return v != 0; }
 // shapes the kernel is built for: every contraction length a whole number of ring groups (256 floats), RoPE pairs inside a head
 static bool skinny_ok(const ModelDesc& m, uint32_t n) {
-    return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % (SK_RING * SK_KB) == 0 && m.F % (SK_RING * SK_KB) == 0 && m.hd % 2 == 0;
+    return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % SK_GRP == 0 && m.F % SK_GRP == 0 && m.hd % 2 == 0;
 }
 template <int PRO, int EPI, int MAP>
 static int launch_skinny(Plan* p, SkinnyArgs a, const char* name) {
     lh_ctx* ctx = p->ctx;
     auto kern = k_skinny<SKINNY_NP, PRO, EPI, MAP>;
     // K-chunks: the staged activation tile is at most 8 x 4096 floats; chunks are whole ring groups (256 floats) of nearly equal length
-    constexpr uint32_t GR = SK_RING * SK_KB;
+    constexpr uint32_t GR = SK_GRP;
     const uint32_t nchunks = (a.K + SKINNY_KC_MAX - 1) / SKINNY_KC_MAX;
     const uint32_t kc_max = ((a.K / GR + nchunks - 1) / nchunks) * GR;
     const uint32_t nwg = (uint32_t)ctx->ds->num_cu, npairs = a.M / 2;
