@@ -65,7 +65,7 @@ __host__ __device__ inline uint32_t skinny_ksplit(uint32_t ntiles) {
 }
 __host__ __device__ inline uint32_t skinny_units_cap(uint32_t rows_cap) {
     const uint32_t nt = (rows_cap + SK_TR - 1) / SK_TR;
-    return nt >= 16 ? nt : 60;                         // <= 15 tiles x 4 ranges below 16 tiles
+    return nt > 60 ? nt : 60;                          // a workgroup with fewer rows than the cap may split: <= 15 tiles x 4 ranges below 16 tiles
 }
 // LDS bytes of one launch (host and device agree through this one function)
 __host__ __device__ inline size_t skinny_lds_bytes(uint32_t NP, uint32_t kc, uint32_t rows_cap, uint32_t hd, bool resid, bool part, bool rope) {

@@ -557,6 +557,15 @@ static int launch_attention_split(Plan* p, const AttnArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+static void drop_graphs(Plan* p, uint32_t mask) {
+    for (int i = 0; i < Plan::G_COUNT; ++i) {
+        if (!(mask & (1u << i))) continue;
+        if (p->exec[i]) { hipGraphExecDestroy(p->exec[i]); p->exec[i] = nullptr; }
+        if (p->graph[i]) { hipGraphDestroy(p->graph[i]); p->graph[i] = nullptr; }
+    }
+}
+static constexpr uint32_t GM_ADV = (1u << Plan::G_ADV1) | (1u << Plan::G_ADVN), GM_SMP = (1u << Plan::G_SMP1) | (1u << Plan::G_SMPN);
+
 int plan_ensure_rows(Plan* p, uint32_t n) {
     if (n <= p->n_cap) return 0;
     lh_ctx* ctx = p->ctx;
@@ -578,12 +587,7 @@ int plan_ensure_rows(Plan* p, uint32_t n) {
     LH_HIP(ctx, hipMalloc((void**)&p->tokens_dev, (size_t)n * 4));
     p->n_cap = n;
     // captured graphs hold the old scratch addresses
-    if (p->exec_step) { hipGraphExecDestroy(p->exec_step); p->exec_step = nullptr; }
-    if (p->exec_step_adv) { hipGraphExecDestroy(p->exec_step_adv); p->exec_step_adv = nullptr; }
-    if (p->graph_step) { hipGraphDestroy(p->graph_step); p->graph_step = nullptr; }
-    if (p->graph_step_adv) { hipGraphDestroy(p->graph_step_adv); p->graph_step_adv = nullptr; }
-    if (p->exec_step_smp) { hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr; }
-    if (p->graph_step_smp) { hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr; }
+    drop_graphs(p, ~0u);
     return 0;
 }
 
@@ -619,14 +623,9 @@ void plan_destroy(Plan* p) {
     if (!p) return;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    if (p->exec_step) hipGraphExecDestroy(p->exec_step);
-    if (p->exec_step_adv) hipGraphExecDestroy(p->exec_step_adv);
-    if (p->exec_step_smp) hipGraphExecDestroy(p->exec_step_smp);
-    if (p->graph_step_smp) hipGraphDestroy(p->graph_step_smp);
+    drop_graphs(p, ~0u);
     if (p->ss_dev) hipFree(p->ss_dev);
     if (p->ring_dev) hipFree(p->ring_dev);
-    if (p->graph_step) hipGraphDestroy(p->graph_step);
-    if (p->graph_step_adv) hipGraphDestroy(p->graph_step_adv);
     float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part};
     for (float* b : bufs) if (b) hipFree(b);
     if (p->tokens_dev) hipFree(p->tokens_dev);
@@ -739,18 +738,16 @@ static int ensure_out_tokens(Plan* p, uint32_t n) {
     LH_HIP(ctx, hipMalloc((void**)&p->out_tokens_dev, (size_t)cap * 4));
     p->out_cap = cap;
     // graphs captured the old pointer
-    if (p->exec_step_adv) { hipGraphExecDestroy(p->exec_step_adv); p->exec_step_adv = nullptr; }
-    if (p->graph_step_adv) { hipGraphDestroy(p->graph_step_adv); p->graph_step_adv = nullptr; }
-    if (p->exec_step_smp) { hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr; }
-    if (p->graph_step_smp) { hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr; }
+    drop_graphs(p, GM_ADV | GM_SMP);
     return 0;
 }
 
-static int ensure_decode_graph(Plan* p, int adv) {
+// slot: Plan::G_*; the multi-step slots capture GRAPH_MULTI consecutive steps (the step parameters advance in device memory)
+static int ensure_decode_graph(Plan* p, int slot) {
     lh_ctx* ctx = p->ctx;
-    hipGraphExec_t& exec = adv == 2 ? p->exec_step_smp : adv ? p->exec_step_adv : p->exec_step;
-    hipGraph_t& graph = adv == 2 ? p->graph_step_smp : adv ? p->graph_step_adv : p->graph_step;
-    if (exec) return 0;
+    if (p->exec[slot]) return 0;
+    const int adv = slot == Plan::G_STEP ? 0 : (slot == Plan::G_ADV1 || slot == Plan::G_ADVN) ? 1 : 2;
+    const uint32_t reps = (slot == Plan::G_ADVN || slot == Plan::G_SMPN) ? Plan::GRAPH_MULTI : 1;
     if (adv) { int rc = ensure_out_tokens(p, 1); if (rc) return rc; }
     g_prepare_only = true;
     int rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
@@ -760,11 +757,28 @@ static int ensure_decode_graph(Plan* p, int adv) {
     // captured stream is non-blocking and nothing inside the capture touches the legacy stream; in the stricter modes a
     // synchronous hipMemcpy of ANOTHER thread invalidated this capture (tests/test_gpu_llama.py::test_concurrent_pods_share_one_model).
     LH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
-    rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
-    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    for (uint32_t r = 0; r < reps && !rc; ++r) rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, adv, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &p->graph[slot]);
     if (rc) return rc;
     if (e != hipSuccess) LH_FAIL(ctx, LH_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    LH_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    LH_HIP(ctx, hipGraphInstantiate(&p->exec[slot], p->graph[slot], nullptr, nullptr, 0));
+    return 0;
+}
+// n_steps resident steps as graph launches: as many GRAPH_MULTI-step launches as fit, single steps for the rest
+static int launch_resident_steps(Plan* p, uint32_t n_steps, int slot1, int slotn) {
+    lh_ctx* ctx = p->ctx;
+    int rc;
+    uint32_t s = 0;
+    // both graphs are captured at the first resident call of a context, whatever its length: a short warm-up run then pays for the
+    // capture + instantiation of the multi-step graph too, not the first long run after it
+    if ((rc = ensure_decode_graph(p, slotn))) return rc;
+    if (n_steps >= Plan::GRAPH_MULTI) {
+        for (; s + Plan::GRAPH_MULTI <= n_steps; s += Plan::GRAPH_MULTI) LH_HIP(ctx, hipGraphLaunch(p->exec[slotn], ctx->stream));
+    }
+    if (s < n_steps) {
+        if ((rc = ensure_decode_graph(p, slot1))) return rc;
+        for (; s < n_steps; ++s) LH_HIP(ctx, hipGraphLaunch(p->exec[slot1], ctx->stream));
+    }
     return 0;
 }
 
@@ -782,9 +796,9 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
     if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "plan_decode_step needs a whole-model plan");
     int rc;
     if (p->use_graph) {
-        if ((rc = ensure_decode_graph(p, false))) return rc;
+        if ((rc = ensure_decode_graph(p, Plan::G_STEP))) return rc;
         if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
-        LH_HIP(ctx, hipGraphLaunch(p->exec_step, ctx->stream));
+        LH_HIP(ctx, hipGraphLaunch(p->exec[Plan::G_STEP], ctx->stream));
         return 0;
     }
     if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
@@ -1099,11 +1113,12 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
     if (first_token >= md.V) LH_FAIL(ctx, LH_EINVAL, "decode: token id %u outside the vocabulary of %u", first_token, md.V);
     int rc;
     if ((rc = ensure_out_tokens(p, n_steps))) return rc;
-    if (p->use_graph && (rc = ensure_decode_graph(p, true))) return rc;
     if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
-    for (uint32_t s = 0; s < n_steps; ++s) {
-        if (p->use_graph) LH_HIP(ctx, hipGraphLaunch(p->exec_step_adv, ctx->stream));
-        else if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
+    if (p->use_graph) {
+        if ((rc = launch_resident_steps(p, n_steps, Plan::G_ADV1, Plan::G_ADVN))) return rc;
+    } else {
+        for (uint32_t s = 0; s < n_steps; ++s)
+            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
     }
     if (out_tokens) LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, p->logits, (size_t)md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1128,10 +1143,7 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
     if ((rc = sample_check(ctx, sp, md.V))) return rc;
     if ((rc = ensure_out_tokens(p, n_predict))) return rc;
     if (!p->ss_dev) LH_HIP(ctx, hipMalloc((void**)&p->ss_dev, sizeof(SampleState)));
-    if ((sp->top_k <= 64) != (p->smp_topk <= 64) && p->exec_step_smp) {  // the captured graph holds the kernel variant
-        hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr;
-        hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr;
-    }
+    if ((sp->top_k <= 64) != (p->smp_topk <= 64)) drop_graphs(p, GM_SMP);  // the captured graphs hold the kernel variant
     p->smp_topk = sp->top_k;
     if (ring_size > p->ring_cap) {  // the captured sampler holds the ring pointer
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1140,8 +1152,7 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
         p->ring_cap = 0;
         LH_HIP(ctx, hipMalloc((void**)&p->ring_dev, (size_t)ring_size * 4));
         p->ring_cap = ring_size;
-        if (p->exec_step_smp) { hipGraphExecDestroy(p->exec_step_smp); p->exec_step_smp = nullptr; }
-        if (p->graph_step_smp) { hipGraphDestroy(p->graph_step_smp); p->graph_step_smp = nullptr; }
+        drop_graphs(p, GM_SMP);
     }
     // ring: ring_size zeros, then the prompt ids (appendToken, server.go:129-138, 193-197): what remains is the last ring_size of them
     {
@@ -1156,14 +1167,15 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
         LH_HIP(ctx, hipMemcpyAsync(p->ss_dev, (char*)ctx->staging + (size_t)ring_size * 4, sizeof st, hipMemcpyHostToDevice, ctx->stream));
     }
     if ((rc = plan_eval(p, prompt, nullptr, nullptr, n_prompt, 0, true))) return rc;
-    if (p->use_graph && n_predict > 1 && (rc = ensure_decode_graph(p, 2))) return rc;
     // first sample on the last prompt row; the bookkeeping moves {past: n_prompt - 1, step: 0} to {token, past: n_prompt, step: 1}
     if ((rc = upload_step_params(p, 0, 0, n_prompt - 1, 0))) return rc;
     const float* last_row = n_prompt == 1 ? p->logits : p->logits + (size_t)(n_prompt - 1) * md.V;
     if ((rc = sample_launch(ctx, last_row, md.V, p->ss_dev, p->ring_dev, p->sp_dev, p->out_tokens_dev, nullptr, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
-    for (uint32_t s = 1; s < n_predict; ++s) {
-        if (p->use_graph) LH_HIP(ctx, hipGraphLaunch(p->exec_step_smp, ctx->stream));
-        else if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
+    if (p->use_graph) {
+        if (n_predict > 1 && (rc = launch_resident_steps(p, n_predict - 1, Plan::G_SMP1, Plan::G_SMPN))) return rc;
+    } else {
+        for (uint32_t s = 1; s < n_predict; ++s)
+            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
     }
     LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_predict * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
