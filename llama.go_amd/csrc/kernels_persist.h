@@ -31,13 +31,24 @@ constexpr uint32_t P_LDS_BYTES = 96 * 1024; // > 80 KiB: one workgroup per CU
 constexpr uint32_t P_MAX_ROWS = 1024;       // rows one workgroup may own in a phase (32 KB of partials)
 
 struct PersistCtl {
-    unsigned long long* count;   // arrival counter (monotonic; a launch adds barriers_per_launch * #workgroups)
+    unsigned long long* count;   // arrival counter (monotonic; every launch adds exactly arrivals_per_launch)
     uint32_t* err;               // != 0: a barrier timed out; the results are garbage
-    uint32_t barriers_per_launch;
+    unsigned long long arrivals_per_launch;
     uint32_t timeout_ticks;      // per barrier, in 100 MHz ticks
     uint32_t nowait;             // probe only: arrive but never wait (results are garbage; shows the stream's ceiling)
     const float* dummy;          // cache-resident, >= max K floats: target of the ring's out-of-range refills
+#ifdef PERSIST_TRACE
+    unsigned long long* trace;   // tools/resident_probe: [3][PERSIST_TRACE_MAX] realtime stamps of workgroups 0, #wg/2, #wg-1
+#endif
 };
+#ifdef PERSIST_TRACE
+constexpr uint32_t PERSIST_TRACE_MAX = 4096;
+#define PERSIST_STAMP(c, wg, nwg, idx) do { if (threadIdx.x == 0 && ((wg) == 0 || (wg) == (nwg) / 2 || (wg) == (nwg) - 1)) { \
+        const uint32_t slot_ = (wg) == 0 ? 0u : (wg) == (nwg) - 1 ? 2u : 1u; \
+        if ((idx) < PERSIST_TRACE_MAX) (c).trace[slot_ * PERSIST_TRACE_MAX + (idx)] = __builtin_amdgcn_s_memrealtime(); } ++(idx); } while (0)
+#else
+#define PERSIST_STAMP(c, wg, nwg, idx) do { } while (0)
+#endif
 
 // Pointers read out of descriptor tables in memory are generic to the compiler (flat_load: both counters, no scalar base);
 // everything this kernel touches outside LDS is global memory, so say so.
@@ -77,10 +88,10 @@ __device__ __forceinline__ unsigned long long persist_poll_scalar(const unsigned
     return v;
 }
 
-// First value of the counter that belongs to this launch.  Every launch adds exactly per_launch = barriers * #workgroups, and no
-// workgroup can pass barrier 0 before this one arrived, so the counter read here is < base + per_launch.
+// First value of the counter that belongs to this launch.  Every launch adds exactly arrivals_per_launch, and no workgroup can
+// pass the first barrier before this one arrived, so the counter read here is < base + arrivals_per_launch.
 __device__ __forceinline__ unsigned long long persist_base(const PersistCtl& c, uint32_t nwg) {
-    const unsigned long long per = (unsigned long long)c.barriers_per_launch * nwg;
+    const unsigned long long per = c.arrivals_per_launch;
     const unsigned long long cur = __hip_atomic_load(c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return cur - cur % per;
 }
@@ -131,7 +142,7 @@ __device__ __forceinline__ void persist_rows(uint32_t M, uint32_t wg, uint32_t n
 // barrier wait and the fetch of x).  Everything issued before the stores delays the arrive by its own landing time (the store's
 // completion is observed through the same in-order counter), so the early part is kept short.
 template <int KI, int NP, int I0, int I1, int MAP>
-__device__ __forceinline__ void persist_park(const GemvArgs& a, const PersistCtl& c, uint32_t wg, uint32_t nwg, f4 (&pk)[NP > 0 ? NP : 1][KI]) {
+__device__ __forceinline__ void persist_park(const GemvArgs& a, const PersistCtl& c, uint32_t wg, uint32_t nwg, f4 (&pk)[NP > 0 ? NP : 1][KI], bool real = true) {
     static_assert(I0 >= 0 && I0 <= I1 && I1 <= NP, "row range");
     if (I0 == I1) return;
     const int tid = threadIdx.x;
@@ -145,7 +156,9 @@ __device__ __forceinline__ void persist_park(const GemvArgs& a, const PersistCtl
     for (int j = 0; j < KI; ++j) loff[j] = (uint32_t)(tid + j * PTH) < K4 ? (uint32_t)(tid + j * PTH) * 16u : 0u;
 #pragma unroll
     for (int i = I0; i < I1; ++i) {
-        const char* p = (r0 + i < r1) ? gemv_row_base<MAP>(w0, w1, w2, a.rows_per_mat, r0 + i, row_bytes) : (const char*)c.dummy;
+        // real == false: every register is still (re)defined, from the cache-resident dummy row - a workgroup that parks later
+        // than the others must not leave the compiler a path on which last iteration's values stay live through the whole loop
+        const char* p = (real && r0 + i < r1) ? gemv_row_base<MAP>(w0, w1, w2, a.rows_per_mat, r0 + i, row_bytes) : (const char*)c.dummy;
 #pragma unroll
         for (int j = 0; j < KI; ++j) pk[i][j] = ld_nt_g(p + loff[j]);
     }
@@ -189,13 +202,20 @@ __device__ __forceinline__ void persist_finish(const GemvArgs& a, const float* r
                 const uint32_t e = v < d ? v : v - d;
                 float o0, o1;
                 rope_rotate(s0, s1, cs_pre, &o0, &o1);
-                float* dst = v < d ? a.q_out + e : a.k_cache + (size_t)past_pre * d + e;
-                stx1<XM>(dst, o0);
-                stx1<XM>(dst + 1, o1);
+                // q goes to an exchange vector; the K / V rows go into the caller's cache (ordinary memory, read by other XCDs in the
+                // attention phase of the same launch): agent-scope stores, whatever XM is
+                if (v < d) {
+                    stx1<XM>(a.q_out + e, o0);
+                    stx1<XM>(a.q_out + e + 1, o1);
+                } else {
+                    float* dst = a.k_cache + (size_t)past_pre * d + e;
+                    stx1<XM_SCOPED>(dst, o0);
+                    stx1<XM_SCOPED>(dst + 1, o1);
+                }
             } else {
                 float* dst = a.v_cache + (size_t)past_pre * d + (v - 2 * d);
-                stx1<XM>(dst, s0);
-                stx1<XM>(dst + 1, s1);
+                stx1<XM_SCOPED>(dst, s0);
+                stx1<XM_SCOPED>(dst + 1, s1);
             }
         }
     }
@@ -307,6 +327,22 @@ __device__ __forceinline__ void persist_gemv(const GemvArgs& a, const PersistCtl
     // Nothing of this phase stays in flight (the ring's tail refills, the stores): the stores must be complete before the arrive,
     // and the compiler's counter bookkeeping starts the next phase clean on every path.
     wait_vmcnt<0>();
+}
+
+// Boundary pieces for schedules where not every workgroup arrives or parks at the same point (decode: only the attention
+// workgroups arrive at the barrier behind the attention phase).  `target` is the counter value that completes the barrier.
+template <int XM>
+__device__ __forceinline__ void persist_arrive_wg(const PersistCtl& c) {
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (threadIdx.x == 0) persist_arrive<XM>(c);
+}
+template <int XM, int POLL>
+__device__ __forceinline__ void persist_wait_wg(const PersistCtl& c, unsigned long long target, bool* aborted) {
+    if (!c.nowait && threadIdx.x < 64) persist_wait<POLL>(c, target, aborted);
+    __builtin_amdgcn_s_barrier();  // raw: parked rows stay in flight across it
+    if (XM == XM_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("" ::: "memory");
 }
 
 // Phase boundary: stores complete -> arrive -> park the next phase's first rows -> wait -> (acquire).

@@ -6,6 +6,7 @@
 namespace lh {
 
 struct SampleState;
+struct PersistState;   // resident decode kernel: uncached exchange vectors, barrier counter, layer table (plan.hip)
 
 struct LayerW {
     const float *attn_norm = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
@@ -68,6 +69,9 @@ struct Plan {
     uint32_t smp_topk = 0;                    // topK the sampler launches (and the captured graph) were chosen for
     uint32_t slot_counter = 0;   // round-robin over the pinned StepParams slots of eager (non-graph) steps
     bool use_graph = true;
+    // resident decode kernel (csrc/kernels_decode_persist.h); graphs_resident = what the captured decode graphs contain
+    PersistState* ps = nullptr;
+    bool graphs_resident = false;
 };
 
 int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out);

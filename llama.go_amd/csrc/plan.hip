@@ -8,6 +8,7 @@
 #include "kernels_skinny.h"
 #include "kernels_attn.h"
 #include "kernels_sample.h"
+#include "kernels_decode_persist.h"
 #include <math.h>
 #include <algorithm>
 
@@ -595,6 +596,13 @@ static constexpr uint32_t SP_SLOTS = 64;
 
 int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     if (md.d % md.H || md.d % 4 || md.F % 4) LH_FAIL(ctx, LH_ESHAPE, "plan: embd %u / heads %u / ff %u not supported", md.d, md.H, md.F);
+    if (!ctx->counted_for_resident) {
+        // second context with a plan on the device: from now on decode takes the per-layer kernels; a resident kernel still in flight
+        // (launched under this mutex by the first context) finishes before this context launches anything
+        std::lock_guard<std::mutex> lk(ctx->ds->resident_mu);
+        ctx->counted_for_resident = true;
+        if (++ctx->ds->live_ctx == 2) hipDeviceSynchronize();
+    }
     Plan* p = new Plan();
     p->ctx = ctx;
     p->md = md;
@@ -619,11 +627,14 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     return 0;
 }
 
+static void persist_destroy(Plan* p);
+
 void plan_destroy(Plan* p) {
     if (!p) return;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p, ~0u);
+    persist_destroy(p);
     if (p->ss_dev) hipFree(p->ss_dev);
     if (p->ring_dev) hipFree(p->ring_dev);
     float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part};
@@ -651,6 +662,163 @@ void destroy_plans(lh_ctx* ctx) {
     ctx->plans.clear();
 }
 
+// ---- resident decode kernel (csrc/kernels_decode_persist.h) ---------------------------------------------------------------------
+// One launch per token instead of 5 per layer.  OFF by default: measured on the 7B benchmark it ties with the per-layer kernels
+// (4349-4398 us vs 4353 us per token, profiles/r02b_resident_trace.txt: the five all-to-all hand-offs per layer cost what the launch
+// boundaries cost).  LLAMAHIP_RESIDENT=1 (read when a plan first decodes) selects it for whole-model fp32 plans whose shape has an
+// instantiation, while this context is the only one with a plan on the device (DeviceState::live_ctx).
+struct PersistState {
+    float *xa = nullptr, *xb = nullptr, *q = nullptr, *attn = nullptr, *g = nullptr;   // uncached exchange vectors
+    unsigned long long* count = nullptr;   // uncached
+    uint32_t* err = nullptr;               // uncached
+    float* dummy = nullptr;                // ordinary memory, zeros, >= the longest row
+    PersistLayer* layers_dev = nullptr;
+    int kd = 0, kf = 0;                    // float4 per thread of a d-long / ff-long row
+    bool failed = false;                   // a barrier timed out once: the plan stays on the ordinary kernels
+};
+
+static bool resident_env_on() { return env_int("LLAMAHIP_RESIDENT", 0) != 0; }
+static thread_local bool g_resident = false;   // decode launches of this thread take the resident kernel (set by ResidentScope)
+static thread_local int g_resident_depth = 0;
+
+static bool persist_shape_ok(const Plan* p, int* kd, int* kf) {
+    const ModelDesc& m = p->md;
+    if (!resident_env_on() || !m.first_stage() || !m.last_stage() || m.wtype != 0 || p->attn_part) return false;
+    if (m.d % 4 || m.F % 4 || m.hd % 4 || m.hd > (uint32_t)PTH || PTH % m.hd) return false;
+    const uint32_t nwg = (uint32_t)p->ctx->ds->num_cu;
+    if (m.H > nwg || nwg < 2) return false;
+    // one finishing thread per row (store / residual epilogues) or per row pair (RoPE / SiLU epilogues)
+    if (m.V / nwg + 4 > (uint32_t)PTH || m.d / nwg + 4 > (uint32_t)PTH || 3 * m.d / nwg + 4 > 2u * PTH || 2 * m.F / nwg + 4 > 2u * PTH) return false;
+    if ((2 * (size_t)((m.ctx + 63) & ~63u) + PTH) * 4 > 32 * 1024) return false;   // attention scores in LDS
+    *kd = (int)((m.d / 4 + PTH - 1) / PTH);
+    *kf = (int)((m.F / 4 + PTH - 1) / PTH);
+    return (*kd == 1 && (*kf == 1 || *kf == 2)) || (*kd == 2 && *kf == 6);
+}
+
+static bool persist_shape_ok_cached(Plan* p) {
+    if (p->ps) return !p->ps->failed;
+    int kd, kf;
+    return persist_shape_ok(p, &kd, &kf);
+}
+
+static void persist_destroy(Plan* p) {
+    PersistState* s = p->ps;
+    if (!s) return;
+    void* bufs[] = {s->xa, s->xb, s->q, s->attn, s->g, s->count, s->err, s->dummy, s->layers_dev};
+    for (void* b : bufs) if (b) hipFree(b);
+    delete s;
+    p->ps = nullptr;
+}
+
+// Allocates the resident kernel's state on first use.  Returns false (and leaves the plan on the ordinary kernels) when the shape has
+// no instantiation or the uncached allocations are not available.
+static bool persist_ready(Plan* p) {
+    if (p->ps) return !p->ps->failed;
+    int kd, kf;
+    if (!persist_shape_ok(p, &kd, &kf)) return false;
+    const ModelDesc& m = p->md;
+    PersistState* s = new PersistState();
+    s->kd = kd; s->kf = kf;
+    p->ps = s;
+    auto uc = [&](void** ptr, size_t bytes) { return hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached) == hipSuccess && hipMemset(*ptr, 0, bytes) == hipSuccess; };
+    const size_t longest = (size_t)std::max(m.d, m.F) * 4 + 4096;
+    bool ok = uc((void**)&s->xa, (size_t)m.d * 4) && uc((void**)&s->xb, (size_t)m.d * 4) && uc((void**)&s->q, (size_t)m.d * 4) && uc((void**)&s->attn, (size_t)m.d * 4) &&
+              uc((void**)&s->g, (size_t)m.F * 4) && uc((void**)&s->count, 64) && uc((void**)&s->err, 64);
+    ok = ok && hipMalloc((void**)&s->dummy, longest) == hipSuccess && hipMemset(s->dummy, 0, longest) == hipSuccess;
+    std::vector<PersistLayer> hl(m.L);
+    for (uint32_t il = 0; il < m.L; ++il) {
+        const LayerW& L = m.layers[il];
+        const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
+        hl[il] = PersistLayer{L.attn_norm, L.wq, L.wk, L.wv, L.wo, L.ffn_norm, L.w1, L.w3, L.w2, m.kc + slot, m.vc + slot};
+    }
+    ok = ok && hipMalloc((void**)&s->layers_dev, sizeof(PersistLayer) * m.L) == hipSuccess &&
+         hipMemcpy(s->layers_dev, hl.data(), sizeof(PersistLayer) * m.L, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); s->failed = true; }
+    return ok;
+}
+
+template <int KD, int KF>
+static int launch_persist(lh_ctx* ctx, const PersistDecodeArgs& a, uint64_t bytes) {
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, k_decode_persist<KD, KF>, P_LDS_BYTES, flags);
+    if (rc) return rc;
+    if (skip_launch("gemv_decode_resident")) return 0;
+    ProfScope ps(ctx->stream, "gemv_decode_resident", bytes);
+    hipLaunchKernelGGL((k_decode_persist<KD, KF>), dim3(ctx->ds->num_cu), dim3(PTH), P_LDS_BYTES, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// embed -> resident kernel (all layers + lm_head): the decode step between the token id and the logits
+static int enqueue_decode_resident(Plan* p, const StepParams* sp, const uint32_t* tokens_dev, uint32_t logits_row) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    PersistState* s = p->ps;
+    if (!g_prepare_only && !g_only) {
+        ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
+        hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, s->xa, m.d, m.V);
+        LH_HIP(ctx, hipGetLastError());
+    }
+    PersistDecodeArgs a = {};
+    a.layers = s->layers_dev; a.n_layers = m.L; a.d = m.d; a.F = m.F; a.V = m.V; a.H = m.H; a.hd = m.hd;
+    a.xa = s->xa; a.xb = s->xb; a.q = s->q; a.attn = s->attn; a.g = s->g;
+    a.norm = m.norm; a.output = m.output; a.logits = p->logits + logits_row * (size_t)m.V;
+    a.rope = p->rope; a.sp = sp; a.scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
+    a.ctl.count = s->count; a.ctl.err = s->err; a.ctl.arrivals_per_launch = persist_decode_arrivals(m.L, (uint32_t)ctx->ds->num_cu, m.H);
+    a.ctl.timeout_ticks = 2000000;   // 20 ms per barrier
+    a.ctl.nowait = 0; a.ctl.dummy = s->dummy;
+    const uint64_t bytes = 4ull * ((uint64_t)m.L * (4ull * m.d * m.d + 3ull * m.d * m.F + 2ull * m.d) + (uint64_t)m.V * m.d + m.d);
+    if (s->kd == 1 && s->kf == 1) return launch_persist<1, 1>(ctx, a, bytes);
+    if (s->kd == 1 && s->kf == 2) return launch_persist<1, 2>(ctx, a, bytes);
+    return launch_persist<2, 6>(ctx, a, bytes);
+}
+
+// Decides, for the decode launches a thread is about to enqueue, whether they take the resident kernel, and keeps the decision valid
+// while they are enqueued: resident launches happen under DeviceState::resident_mu, the same mutex under which a second context
+// announces itself (and then drains the device).  Captured decode graphs of the other kind are dropped.  Nested scopes are no-ops.
+struct ResidentScope {
+    Plan* p;
+    std::unique_lock<std::mutex> lk;
+    bool outer;
+    explicit ResidentScope(Plan* plan) : p(plan), outer(g_resident_depth++ == 0) {
+        if (!outer) return;
+        bool want = false;
+        if (persist_shape_ok_cached(p)) {
+            lk = std::unique_lock<std::mutex>(p->ctx->ds->resident_mu);
+            want = p->ctx->ds->live_ctx == 1 && persist_ready(p);
+            if (!want) lk.unlock();
+        }
+        if (want != p->graphs_resident) {
+            hipStreamSynchronize(p->ctx->stream);
+            drop_graphs(p, ~0u);
+            p->graphs_resident = want;
+        }
+        g_resident = want;
+    }
+    ~ResidentScope() {
+        --g_resident_depth;
+        if (outer) g_resident = false;
+    }
+};
+
+// After a stream synchronisation: did a barrier of the resident kernel time out (another process holding CUs)?  The results of
+// that call are then invalid: report it, reset the counter, and keep this plan on the ordinary kernels.
+static int persist_check(Plan* p) {
+    PersistState* s = p->ps;
+    if (!s || s->failed || !p->graphs_resident) return 0;
+    lh_ctx* ctx = p->ctx;
+    uint32_t err = 0;
+    LH_HIP(ctx, hipMemcpy(&err, s->err, 4, hipMemcpyDeviceToHost));
+    if (!err) return 0;
+    s->failed = true;
+    hipMemset(s->err, 0, 4);
+    hipMemset(s->count, 0, 8);
+    drop_graphs(p, ~0u);
+    p->graphs_resident = false;
+    LH_FAIL(ctx, LH_EHIP, "resident decode kernel: a grid barrier timed out (the GPU is shared with another process?); this call's results are invalid, "
+                         "later calls use the per-layer kernels");
+}
+
 // ---- decode step (N = 1): 5 kernels per layer --------------------------------------------------------
 // advance: 0 = logits only, 1 = greedy argmax + loop bookkeeping, 2 = device sampler + loop bookkeeping
 static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, int argmax_advance, uint32_t* argmax_out,
@@ -660,7 +828,10 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     const double2* rope = p->rope;
     int rc;
     const float* x = p->xa;
-    if (m.first_stage()) {
+    const bool resident = g_resident && p->ps && !p->ps->failed && !x_in && !x_out;
+    if (resident) {
+        if ((rc = enqueue_decode_resident(p, sp, tokens_dev, logits_row))) return rc;
+    } else if (m.first_stage()) {
         if (!g_prepare_only && !g_only) {
             ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
             TraceScope ts_(ctx->stream, "embed1");
@@ -673,7 +844,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     float* xa = p->xa;
     float* xb = p->xb;
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
-    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+    for (uint32_t il = m.layer0; il < m.layer1 && !resident; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
         {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K) -> K,V appended to the cache   (llama.go:255-297)
@@ -709,9 +880,11 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         x = xa;
     }
     if (m.last_stage()) {   // final RMSNorm*gamma -> lm_head   (llama.go:374-384)
-        GemvArgs a = {};
-        a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
-        if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
+        if (!resident) {
+            GemvArgs a = {};
+            a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
+            if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
+        }
         if (g_only) {
         } else if (argmax_advance == 2 && !g_prepare_only) {
             ProfScope ps(ctx->stream, "sample", (uint64_t)m.V * 4);
@@ -795,6 +968,7 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
     if (past >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: position %u outside the context window of %u", past, m.ctx);
     if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "plan_decode_step needs a whole-model plan");
     int rc;
+    ResidentScope rs(p);
     if (p->use_graph) {
         if ((rc = ensure_decode_graph(p, Plan::G_STEP))) return rc;
         if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
@@ -822,6 +996,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     if ((rc = plan_ensure_rows(p, n))) return rc;
     if (n == 1) {
         if (m.first_stage() && m.last_stage() && p->use_graph) return plan_decode_step(p, tokens_host[0], past);
+        ResidentScope rs(p);
         const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
@@ -1013,6 +1188,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     if (ctx->splitk) hipFree(ctx->splitk);
     if (ctx->staging) hipHostFree(ctx->staging);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    if (ctx->ds && ctx->counted_for_resident) { std::lock_guard<std::mutex> lk(ctx->ds->resident_mu); --ctx->ds->live_ctx; }
     delete ctx;
 }
 
@@ -1099,7 +1275,7 @@ int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past
     if (logits_host)
         LH_HIP(ctx, hipMemcpyAsync(logits_host, p->logits + (size_t)(n - 1) * p->md.V, (size_t)p->md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return LH_OK;
+    return n == 1 ? persist_check(p) : LH_OK;
 }
 
 int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host) {
@@ -1113,17 +1289,20 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
     if (first_token >= md.V) LH_FAIL(ctx, LH_EINVAL, "decode: token id %u outside the vocabulary of %u", first_token, md.V);
     int rc;
     if ((rc = ensure_out_tokens(p, n_steps))) return rc;
-    if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
-    if (p->use_graph) {
-        if ((rc = launch_resident_steps(p, n_steps, Plan::G_ADV1, Plan::G_ADVN))) return rc;
-    } else {
-        for (uint32_t s = 0; s < n_steps; ++s)
-            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
+    {
+        ResidentScope rs(p);
+        if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
+        if (p->use_graph) {
+            if ((rc = launch_resident_steps(p, n_steps, Plan::G_ADV1, Plan::G_ADVN))) return rc;
+        } else {
+            for (uint32_t s = 0; s < n_steps; ++s)
+                if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
+        }
     }
     if (out_tokens) LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, p->logits, (size_t)md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return LH_OK;
+    return persist_check(p);
 }
 
 int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t ring_size, const lh_sample_params* sp,
@@ -1171,15 +1350,18 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
     if ((rc = upload_step_params(p, 0, 0, n_prompt - 1, 0))) return rc;
     const float* last_row = n_prompt == 1 ? p->logits : p->logits + (size_t)(n_prompt - 1) * md.V;
     if ((rc = sample_launch(ctx, last_row, md.V, p->ss_dev, p->ring_dev, p->sp_dev, p->out_tokens_dev, nullptr, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
-    if (p->use_graph) {
-        if (n_predict > 1 && (rc = launch_resident_steps(p, n_predict - 1, Plan::G_SMP1, Plan::G_SMPN))) return rc;
-    } else {
-        for (uint32_t s = 1; s < n_predict; ++s)
-            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
+    {
+        ResidentScope rs(p);
+        if (p->use_graph) {
+            if (n_predict > 1 && (rc = launch_resident_steps(p, n_predict - 1, Plan::G_SMP1, Plan::G_SMPN))) return rc;
+        } else {
+            for (uint32_t s = 1; s < n_predict; ++s)
+                if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
+        }
     }
     LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_predict * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return LH_OK;
+    return persist_check(p);
 }
 
 int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_dev, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past,
@@ -1196,6 +1378,7 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
         const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if (md.first_stage() && !tokens && !tokens_dev) LH_FAIL(ctx, LH_EINVAL, "stage: first stage needs a token id (host or device)");
         if (md.first_stage() && tokens && tokens[0] >= md.V) LH_FAIL(ctx, LH_EINVAL, "stage: token id %u outside the vocabulary of %u", tokens[0], md.V);
+        ResidentScope rs(p);
         if ((rc = upload_step_params(p, slot, tokens ? tokens[0] : 0, past, 0))) return rc;
         if ((rc = enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, md.last_stage() ? argmax_dev : nullptr, tokens ? nullptr : tokens_dev))) return rc;
     } else {
@@ -1219,6 +1402,7 @@ int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t
     LH_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = ensure_out_tokens(p, 1))) return rc;
+    ResidentScope rs(p);
     const float* pin = p->md.first_stage() ? nullptr : p->h;   // stage models: scratch stands in for the received residual
     float* pout = p->md.last_stage() ? nullptr : p->attn;
     ProfSink sink;

@@ -71,6 +71,88 @@ __global__ __launch_bounds__(PTH) void k_persist_probe(const ProbePhase* __restr
     persist_report(c, aborted);
 }
 
+
+// ---- attention || wo: ONE launch, heterogeneous blocks.  Blocks [0, H) stand in for the attention heads (latency-bound, ~5 us: here a timed
+// spin + 128 scoped stores + arrive), blocks [H, H + #CU) are the wo GEMV: they request ALL their weight rows first (weights do not depend on
+// the attention output), then wait for the H arrivals, fetch x and finish.  Lower block ids are dispatched first, so the heads can never
+// be starved by waiting GEMV blocks.  Self-resetting counters: the last GEMV block to leave zeroes them for the next launch.
+struct AwSync { unsigned int* cnt; unsigned int* done; };
+template <int NP, int U>
+__global__ __launch_bounds__(PTH) void k_aw_probe(GemvArgs a, PersistCtl c, AwSync sy, uint32_t H, uint32_t spin_ticks, float* attn_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x < H) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(2);
+        if (threadIdx.x < 128) stx1<XM_SCOPED>(attn_out + blockIdx.x * 128 + threadIdx.x, 0.001f * (float)(threadIdx.x + blockIdx.x));
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sy.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const uint32_t wg = blockIdx.x - H, nwg = gridDim.x - H;
+    f4 pk[NP > 0 ? NP : 1][2];
+    persist_park<2, NP, 0, NP, MAP_SINGLE>(a, c, wg, nwg, pk);
+    if (threadIdx.x < 64) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < H) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)c.timeout_ticks) { if (threadIdx.x == 0) __hip_atomic_store(c.err, 7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    persist_gemv<XM_SCOPED, 2, U, NP, PRO_PLAIN, EPI_RESID, MAP_SINGLE>(a, c, wg, nwg, smem, pk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nwg - 1) {
+            __hip_atomic_store(sy.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sy.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__global__ __launch_bounds__(PTH) void k_spin_heads(uint32_t spin_ticks, float* attn_out) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(2);
+    if (threadIdx.x < 128) attn_out[blockIdx.x * 128 + threadIdx.x] = 0.001f * (float)(threadIdx.x + blockIdx.x);
+}
+
+
+// two launches that overlap through a forked capture: heads on stream 2, the waiting wo GEMV on stream 1 (gemv_only: every block is a GEMV block)
+template <int NP, int U>
+__global__ __launch_bounds__(PTH) void k_wo_wait(GemvArgs a, PersistCtl c, AwSync sy, uint32_t H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t wg = blockIdx.x, nwg = gridDim.x;
+    f4 pk[NP > 0 ? NP : 1][2];
+    persist_park<2, NP, 0, NP, MAP_SINGLE>(a, c, wg, nwg, pk);
+    if (threadIdx.x < 64) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(sy.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < H) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (uint64_t)c.timeout_ticks) { if (threadIdx.x == 0) __hip_atomic_store(c.err, 9u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    persist_gemv<XM_SCOPED, 2, U, NP, PRO_PLAIN, EPI_RESID, MAP_SINGLE>(a, c, wg, nwg, smem, pk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == nwg - 1) {
+            __hip_atomic_store(sy.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sy.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__global__ __launch_bounds__(PTH) void k_heads_arrive(uint32_t spin_ticks, float* attn_out, AwSync sy) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(2);
+    if (threadIdx.x < 128) stx1<XM_SCOPED>(attn_out + blockIdx.x * 128 + threadIdx.x, 0.001f * (float)(threadIdx.x + blockIdx.x));
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sy.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 static int nCU;
 static hipStream_t st;
 static hipEvent_t e0, e1;
@@ -182,7 +264,7 @@ int main(int argc, char** argv) {
         make_phases(e, ph);
         CK(hipMemcpy(dph, ph.data(), sizeof(ProbePhase) * ph.size(), hipMemcpyHostToDevice));
         PersistCtl c = {};
-        c.count = e.count; c.err = e.err; c.barriers_per_launch = (uint32_t)ph.size() - 1; c.timeout_ticks = 300000; /* 3 ms */ c.dummy = dummy; c.nowait = nowait;
+        c.count = e.count; c.err = e.err; c.arrivals_per_launch = (unsigned long long)(ph.size() - 1) * nCU; c.timeout_ticks = 300000; /* 3 ms */ c.dummy = dummy; c.nowait = nowait;
         const size_t lds = P_LDS_BYTES;
         bool found = false;
         auto launch = [&](void) {
@@ -214,6 +296,7 @@ int main(int argc, char** argv) {
         report(label, ms);
         if (!same && !err && !nowait) printf("      max |diff| %.3e\n", md);
     };
+    if (!getenv("PROBE_SKIP_PERSIST")) {
     // ceiling of the resident stream: arrive, never wait
     run_persist(exU, XM_PLAIN, 0, 2, 0, 0, 0, 0, 1);
     run_persist(exU, XM_PLAIN, 0, 2, 8, 0, 3, 0, 1);
@@ -240,6 +323,78 @@ int main(int argc, char** argv) {
     run_persist(exN, XM_SCOPED, 0, 2, 4, 2, 2, 1);
     run_persist(exU, XM_PLAIN, 0, 4, 8, 3, 3, 1);
     run_persist(exU, XM_PLAIN, 0, 4, 8, 0, 3, 0);
+    }
+
+    // ---- attention || wo in one launch vs two kernels (32 layers of wo only; the heads spin 3.0 us to land at ~4.9 us as a kernel) ----
+    {
+        const uint32_t H = 32;
+        float *attn, *xres, *yo; unsigned int* sync;
+        CK(hipMalloc(&attn, d * 4)); CK(hipMalloc(&xres, d * 4)); CK(hipMalloc(&yo, d * 4)); CK(hipMalloc(&sync, 256)); CK(hipMemset(sync, 0, 256));
+        CK(hipMemcpy(xres, v0, d * 4, hipMemcpyDeviceToDevice));
+        AwSync sy = {sync, sync + 32};
+        PersistCtl c = {}; c.err = exN.err; c.count = exN.count; c.timeout_ticks = 300000; c.dummy = dummy;
+        CK(hipMemset(exN.err, 0, 4));
+        std::vector<const float*> wo; { size_t off = 0; for (int l = 0; l < L; ++l) { off += (size_t)Ms[0] * Ks[0]; wo.push_back(W + off); off += (size_t)Ms[1] * Ks[1] + (size_t)Ms[2] * Ks[2] + (size_t)Ms[3] * Ks[3]; } }
+        auto ga = [&](int l) { GemvArgs a = {}; a.w[0] = wo[l]; a.M = d; a.K = d; a.x = attn; a.resid = xres; a.y = yo; return a; };
+        for (uint32_t spin : {300u, 400u}) {
+            // two kernels, as today (product shape: 256 threads for K = 4096)
+            {
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+                for (int l = 0; l < L; ++l) { hipLaunchKernelGGL(k_spin_heads, dim3(H), dim3(PTH), 0, st, spin, attn); hipLaunchKernelGGL(K_a256, dim3(nCU), dim3(256), FAT, st, ga(l)); }
+                CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                float ms = time_ms([&] { CK(hipGraphLaunch(ge, st)); }, 5);
+                printf("  heads(spin %u ticks) ; wo as two kernels                      %8.3f ms  %7.2f us/layer\n", spin, ms, ms * 1e3 / L);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            }
+            {
+                hipGraph_t g; hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+                for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k_spin_heads, dim3(H), dim3(PTH), 0, st, spin, attn);
+                CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                float ms = time_ms([&] { CK(hipGraphLaunch(ge, st)); }, 5);
+                printf("  heads(spin %u ticks) alone                                    %8.3f ms  %7.2f us/layer\n", spin, ms, ms * 1e3 / L);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+            }
+#define AW(NP_, U_) { auto k = k_aw_probe<NP_, U_>; CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P_LDS_BYTES)); \
+                hipGraph_t g; hipGraphExec_t ge; CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed)); \
+                for (int l = 0; l < L; ++l) hipLaunchKernelGGL(k, dim3(H + nCU), dim3(PTH), P_LDS_BYTES, st, ga(l), c, sy, H, spin, attn); \
+                CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0)); \
+                float ms = time_ms([&] { CK(hipGraphLaunch(ge, st)); }, 5); \
+                uint32_t err; CK(hipMemcpy(&err, exN.err, 4, hipMemcpyDeviceToHost)); unsigned hs[64]; CK(hipMemcpy(hs, sync, 256, hipMemcpyDeviceToHost)); \
+                printf("  heads(spin %u) || wo in ONE launch, %2d rows parked, ring U=%d     %8.3f ms  %7.2f us/layer  err=%u cnt=%u done=%u\n", spin, NP_, U_, ms, ms * 1e3 / L, err, hs[0], hs[32]); \
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); }
+            AW(16, 1) AW(12, 2) AW(8, 2) AW(4, 2) AW(0, 2)
+
+            {   // forked capture: heads on a second stream, waiting wo on the first
+                static hipStream_t s2 = nullptr; static hipEvent_t ef, ej;
+                if (!s2) { CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&ej, hipEventDisableTiming)); }
+                auto k = k_wo_wait<12, 2>; const size_t lds = 72 * 1024;
+                CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipGraph_t g; hipGraphExec_t ge; CK(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+                for (int l = 0; l < L; ++l) {
+                    CK(hipEventRecord(ef, st)); CK(hipStreamWaitEvent(s2, ef, 0));
+                    hipLaunchKernelGGL(k_heads_arrive, dim3(H), dim3(PTH), 0, s2, spin, attn, sy);
+                    hipLaunchKernelGGL(k, dim3(nCU), dim3(PTH), lds, st, ga(l), c, sy, H);
+                    CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(st, ej, 0));
+                }
+                CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                float ms = time_ms([&] { CK(hipGraphLaunch(ge, st)); }, 5);
+                uint32_t err; CK(hipMemcpy(&err, exN.err, 4, hipMemcpyDeviceToHost)); unsigned hs[64]; CK(hipMemcpy(hs, sync, 256, hipMemcpyDeviceToHost));
+                printf("  heads(spin %u) || wo as two launches, forked graph, 12 parked      %8.3f ms  %7.2f us/layer  err=%u cnt=%u done=%u\n", spin, ms, ms * 1e3 / L, err, hs[0], hs[32]);
+                CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g)); CK(hipMemset(sync, 0, 256)); CK(hipMemset(exN.err, 0, 4));
+            }
+        }
+        // correctness of the fused launch: same y as the two-kernel path with 512 threads
+        {
+            std::vector<float> y1(d), y2(d);
+            hipLaunchKernelGGL(k_spin_heads, dim3(H), dim3(PTH), 0, st, 100u, attn); hipLaunchKernelGGL(K_b2, dim3(nCU), dim3(512), FAT, st, ga(3));
+            CK(hipStreamSynchronize(st)); CK(hipMemcpy(y1.data(), yo, d * 4, hipMemcpyDeviceToHost)); CK(hipMemset(yo, 0, d * 4)); CK(hipMemset(attn, 0, d * 4));
+            auto k = k_aw_probe<12, 2>; hipLaunchKernelGGL(k, dim3(H + nCU), dim3(PTH), P_LDS_BYTES, st, ga(3), c, sy, H, 100u, attn);
+            CK(hipStreamSynchronize(st)); CK(hipMemcpy(y2.data(), yo, d * 4, hipMemcpyDeviceToHost));
+            printf("  fused launch result vs two kernels: %s\n", memcmp(y1.data(), y2.data(), d * 4) ? "MISMATCH" : "bit-exact");
+        }
+    }
     printf("done\n");
     return 0;
 }
