@@ -1,0 +1,194 @@
+// csrc/kernels_stream.h — weight-streaming GEMM for SHORT prompts of 9..64 token rows (fp32):  Y[n][M] = X[n][K] . W[M][K]^T (+ R).
+//
+// Reference: server.Do feeds the whole prompt as ONE Eval (pkg/server/server.go:185-192); the matmuls are ComputeForwardMulMatFP32
+// (pkg/ml/ml.go:1976-2098).  Up to ~48 rows one pass over the 26.4 GB of 7B weights is HBM-bound (the fp32 matrix pipe needs 2.7 ms
+// at 32 rows, the stream 4.2 ms), so the kernel is built around the weight stream, like the decode GEMV, and the matrix cores only
+// have to keep up.  Round 2 ran this range on the prefill tile GEMM (k_gemm_glds, 64 x 128 tiles + split-K): its LDS image makes one
+// load instruction touch 8 rows x 128 B and it reached 2.8 TB/s (profiles/r02b_ttft_kernel_trace.txt: 72.7 us per GEMM launch, four
+// per layer, plus a split-K reduce pass each).
+//   * grid = #CU workgroups of 4 waves; a workgroup owns a contiguous block of 16-row tiles of the (grouped) weight matrix and ALL
+//     token columns, so every weight byte is read once and no partial sum leaves the chip (no split-K pass);
+//   * weights travel global -> registers -> LDS: a wave-instruction loads 2 rows x 512 contiguous bytes (non-temporal), two K-chunks
+//     of 128 columns stay in flight in registers (the matrix work of the current chunk runs under them), then ds_write_b128 into a
+//     [rows][128 + 4] image (the pad spreads the 16 rows of a tile over all 64 banks for the operand reads);
+//   * activations the same way into a [columns][128 + 4] image (they come out of L2: every workgroup reads all of X);
+//   * v_mfma_f32_16x16x4_f32: A = 16 weight rows x 4 k, B = 4 k x 16 token columns.  A lane (row or column l & 15, slot l >> 4) takes
+//     one ds_read_b128 = 4 consecutive k of its row / column and feeds them to 4 consecutive MFMAs (MFMA s contracts the k's
+//     16 b + 4 slot + s: any grouping of k's is valid as long as A and B agree).  The 8 k-blocks of a chunk are dealt to the 4 waves
+//     (two each), every wave runs ALL row tiles for its k-blocks: the B operands are read once per k-block and reused across the
+//     tiles, consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue), and the waves are
+//     balanced whatever the tile count;
+//   * after the last chunk the four waves' partial tiles meet in LDS and are added in wave order (bit-reproducible), + residual.
+// Summation order differs from the scalar reference (k interleaved over 4 waves x 4 slots): within 1e-4 like every MFMA path.
+#pragma once
+#include "kernels_llama.h"
+
+namespace lh {
+
+struct StreamArgs {
+    const float* w[3];   // matrices of the group, each [M][K] row-major
+    float* y[3];         // outputs, y[g][c * ldy + row]
+    const float* r[3];   // optional residuals, same layout as y
+    const float* x;      // activations [n][K], row c at x + c * ldx
+    uint32_t groups, M, K, n, ldx, ldy;
+};
+
+constexpr int ST_TH = 256, ST_KC = 128, ST_PITCH = ST_KC + 4;   // threads, K-chunk (floats), LDS row pitch (floats)
+
+__host__ __device__ inline size_t stream_lds_bytes(int maxt, int nct) { return (size_t)(maxt + nct) * 16 * ST_PITCH * 4; }
+
+typedef float f4m __attribute__((ext_vector_type(4)));
+
+// s_waitcnt vmcnt(N) as an instruction the compiler's counter bookkeeping understands (gfx9 encoding)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+
+// Workgroup barrier that waits for this wave's LDS operations (operand reads of the image about to be overwritten) but NOT for its
+// global loads: __syncthreads() would drain the chunks in flight.  The LDS wait is not optional: with one wave per SIMD a write another
+// wave issues behind the barrier can overtake a read this wave issued in front of it but that has not executed yet (seen as wrong
+// sums in some tiles with four column tiles, tests/test_gpu_ops.py::test_mul_mat_weights[11008-256-33]).
+__device__ __forceinline__ void barrier_lds_only() {
+    __builtin_amdgcn_s_waitcnt(0xF | (0x7 << 4) | (0x0 << 8) | (0x3 << 14));   // lgkmcnt(0), vmcnt and expcnt untouched
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int MAXT, int NCT>
+__global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Wt = (float*)smem_raw;                       // [MAXT * 16][ST_PITCH]
+    float* Xt = Wt + (size_t)MAXT * 16 * ST_PITCH;      // [NCT * 16][ST_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
+    const uint32_t t0 = (uint32_t)(((uint64_t)blockIdx.x * T) / gridDim.x), t1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * T) / gridDim.x);
+    if (t1 <= t0) return;
+    const uint32_t nt = t1 - t0;                        // <= MAXT (host)
+    const uint32_t nch = a.K / ST_KC;
+    typedef const f4 __attribute__((address_space(1))) gf4;
+
+    // ---- this thread's share of a chunk: rows i*8 + (tid >> 5) of the weight image (and columns of the activation image), float4 tid & 31
+    const uint32_t rsub = (uint32_t)tid >> 5, seg = (uint32_t)tid & 31;
+    const float* wp[2 * MAXT];
+#pragma unroll
+    for (int i = 0; i < 2 * MAXT; ++i) {
+        uint32_t rr = (uint32_t)i * 8 + rsub;
+        rr = rr < nt * 16 ? rr : nt * 16 - 1;            // rows past this workgroup's tiles: a duplicate load, never used
+        const uint32_t v = t0 * 16 + rr, g = v / a.M, row = v - g * a.M;
+        const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
+        wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
+    }
+    const float* xp[2 * NCT];
+#pragma unroll
+    for (int i = 0; i < 2 * NCT; ++i) {
+        uint32_t c = (uint32_t)i * 8 + rsub;
+        c = c < a.n ? c : a.n - 1;
+        xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
+    }
+    f4 wa[2 * MAXT], xa[2 * NCT], wb[2 * MAXT], xb[2 * NCT];
+    auto issue = [&](f4 (&wr)[2 * MAXT], f4 (&xr)[2 * NCT], uint32_t ch) {
+        const uint32_t k0 = (ch < nch ? ch : nch - 1) * ST_KC;      // past the end: the last chunk again (never stored)
+#pragma unroll
+        for (int i = 0; i < 2 * MAXT; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0));
+#pragma unroll
+        for (int i = 0; i < 2 * NCT; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
+    };
+    auto stash = [&](const f4 (&wr)[2 * MAXT], const f4 (&xr)[2 * NCT]) {
+#pragma unroll
+        for (int i = 0; i < 2 * MAXT; ++i) *(f4*)(Wt + (size_t)(i * 8 + rsub) * ST_PITCH + seg * 4) = wr[i];
+#pragma unroll
+        for (int i = 0; i < 2 * NCT; ++i) *(f4*)(Xt + (size_t)(i * 8 + rsub) * ST_PITCH + seg * 4) = xr[i];
+    };
+    f4m acc[MAXT][NCT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+    const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
+    auto compute = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t koff = (uint32_t)(2 * wave + h) * 16 + slot * 4;
+            f4 bf[NCT], af[MAXT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bf[c] = *(const f4*)(Xt + (size_t)(c * 16 + r16) * ST_PITCH + koff);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) af[t] = *(const f4*)(Wt + (size_t)(t * 16 + r16) * ST_PITCH + koff);
+            // Straight-line: all MAXT tiles, also the ones past this workgroup's count (their image rows hold a duplicate of the last
+            // row and their sums are dropped).  A branch per tile kept the operand reads next to their MFMAs (LDS latency exposed)
+            // and made the compiler drain ALL loads in flight at the loop head; the matrix pipe has the slack (<= 65 % busy).
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[c][s], acc[t][c], 0, 0, 0);
+        }
+    };
+    // ---- main stream: two chunks in flight in registers, one in LDS under the matrix cores
+    // (the chunk count is even - host check - so the loop body is the same straight line every time and the compiler can count the
+    // loads in flight: the wait in front of a stash leaves the OTHER register set's chunk in flight)
+    constexpr int PER_SET = 2 * MAXT + 2 * NCT;
+    issue(wa, xa, 0);
+    __builtin_amdgcn_sched_barrier(0);   // keep the issue order: the scheduler swapped the two groups, and the first stash then had to drain both
+    issue(wb, xb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (uint32_t ch = 0; ch < nch; ch += 2) {
+        barrier_lds_only();              // everybody is done with the image of the previous chunk
+        wait_vm<PER_SET>();
+        stash(wa, xa);
+        issue(wa, xa, ch + 2);
+        __syncthreads();
+        compute();
+        barrier_lds_only();
+        wait_vm<PER_SET>();
+        stash(wb, xb);
+        issue(wb, xb, ch + 3);
+        __syncthreads();
+        compute();
+    }
+    __syncthreads();
+    // ---- the four waves' partial tiles meet in LDS: part[tile in batch][wave][column][16 rows]; thread (column, row quad) adds them in wave order
+    constexpr int NC = NCT * 16;
+    float* part = (float*)smem_raw;
+    constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
+    const uint32_t batch = (uint32_t)(stream_lds_bytes(MAXT, NCT) / (TILE_FLOATS * 4));   // >= 1: (MAXT + NCT) * 16 * 132 >= 64 * NCT * 16
+    for (uint32_t tb = 0; tb < nt; tb += batch) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+                    *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)wave * NC + c * 16 + r16) * 16 + slot * 4) = acc[t][c];
+            }
+        }
+        __syncthreads();
+        const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
+        if (col < (uint32_t)NC && col < a.n) {
+            for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
+                const float* p = part + (size_t)(t - tb) * TILE_FLOATS + (size_t)col * 16 + quad * 4;
+                f4 s = *(const f4*)p;
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
+                    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+                }
+                const uint32_t v = (t0 + t) * 16 + quad * 4, g = v / a.M, row = v - g * a.M;
+                const size_t o = (size_t)col * a.ldy + row;
+                const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
+                float* yp = g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2]);
+                if (rp) {
+                    const f4 rv = *(const f4*)(rp + o);
+                    s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
+                }
+                *(f4*)(yp + o) = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace lh

@@ -9,6 +9,7 @@
 #include "kernels_attn.h"
 #include "kernels_sample.h"
 #include "kernels_decode_persist.h"
+#include "kernels_stream.h"
 #include <math.h>
 #include <algorithm>
 
@@ -414,8 +415,56 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 
 // groups (<= 3) weight matrices of equal shape multiplied with the same X in ONE launch (wq|wk|wv, w1|w3): more tiles per
 // launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
+// ---- short prompts, 9..64 rows: the weight-streaming MFMA kernel (kernels_stream.h) ------------------------------------------------
+static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 1); return v != 0; }
+static constexpr uint32_t STREAM_MAX_ROWS = 64;
+
+template <int MAXT, int NCT>
+static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    static bool flags[16] = {};
+    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT), 82 * 1024);   // one workgroup per CU, every CU an equal share of the rows
+    int rc = set_lds_once(ctx, k_stream_mm<MAXT, NCT>, lds, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
+    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+template <int MAXT>
+static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    if (a.n <= 16) return launch_stream<MAXT, 1>(ctx, a, name);
+    if (a.n <= 32) return launch_stream<MAXT, 2>(ctx, a, name);
+    return launch_stream<MAXT, 4>(ctx, a, name);
+}
+// returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
+static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
+                             uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
+    if (!stream_mm_on() || n > STREAM_MAX_ROWS || groups > 3 || M % 16 || K % (2 * ST_KC) || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups, maxt = (T + ncu - 1) / ncu;
+    if (maxt > 8) return -1;
+    StreamArgs a = {};
+    a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy;
+    for (uint32_t g = 0; g < groups; ++g) {
+        a.w[g] = w[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr;
+        if (((uintptr_t)w[g] & 15) || ((uintptr_t)y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15))) return -1;
+    }
+    switch (maxt) {
+        case 1: return launch_stream_n<1>(ctx, a, name);
+        case 2: return launch_stream_n<2>(ctx, a, name);
+        case 3: return launch_stream_n<3>(ctx, a, name);
+        case 4: return launch_stream_n<4>(ctx, a, name);
+        case 5: case 6: return launch_stream_n<6>(ctx, a, name);
+        default: return launch_stream_n<8>(ctx, a, name);
+    }
+}
+
 int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                     uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
+    if (n <= STREAM_MAX_ROWS) {
+        const int rs = gemm_stream_group(ctx, x, ldx, groups, w, y, r, M, K, n, ldy, name);
+        if (rs >= 0) return rs;
+    }
     GemmArgs a = {};
     a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) { a.w[g] = w[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }

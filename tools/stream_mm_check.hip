@@ -1,0 +1,47 @@
+// tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
+// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [MAXT]
+#include "../llama.go_amd/csrc/kernels_stream.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+using namespace lh;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
+    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT), 82 * 1024);
+    CK(hipFuncSetAttribute((const void*)k_stream_mm<MAXT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT>), dim3(nCU), dim3(ST_TH), lds, 0, a);
+    CK(hipDeviceSynchronize());
+}
+int main(int argc, char** argv) {
+    const uint32_t M = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 33;
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); const int nCU = p.multiProcessorCount;
+    std::vector<float> W((size_t)M * K), X((size_t)N * K), Y((size_t)N * M);
+    unsigned s = 1; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); };
+    for (auto& v : W) v = rnd(); for (auto& v : X) v = rnd();
+    float *dW, *dX, *dY; CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dY, Y.size() * 4));
+    CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dY, 0xFF, Y.size() * 4));
+    StreamArgs a = {}; a.w[0] = dW; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M;
+    const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
+    printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
+#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else run<MT, 4>(a, nCU); }
+    if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
+    CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0; const uint32_t CT = (N + 15) / 16;
+    std::vector<double> blk((size_t)T * CT, 0.0);
+    for (uint32_t c = 0; c < N; ++c) for (uint32_t r = 0; r < M; ++r) {
+        double ref = 0; for (uint32_t k = 0; k < K; ++k) ref += (double)W[(size_t)r * K + k] * X[(size_t)c * K + k];
+        const double e = fabs(ref - Y[(size_t)c * M + r]); worst = e > worst ? e : worst;
+        double& b = blk[(size_t)(r / 16) * CT + c / 16]; b = e > b ? e : b;
+    }
+    printf("max abs err %.3e (values ~ %.1f)\nblock map (rows = 16-row tiles, columns = 16-column tiles; x = wrong):\n", worst, sqrt((double)K) / 3);
+    for (uint32_t t = 0; t < T && t < 40; ++t) { printf("  tile %3u ", t); for (uint32_t c = 0; c < CT; ++c) printf("%c", blk[(size_t)t * CT + c] > 1e-3 * sqrt((double)K) ? 'x' : '.'); printf("\n"); }
+    // element map of the first wrong block
+    for (uint32_t t = 0; t < T; ++t) for (uint32_t c = 0; c < CT; ++c) if (blk[(size_t)t * CT + c] > 1e-3 * sqrt((double)K)) {
+        printf("first wrong block: tile %u column tile %u (rows down, columns across; x = wrong)\n", t, c);
+        for (uint32_t r = 0; r < 16; ++r) { printf("   "); for (uint32_t j = 0; j < 16 && c * 16 + j < N; ++j) {
+            double ref = 0; for (uint32_t k = 0; k < K; ++k) ref += (double)W[(size_t)(t * 16 + r) * K + k] * X[(size_t)(c * 16 + j) * K + k];
+            printf("%c", fabs(ref - Y[(size_t)(c * 16 + j) * M + t * 16 + r]) > 1e-3 * sqrt((double)K) ? 'x' : '.'); } printf("\n"); }
+        return 0; }
+    return 0;
+}
