@@ -8,14 +8,16 @@
 // per layer, plus a split-K reduce pass each).
 //   * grid = #CU workgroups of 4 waves; a workgroup owns a contiguous block of 16-row tiles of the (grouped) weight matrix and ALL
 //     token columns, so every weight byte is read once and no partial sum leaves the chip (no split-K pass);
-//   * weights travel global -> registers -> LDS: a wave-instruction loads 2 rows x 512 contiguous bytes (non-temporal), two K-chunks
-//     of 128 columns stay in flight in registers (the matrix work of the current chunk runs under them), then ds_write_b128 into a
-//     [rows][128 + 4] image (the pad spreads the 16 rows of a tile over all 64 banks for the operand reads);
-//   * activations the same way into a [columns][128 + 4] image (they come out of L2: every workgroup reads all of X);
+//   * weights travel global -> registers -> LDS in K-chunks of KC = 128 / 256 / 512 columns (the host picks the largest that fits the
+//     registers and LDS: few-row matrices like wo and w2 need the long chunks to have enough HBM bytes in flight): a wave-instruction
+//     loads 1 KB contiguous of ONE row from KC = 256 on (2 rows x 512 B at 128), non-temporal; two chunks stay in flight in registers
+//     (the matrix work of the current chunk runs under them), then ds_write_b128 into a [rows][KC + 4] image (the pad spreads the 16
+//     rows of a tile over all 64 banks for the operand reads);
+//   * activations the same way into a [columns][KC + 4] image (they come out of L2: every workgroup reads all of X);
 //   * v_mfma_f32_16x16x4_f32: A = 16 weight rows x 4 k, B = 4 k x 16 token columns.  A lane (row or column l & 15, slot l >> 4) takes
 //     one ds_read_b128 = 4 consecutive k of its row / column and feeds them to 4 consecutive MFMAs (MFMA s contracts the k's
-//     16 b + 4 slot + s: any grouping of k's is valid as long as A and B agree).  The 8 k-blocks of a chunk are dealt to the 4 waves
-//     (two each), every wave runs ALL row tiles for its k-blocks: the B operands are read once per k-block and reused across the
+//     16 b + 4 slot + s: any grouping of k's is valid as long as A and B agree).  The KC / 16 k-blocks of a chunk are dealt to the 4 waves,
+//     every wave runs ALL row tiles for its k-blocks: the B operands are read once per k-block and reused across the
 //     tiles, consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue), and the waves are
 //     balanced whatever the tile count;
 //   * after the last chunk the four waves' partial tiles meet in LDS and are added in wave order (bit-reproducible), + residual.
@@ -31,11 +33,13 @@ struct StreamArgs {
     const float* r[3];   // optional residuals, same layout as y
     const float* x;      // activations [n][K], row c at x + c * ldx
     uint32_t groups, M, K, n, ldx, ldy;
+    uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
+                         // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
 
-constexpr int ST_TH = 256, ST_KC = 128, ST_PITCH = ST_KC + 4;   // threads, K-chunk (floats), LDS row pitch (floats)
+constexpr int ST_TH = 256;   // threads; the K-chunk KC (floats per row and step) is a template parameter, LDS row pitch KC + 4 floats
 
-__host__ __device__ inline size_t stream_lds_bytes(int maxt, int nct) { return (size_t)(maxt + nct) * 16 * ST_PITCH * 4; }
+__host__ __device__ inline size_t stream_lds_bytes(int maxt, int nct, int kc) { return (size_t)(maxt + nct) * 16 * (kc + 4) * 4; }
 
 typedef float f4m __attribute__((ext_vector_type(4)));
 
@@ -56,8 +60,12 @@ __device__ __forceinline__ void barrier_lds_only() {
     asm volatile("" ::: "memory");
 }
 
-template <int MAXT, int NCT>
+template <int MAXT, int NCT, int KC>
 __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
+    static_assert(KC == 128 || KC == 256 || KC == 512, "chunk");
+    constexpr int ST_KC = KC, ST_PITCH = KC + 4;
+    constexpr int RPP = 1024 / KC;                      // image rows one pass of the 256 threads covers (a wave: 64 x 16 B of ONE row from KC = 256)
+    constexpr int NW = MAXT * 16 / RPP, NX = NCT * 16 / RPP;   // float4 per thread and chunk: weights, activations
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* Wt = (float*)smem_raw;                       // [MAXT * 16][ST_PITCH]
     float* Xt = Wt + (size_t)MAXT * 16 * ST_PITCH;      // [NCT * 16][ST_PITCH]
@@ -71,72 +79,90 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
     typedef const f4 __attribute__((address_space(1))) gf4;
 
     // ---- this thread's share of a chunk: rows i*8 + (tid >> 5) of the weight image (and columns of the activation image), float4 tid & 31
-    const uint32_t rsub = (uint32_t)tid >> 5, seg = (uint32_t)tid & 31;
-    const float* wp[2 * MAXT];
+    const uint32_t rsub = (uint32_t)tid / (KC / 4), seg = (uint32_t)tid % (KC / 4);
+    const float* wp[NW];
 #pragma unroll
-    for (int i = 0; i < 2 * MAXT; ++i) {
-        uint32_t rr = (uint32_t)i * 8 + rsub;
+    for (int i = 0; i < NW; ++i) {
+        uint32_t rr = (uint32_t)i * RPP + rsub;
         rr = rr < nt * 16 ? rr : nt * 16 - 1;            // rows past this workgroup's tiles: a duplicate load, never used
         const uint32_t v = t0 * 16 + rr, g = v / a.M, row = v - g * a.M;
         const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
-        wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
+        wp[i] = (const float*)base + (a.tiled ? (size_t)row * KC : (size_t)row * a.K) + seg * 4;
     }
-    const float* xp[2 * NCT];
+    const size_t wstep = a.tiled ? (size_t)a.M * KC : (size_t)KC;   // floats between consecutive chunks of a row
+    const float* xp[NX];
 #pragma unroll
-    for (int i = 0; i < 2 * NCT; ++i) {
-        uint32_t c = (uint32_t)i * 8 + rsub;
+    for (int i = 0; i < NX; ++i) {
+        uint32_t c = (uint32_t)i * RPP + rsub;
         c = c < a.n ? c : a.n - 1;
         xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
     }
-    f4 wa[2 * MAXT], xa[2 * NCT], wb[2 * MAXT], xb[2 * NCT];
-    auto issue = [&](f4 (&wr)[2 * MAXT], f4 (&xr)[2 * NCT], uint32_t ch) {
-        const uint32_t k0 = (ch < nch ? ch : nch - 1) * ST_KC;      // past the end: the last chunk again (never stored)
+    f4 wa[NW], xa[NX], wb[NW], xb[NX];
+    auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], uint32_t ch) {
+        const uint32_t cc = ch < nch ? ch : nch - 1;                // past the end: the last chunk again (never stored)
+        const uint32_t k0 = cc * ST_KC;
+        const size_t w0 = (size_t)cc * wstep;
 #pragma unroll
-        for (int i = 0; i < 2 * MAXT; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0));
+        for (int i = 0; i < NW; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + w0));
 #pragma unroll
-        for (int i = 0; i < 2 * NCT; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
+        for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
     };
-    auto stash = [&](const f4 (&wr)[2 * MAXT], const f4 (&xr)[2 * NCT]) {
+    auto stash = [&](const f4 (&wr)[NW], const f4 (&xr)[NX]) {
 #pragma unroll
-        for (int i = 0; i < 2 * MAXT; ++i) *(f4*)(Wt + (size_t)(i * 8 + rsub) * ST_PITCH + seg * 4) = wr[i];
+        for (int i = 0; i < NW; ++i) *(f4*)(Wt + (size_t)(i * RPP + rsub) * ST_PITCH + seg * 4) = wr[i];
 #pragma unroll
-        for (int i = 0; i < 2 * NCT; ++i) *(f4*)(Xt + (size_t)(i * 8 + rsub) * ST_PITCH + seg * 4) = xr[i];
+        for (int i = 0; i < NX; ++i) *(f4*)(Xt + (size_t)(i * RPP + rsub) * ST_PITCH + seg * 4) = xr[i];
     };
-    f4m acc[MAXT][NCT];
+    // KA independent accumulator sets per (tile, column tile), k-blocks dealt to them in turn: with one or two tiles a single
+    // accumulator makes every MFMA wait for its predecessor (40 cycles dependent vs 32 issue) and the chunk's matrix work a serial chain
+    constexpr int KB = KC / 64;                         // k-blocks of a chunk per wave
+    constexpr int KA0 = (MAXT * NCT >= 4) ? 1 : (MAXT * NCT >= 2 ? 2 : 4), KA = KA0 < KB ? KA0 : KB;
+    f4m acc[KA][MAXT][NCT];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
+    for (int q = 0; q < KA; ++q)
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[q][t][c] = f4m{0.f, 0.f, 0.f, 0.f};
     const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
     auto compute = [&]() {
+        // Straight-line: all MAXT tiles, also the ones past this workgroup's count (their image rows hold a duplicate of the last
+        // row and their sums are dropped).  A branch per tile kept the operand reads next to their MFMAs (LDS latency exposed)
+        // and made the compiler drain ALL loads in flight at the loop head; the matrix pipe has the slack (<= 65 % busy).
+        // Operands of a pair of k-blocks are read together, ahead of their MFMAs.
+        constexpr int HB = KB >= 2 ? 2 : 1;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t koff = (uint32_t)(2 * wave + h) * 16 + slot * 4;
-            f4 bf[NCT], af[MAXT];
+        for (int h0 = 0; h0 < KB; h0 += HB) {
+            f4 bf[HB][NCT], af[HB][MAXT];
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) bf[c] = *(const f4*)(Xt + (size_t)(c * 16 + r16) * ST_PITCH + koff);
+            for (int hh = 0; hh < HB; ++hh) {
+                const uint32_t koff = (uint32_t)(KB * wave + h0 + hh) * 16 + slot * 4;
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) af[t] = *(const f4*)(Wt + (size_t)(t * 16 + r16) * ST_PITCH + koff);
-            // Straight-line: all MAXT tiles, also the ones past this workgroup's count (their image rows hold a duplicate of the last
-            // row and their sums are dropped).  A branch per tile kept the operand reads next to their MFMAs (LDS latency exposed)
-            // and made the compiler drain ALL loads in flight at the loop head; the matrix pipe has the slack (<= 65 % busy).
+                for (int c = 0; c < NCT; ++c) bf[hh][c] = *(const f4*)(Xt + (size_t)(c * 16 + r16) * ST_PITCH + koff);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) af[hh][t] = *(const f4*)(Wt + (size_t)(t * 16 + r16) * ST_PITCH + koff);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < MAXT; ++t)
+                for (int hh = 0; hh < HB; ++hh)
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[c][s], acc[t][c], 0, 0, 0);
+                    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c)
+                            acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
         }
     };
     // ---- main stream: two chunks in flight in registers, one in LDS under the matrix cores
     // (the chunk count is even - host check - so the loop body is the same straight line every time and the compiler can count the
     // loads in flight: the wait in front of a stash leaves the OTHER register set's chunk in flight)
-    constexpr int PER_SET = 2 * MAXT + 2 * NCT;
+    constexpr int PER_SET = NW + NX;
+    static_assert(PER_SET < 64, "vmcnt range");
     issue(wa, xa, 0);
     __builtin_amdgcn_sched_barrier(0);   // keep the issue order: the scheduler swapped the two groups, and the first stash then had to drain both
     issue(wb, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
-    for (uint32_t ch = 0; ch < nch; ch += 2) {
+    for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
         barrier_lds_only();              // everybody is done with the image of the previous chunk
         wait_vm<PER_SET>();
         stash(wa, xa);
@@ -150,19 +176,30 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
         __syncthreads();
         compute();
     }
+    if (nch & 1) {                       // odd chunk count: the last chunk sits in the first register set
+        barrier_lds_only();
+        wait_vm<PER_SET>();
+        stash(wa, xa);
+        __syncthreads();
+        compute();
+    }
     __syncthreads();
     // ---- the four waves' partial tiles meet in LDS: part[tile in batch][wave][column][16 rows]; thread (column, row quad) adds them in wave order
     constexpr int NC = NCT * 16;
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
-    const uint32_t batch = (uint32_t)(stream_lds_bytes(MAXT, NCT) / (TILE_FLOATS * 4));   // >= 1: (MAXT + NCT) * 16 * 132 >= 64 * NCT * 16
+    const uint32_t batch = (uint32_t)(stream_lds_bytes(MAXT, NCT, KC) / (TILE_FLOATS * 4));   // >= 1: (MAXT + NCT) * 16 * 132 >= 64 * NCT * 16
     for (uint32_t tb = 0; tb < nt; tb += batch) {
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
 #pragma unroll
-                for (int c = 0; c < NCT; ++c)
-                    *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)wave * NC + c * 16 + r16) * 16 + slot * 4) = acc[t][c];
+                for (int c = 0; c < NCT; ++c) {
+                    f4m v = acc[0][t][c];
+#pragma unroll
+                    for (int q = 1; q < KA; ++q) v += acc[q][t][c];
+                    *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)wave * NC + c * 16 + r16) * 16 + slot * 4) = v;
+                }
             }
         }
         __syncthreads();

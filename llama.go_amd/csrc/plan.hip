@@ -417,30 +417,36 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
 // ---- short prompts, 9..64 rows: the weight-streaming MFMA kernel (kernels_stream.h) ------------------------------------------------
 static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 1); return v != 0; }
-static constexpr uint32_t STREAM_MAX_ROWS = 64;
+static constexpr uint32_t STREAM_MAX_ROWS = 32;   // 33..64 rows: the matrix pipe, not the stream, is the limit - the tile GEMM is faster there (13.5 vs 11.8 ms at 64)
 
-template <int MAXT, int NCT>
+template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     static bool flags[16] = {};
-    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT), 82 * 1024);   // one workgroup per CU, every CU an equal share of the rows
-    int rc = set_lds_once(ctx, k_stream_mm<MAXT, NCT>, lds, flags);
+    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU, every CU an equal share of the rows
+    int rc = set_lds_once(ctx, k_stream_mm<MAXT, NCT, KC>, lds, flags);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
-    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
+// K-chunk: 128 columns.  Longer chunks (a whole 1 KB of ONE row per load instruction from 256 on, more bytes in flight for the few-row
+// matrices) measured slower on every 7B shape (tools/stream_mm_check: wo 16.7 / 17.6 / 21.3 us, w1|w3 72.9 / 80.0 us at 128 / 256 /
+// 512), and so did a chunk-major copy of the weights (contiguous runs per workgroup: 2-13 %): profiles/r02b_stream_mm_check.txt.
+template <int MAXT, int NCT>
+static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    return launch_stream<MAXT, NCT, 128>(ctx, a, name);
+}
 template <int MAXT>
 static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    if (a.n <= 16) return launch_stream<MAXT, 1>(ctx, a, name);
-    if (a.n <= 32) return launch_stream<MAXT, 2>(ctx, a, name);
-    return launch_stream<MAXT, 4>(ctx, a, name);
+    if (a.n <= 16) return launch_stream_kc<MAXT, 1>(ctx, a, name);
+    return launch_stream_kc<MAXT, 2>(ctx, a, name);
 }
 // returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                              uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
-    if (!stream_mm_on() || n > STREAM_MAX_ROWS || groups > 3 || M % 16 || K % (2 * ST_KC) || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
+    if (!stream_mm_on() || n > STREAM_MAX_ROWS || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups, maxt = (T + ncu - 1) / ncu;
     if (maxt > 8) return -1;
     StreamArgs a = {};

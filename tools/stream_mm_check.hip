@@ -1,5 +1,5 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
-// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [MAXT]
+// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC]   (N <= 32)
 #include "../llama.go_amd/csrc/kernels_stream.h"
 #include <cstdio>
 #include <cstdlib>
@@ -7,24 +7,43 @@
 #include <cmath>
 using namespace lh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+static int g_kc = 128;
+template <int MAXT, int NCT, int KC> static void run_kc(const StreamArgs& a, int nCU) {
+    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);
+    CK(hipFuncSetAttribute((const void*)k_stream_mm<MAXT, NCT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(nCU), dim3(ST_TH), lds, 0, a);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(nCU), dim3(ST_TH), lds, 0, a);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("k_stream_mm<%d,%d,%d>: %.2f us per launch (same weights every launch: L2 / MALL may help), %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
+}
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
-    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT), 82 * 1024);
-    CK(hipFuncSetAttribute((const void*)k_stream_mm<MAXT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT>), dim3(nCU), dim3(ST_TH), lds, 0, a);
-    CK(hipDeviceSynchronize());
+    constexpr int R = MAXT + NCT;
+    if (g_kc == 512 && R * 512 <= 2048) run_kc<MAXT, NCT, (R * 512 <= 2048 ? 512 : 128)>(a, nCU);
+    else if (g_kc >= 256 && R * 256 <= 2048) run_kc<MAXT, NCT, (R * 256 <= 2048 ? 256 : 128)>(a, nCU);
+    else run_kc<MAXT, NCT, 128>(a, nCU);
 }
 int main(int argc, char** argv) {
     const uint32_t M = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 33;
+    if (argc > 4) g_kc = atoi(argv[4]);
+    const bool tiled = argc > 5 && atoi(argv[5]);
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); const int nCU = p.multiProcessorCount;
     std::vector<float> W((size_t)M * K), X((size_t)N * K), Y((size_t)N * M);
     unsigned s = 1; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); };
     for (auto& v : W) v = rnd(); for (auto& v : X) v = rnd();
     float *dW, *dX, *dY; CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&dX, X.size() * 4)); CK(hipMalloc(&dY, Y.size() * 4));
+    if (tiled) {   // chunk-major copy: [K / KC][M][KC]
+        std::vector<float> Wt_(W.size()); const uint32_t KCc = (uint32_t)g_kc;
+        for (uint32_t r = 0; r < M; ++r) for (uint32_t k = 0; k < K; ++k) Wt_[((size_t)(k / KCc) * M + r) * KCc + k % KCc] = W[(size_t)r * K + k];
+        CK(hipMemcpy(dW, Wt_.data(), W.size() * 4, hipMemcpyHostToDevice));
+    } else
     CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dY, 0xFF, Y.size() * 4));
-    StreamArgs a = {}; a.w[0] = dW; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M;
+    StreamArgs a = {}; a.w[0] = dW; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
     const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
-#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else run<MT, 4>(a, nCU); }
+#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else run<MT, 2>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0; const uint32_t CT = (N + 15) / 16;
