@@ -33,6 +33,9 @@ struct StreamArgs {
     const float* r[3];   // optional residuals, same layout as y
     const float* x;      // activations [n][K], row c at x + c * ldx
     uint32_t groups, M, K, n, ldx, ldy;
+#ifdef STREAM_TRACE
+    unsigned long long* trace;   // tools/stream_mm_check: [4 waves][8] shader-clock totals of workgroup 0's loop phases
+#endif
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
@@ -162,20 +165,39 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
     __builtin_amdgcn_sched_barrier(0);   // keep the issue order: the scheduler swapped the two groups, and the first stash then had to drain both
     issue(wb, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef STREAM_TRACE
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#define ST_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[i] += tn_ - tl; tl = tn_; } while (0)
+#else
+#define ST_STAMP(i) do { } while (0)
+#endif
     for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
         barrier_lds_only();              // everybody is done with the image of the previous chunk
+        ST_STAMP(0);
         wait_vm<PER_SET>();
+        ST_STAMP(1);
         stash(wa, xa);
         issue(wa, xa, ch + 2);
+        ST_STAMP(2);
         __syncthreads();
+        ST_STAMP(3);
         compute();
+        ST_STAMP(4);
         barrier_lds_only();
+        ST_STAMP(0);
         wait_vm<PER_SET>();
+        ST_STAMP(1);
         stash(wb, xb);
         issue(wb, xb, ch + 3);
+        ST_STAMP(2);
         __syncthreads();
+        ST_STAMP(3);
         compute();
+        ST_STAMP(4);
     }
+#ifdef STREAM_TRACE
+    if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
+#endif
     if (nch & 1) {                       // odd chunk count: the last chunk sits in the first register set
         barrier_lds_only();
         wait_vm<PER_SET>();
@@ -227,5 +249,183 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
         __syncthreads();
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_stream_mm2 — the same computation with SPECIALISED waves: 8 waves per workgroup, waves 0-3 only move data (global -> registers ->
+// LDS image), waves 4-7 only run the matrix cores on the image of the previous chunk; two LDS images, ONE workgroup barrier per chunk.
+// Why: in k_stream_mm every wave alternates between issuing a burst of loads and computing.  Its phase trace (tools/stream_mm_check,
+// shader clocks per chunk of w1|w3 at 16 rows: lds-barrier 1647 | wait loads 35 | stash+issue 2991 | barrier 244 | compute 1194) shows
+// that the loads have always landed by the time they are waited for - the time goes into ISSUING them: two chunks per CU are more than
+// the memory pipeline accepts at once, the issue blocks, and with one wave per SIMD a blocked wave also stops feeding its matrix
+// core.  Here a loader wave that blocks costs nothing (that is its job) and the MFMA waves never touch global memory.
+// Same image layout, operand mapping and summation structure as k_stream_mm (4 compute waves x k-blocks, wave order in the epilogue).
+template <int MAXT, int NCT, int KC>
+__global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
+    static_assert(KC == 128 || KC == 256, "chunk");
+    constexpr int ST_PITCH = KC + 4, RPP = 1024 / KC;
+    constexpr int NW = MAXT * 16 / RPP, NX = NCT * 16 / RPP;
+    constexpr size_t IMG = (size_t)(MAXT + NCT) * 16 * ST_PITCH;      // floats per image
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* img = (float*)smem_raw;                      // [2][IMG]: weights [MAXT * 16][PITCH], then activations [NCT * 16][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
+    const uint32_t t0 = (uint32_t)(((uint64_t)blockIdx.x * T) / gridDim.x), t1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * T) / gridDim.x);
+    if (t1 <= t0) return;
+    const uint32_t nt = t1 - t0;
+    const uint32_t nch = a.K / KC;
+    typedef const f4 __attribute__((address_space(1))) gf4;
+    constexpr int KB = KC / 64;
+    constexpr int KA0 = (MAXT * NCT >= 4) ? 1 : (MAXT * NCT >= 2 ? 2 : 4), KA = KA0 < KB ? KA0 : KB;
+    f4m acc[KA][MAXT][NCT];
+    const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
+    if (wave < 4) {
+        // ---- loader waves
+        const uint32_t rsub = (uint32_t)tid / (KC / 4), seg = (uint32_t)tid % (KC / 4);
+        const float* wp[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            uint32_t rr = (uint32_t)i * RPP + rsub;
+            rr = rr < nt * 16 ? rr : nt * 16 - 1;
+            const uint32_t v = t0 * 16 + rr, g = v / a.M, row = v - g * a.M;
+            const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
+            wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
+        }
+        const float* xp[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            uint32_t c = (uint32_t)i * RPP + rsub;
+            c = c < a.n ? c : a.n - 1;
+            xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
+        }
+        f4 wa[NW], xa[NX], wb[NW], xb[NX];
+        auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], uint32_t ch) {
+            const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0));
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
+        };
+        auto stash = [&](const f4 (&wr)[NW], const f4 (&xr)[NX], float* im) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) *(f4*)(im + (size_t)(i * RPP + rsub) * ST_PITCH + seg * 4) = wr[i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) *(f4*)(im + (size_t)(MAXT * 16 + i * RPP + rsub) * ST_PITCH + seg * 4) = xr[i];
+        };
+        constexpr int PER_SET = NW + NX;
+        static_assert(PER_SET < 64, "vmcnt range");
+        issue(wa, xa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(wb, xb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
+            wait_vm<PER_SET>();
+            stash(wa, xa, img);
+            issue(wa, xa, ch + 2);
+            __syncthreads();             // barrier `ch`: image 0 holds chunk ch; the compute waves are done with it as chunk ch - 2
+            wait_vm<PER_SET>();
+            stash(wb, xb, img + IMG);
+            issue(wb, xb, ch + 3);
+            __syncthreads();             // barrier `ch + 1`
+        }
+        if (nch & 1) {
+            wait_vm<PER_SET>();
+            stash(wa, xa, img);
+            __syncthreads();
+        }
+        wait_vm<0>();                    // the clamped tail loads
+    } else {
+        // ---- compute waves
+        const int cw = wave - 4;
+#pragma unroll
+        for (int q = 0; q < KA; ++q)
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[q][t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+        auto compute = [&](const float* im) {
+            const float* Wt = im;
+            const float* Xt = im + (size_t)MAXT * 16 * ST_PITCH;
+            constexpr int HB = KB >= 2 ? 2 : 1;
+#pragma unroll
+            for (int h0 = 0; h0 < KB; h0 += HB) {
+                f4 bf[HB][NCT], af[HB][MAXT];
+#pragma unroll
+                for (int hh = 0; hh < HB; ++hh) {
+                    const uint32_t koff = (uint32_t)(KB * cw + h0 + hh) * 16 + slot * 4;
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) bf[hh][c] = *(const f4*)(Xt + (size_t)(c * 16 + r16) * ST_PITCH + koff);
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) af[hh][t] = *(const f4*)(Wt + (size_t)(t * 16 + r16) * ST_PITCH + koff);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int hh = 0; hh < HB; ++hh)
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                            for (int c = 0; c < NCT; ++c)
+                                acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
+            }
+        };
+        for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
+            __syncthreads();             // barrier `ch`
+            compute(img);
+            __syncthreads();             // barrier `ch + 1`
+            compute(img + IMG);
+        }
+        if (nch & 1) {
+            __syncthreads();
+            compute(img);
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: as in k_stream_mm, the partial tiles of the four compute waves
+    constexpr int NC = NCT * 16;
+    float* part = (float*)smem_raw;
+    constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
+    const uint32_t batch = (uint32_t)(2 * IMG / TILE_FLOATS);
+    for (uint32_t tb = 0; tb < nt; tb += batch) {
+        if (wave >= 4) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) {
+                        f4m v = acc[0][t][c];
+#pragma unroll
+                        for (int q = 1; q < KA; ++q) v += acc[q][t][c];
+                        *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)(wave - 4) * NC + c * 16 + r16) * 16 + slot * 4) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
+        if (col < (uint32_t)NC && col < a.n) {
+            for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
+                const float* p = part + (size_t)(t - tb) * TILE_FLOATS + (size_t)col * 16 + quad * 4;
+                f4 s = *(const f4*)p;
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
+                    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+                }
+                const uint32_t v = (t0 + t) * 16 + quad * 4, g = v / a.M, row = v - g * a.M;
+                const size_t o = (size_t)col * a.ldy + row;
+                const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
+                float* yp = g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2]);
+                if (rp) {
+                    const f4 rv = *(const f4*)(rp + o);
+                    s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
+                }
+                *(f4*)(yp + o) = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+__host__ __device__ inline size_t stream2_lds_bytes(int maxt, int nct, int kc) { return 2 * stream_lds_bytes(maxt, nct, kc); }
 
 }  // namespace lh

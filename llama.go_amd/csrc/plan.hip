@@ -417,25 +417,33 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
 // ---- short prompts, 9..64 rows: the weight-streaming MFMA kernel (kernels_stream.h) ------------------------------------------------
 static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 1); return v != 0; }
-static constexpr uint32_t STREAM_MAX_ROWS = 32;   // 33..64 rows: the matrix pipe, not the stream, is the limit - the tile GEMM is faster there (13.5 vs 11.8 ms at 64)
+// 33..64 rows stay on the tile GEMM: with four column tiles every workgroup re-reads more activation bytes out of L2 per chunk than
+// it streams weight bytes from HBM, and the matrix pipe is the limit anyway (measured 11.4-11.9 ms either way at 33..64 rows)
+static constexpr uint32_t STREAM_MAX_ROWS = 32;
 
 template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    static bool flags[16] = {};
-    const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU, every CU an equal share of the rows
-    int rc = set_lds_once(ctx, k_stream_mm<MAXT, NCT, KC>, lds, flags);
+    static bool flags[2][16] = {};
+    // wave-specialised variant (loader waves + MFMA waves, two LDS images) whenever the two images fit; LLAMAHIP_STREAM_MM=1 forces the
+    // first variant (every wave loads and computes) for A/B runs
+    static const bool v1_only = env_int("LLAMAHIP_STREAM_MM", 2) == 1;
+    const bool v2 = !v1_only && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
+    const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
+    int rc = v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, (KC <= 256 ? KC : 256)>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT, KC>, lds, flags[0]);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
-    hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
+    if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, (KC <= 256 ? KC : 256)>), dim3(ctx->ds->num_cu), dim3(2 * ST_TH), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
-// K-chunk: 128 columns.  Longer chunks (a whole 1 KB of ONE row per load instruction from 256 on, more bytes in flight for the few-row
-// matrices) measured slower on every 7B shape (tools/stream_mm_check: wo 16.7 / 17.6 / 21.3 us, w1|w3 72.9 / 80.0 us at 128 / 256 /
-// 512), and so did a chunk-major copy of the weights (contiguous runs per workgroup: 2-13 %): profiles/r02b_stream_mm_check.txt.
+// K-chunk: 128 columns; 256 for single-tile workgroups on long rows (w2: 37.5 -> 34.9 us).  Longer chunks (a whole 1 KB of ONE row per
+// load instruction, more bytes in flight) measured slower on the other 7B shapes, and a chunk-major copy of the weights (contiguous
+// runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02b_stream_mm_check.txt.
 template <int MAXT, int NCT>
 static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    if (MAXT == 1 && a.K > 4096 && a.K % 256 == 0) return launch_stream<MAXT, NCT, (MAXT == 1 ? 256 : 128)>(ctx, a, name);
     return launch_stream<MAXT, NCT, 128>(ctx, a, name);
 }
 template <int MAXT>
@@ -503,6 +511,10 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
     // from 9 rows on the MFMA GEMM (64-row tiles, split-K) beats two or more passes of the 8-column weight stream (7B, one Eval:
     // 8 rows 10.0 ms and 16 rows 18.4 ms on the stream; 17 rows 11.1 ms on the MFMA path)
     if (n >= MFMA_MIN_ROWS && K % GBK == 0 && ldx % 4 == 0) return gemm_mfma(ctx, w, x, y, resid, M, K, n, ldx, ldy, name);
+    if (n >= 2) {   // 2..8 rows on the general path (LLAMAHIP_SKINNY=0 or a shape k_skinny is not built for): the streaming MFMA kernel
+        const int rs = gemm_stream_group(ctx, x, ldx, 1, &w, &y, resid ? &resid : nullptr, M, K, n, ldy, name);
+        if (rs >= 0) return rs;
+    }
     const uint32_t K4 = K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
     const uint32_t NCmax = ki <= 2 ? 8 : 4;
@@ -529,6 +541,13 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
 static constexpr uint32_t SKINNY_NP = 8, SKINNY_KC_MAX = 4096;
 static bool skinny_on() { static const int v = env_int("LLAMAHIP_SKINNY", 1); return v != 0; }
 // shapes the kernel is built for: every contraction length a whole number of ring groups (256 floats), RoPE pairs inside a head
+// whole-model check for the streaming MFMA kernel (the 2..8-row prompts prefer it over k_skinny: 6.0 vs 6.5 ms on 7B)
+static bool stream_shape_ok(lh_ctx* ctx, const ModelDesc& m) {
+    if (!stream_mm_on() || m.wtype != 0 || m.d % 128 || m.F % 128) return false;
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu;
+    auto maxt = [&](uint32_t rows) { return (rows / 16 + ncu - 1) / ncu; };
+    return maxt(3 * m.d) <= 8 && maxt(2 * m.F) <= 8;
+}
 static bool skinny_ok(const ModelDesc& m, uint32_t n) {
     return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % SK_GRP == 0 && m.F % SK_GRP == 0 && m.hd % 2 == 0;
 }
@@ -1069,7 +1088,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         return 0;
     }
-    if (skinny_ok(m, n)) {
+    if (skinny_ok(m, n) && !stream_shape_ok(ctx, m)) {   // k_skinny only where the streaming MFMA kernel is not built for the shape
         // ---- short prompt: 4 fused weight passes per layer + the per-query attention kernel (like the decode step, n rows wide)
         const float* x = p->xa;
         if (m.first_stage()) {
@@ -1152,7 +1171,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
         { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
-        const bool mfma = n >= MFMA_MIN_ROWS && d % GBK == 0 && F % GBK == 0;
+        // grouped MFMA launches: from 9 rows (tile GEMM), and from 2 rows when the streaming MFMA kernel takes them (<= 64 rows)
+        const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && stream_mm_on() && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;
         const bool q8 = m.wtype == 7;
         if (q8) {
             const float* ws[3] = {L.wq, L.wk, L.wv};

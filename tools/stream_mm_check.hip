@@ -1,5 +1,6 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
 // (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC]   (N <= 32)
+#define STREAM_TRACE
 #include "../llama.go_amd/csrc/kernels_stream.h"
 #include <cstdio>
 #include <cstdlib>
@@ -17,9 +18,26 @@ template <int MAXT, int NCT, int KC> static void run_kc(const StreamArgs& a, int
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(nCU), dim3(ST_TH), lds, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    { unsigned long long tr[32]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost)); const double nh = (double)(a.K / KC);
+      const char* nm[5] = {"lds-barrier", "wait loads", "stash+issue", "syncthreads", "compute"};
+      for (int w = 0; w < 4; w += 3) { printf("   wave %d, shader clocks per chunk:", w); for (int i = 0; i < 5; ++i) printf(" %s %.0f |", nm[i], tr[w * 8 + i] / nh); printf("\n"); } }
     printf("k_stream_mm<%d,%d,%d>: %.2f us per launch (same weights every launch: L2 / MALL may help), %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
 }
+template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, int nCU) {
+    const size_t lds = std::max<size_t>(stream2_lds_bytes(MAXT, NCT, KC), 82 * 1024);
+    if (lds > 160 * 1024) { printf("k_stream_mm2<%d,%d,%d>: images do not fit\n", MAXT, NCT, KC); return; }
+    CK(hipFuncSetAttribute((const void*)k_stream_mm2<MAXT, NCT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC>), dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC>), dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("k_stream_mm2<%d,%d,%d> (specialised waves): %.2f us per launch, %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
+}
+static int g_v2 = 0;
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
+    if (g_v2) { if (g_kc >= 256) run2_kc<MAXT, NCT, 256>(a, nCU); else run2_kc<MAXT, NCT, 128>(a, nCU); return; }
     constexpr int R = MAXT + NCT;
     if (g_kc == 512 && R * 512 <= 2048) run_kc<MAXT, NCT, (R * 512 <= 2048 ? 512 : 128)>(a, nCU);
     else if (g_kc >= 256 && R * 256 <= 2048) run_kc<MAXT, NCT, (R * 256 <= 2048 ? 256 : 128)>(a, nCU);
@@ -28,7 +46,8 @@ template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
 int main(int argc, char** argv) {
     const uint32_t M = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 33;
     if (argc > 4) g_kc = atoi(argv[4]);
-    const bool tiled = argc > 5 && atoi(argv[5]);
+    const bool tiled = argc > 5 && atoi(argv[5]) == 1;
+    g_v2 = argc > 5 && atoi(argv[5]) == 2;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); const int nCU = p.multiProcessorCount;
     std::vector<float> W((size_t)M * K), X((size_t)N * K), Y((size_t)N * M);
     unsigned s = 1; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); };
@@ -41,6 +60,7 @@ int main(int argc, char** argv) {
     } else
     CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dY, 0xFF, Y.size() * 4));
     StreamArgs a = {}; a.w[0] = dW; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
+    CK(hipMalloc(&a.trace, 256)); CK(hipMemset(a.trace, 0, 256));
     const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
 #define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else run<MT, 2>(a, nCU); }
