@@ -298,7 +298,11 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             c = c < a.n ? c : a.n - 1;
             xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
         }
-        f4 wa[NW], xa[NX], wb[NW], xb[NX];
+        // NS register sets = chunks in flight.  Four instead of two for the single-tile workgroups (wo, w2: 8 KB of weights per chunk
+        // and CU) changed nothing (16.0 vs 16.2 us): those launches are not short of bytes in flight - their weight rate falls with
+        // the share of activation bytes every workgroup pulls out of L2 per weight byte (1 : 1 there, 1 : 6 for w1|w3).
+        constexpr int NS = 2;
+        f4 ws[NS][NW], xs[NS][NX];
         auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], uint32_t ch) {
             const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
 #pragma unroll
@@ -313,25 +317,32 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             for (int i = 0; i < NX; ++i) *(f4*)(im + (size_t)(MAXT * 16 + i * RPP + rsub) * ST_PITCH + seg * 4) = xr[i];
         };
         constexpr int PER_SET = NW + NX;
-        static_assert(PER_SET < 64, "vmcnt range");
-        issue(wa, xa, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(wb, xb, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
-            wait_vm<PER_SET>();
-            stash(wa, xa, img);
-            issue(wa, xa, ch + 2);
-            __syncthreads();             // barrier `ch`: image 0 holds chunk ch; the compute waves are done with it as chunk ch - 2
-            wait_vm<PER_SET>();
-            stash(wb, xb, img + IMG);
-            issue(wb, xb, ch + 3);
-            __syncthreads();             // barrier `ch + 1`
+        static_assert(PER_SET * (NS - 1) < 64, "vmcnt range");
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            issue(ws[q], xs[q], (uint32_t)q);
+            __builtin_amdgcn_sched_barrier(0);   // keep the issue order (the waits below count on it)
         }
-        if (nch & 1) {
-            wait_vm<PER_SET>();
-            stash(wa, xa, img);
-            __syncthreads();
+        uint32_t ch = 0;
+        for (; ch + NS <= nch; ch += NS) {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                wait_vm<PER_SET * (NS - 1)>();
+                stash(ws[q], xs[q], (q & 1) ? img + IMG : img);   // chunk ch + q; NS is even, so its image is q & 1
+                issue(ws[q], xs[q], ch + q + NS);
+                __syncthreads();         // barrier `ch + q`: the image holds the chunk; the compute waves are done with what it held before
+            }
+        }
+        const uint32_t rem = nch - ch;   // < NS chunks left, already requested into sets 0..rem-1; nothing new is issued any more
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q) {
+            if ((uint32_t)q < rem) {
+                if (q == 0) wait_vm<PER_SET * (NS - 1)>();
+                else if (q == 1) wait_vm<PER_SET * (NS > 2 ? NS - 2 : 0)>();
+                else wait_vm<PER_SET * (NS > 3 ? NS - 3 : 0)>();
+                stash(ws[q], xs[q], (q & 1) ? img + IMG : img);
+                __syncthreads();
+            }
         }
         wait_vm<0>();                    // the clamped tail loads
     } else {
@@ -369,15 +380,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                                 acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
             }
         };
-        for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
+        for (uint32_t ch = 0; ch < nch; ++ch) {
             __syncthreads();             // barrier `ch`
-            compute(img);
-            __syncthreads();             // barrier `ch + 1`
-            compute(img + IMG);
-        }
-        if (nch & 1) {
-            __syncthreads();
-            compute(img);
+            compute((ch & 1) ? img + IMG : img);
         }
     }
     __syncthreads();
