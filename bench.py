@@ -338,6 +338,18 @@ def main():
                     tt.append(time.perf_counter() - t_p)
                 result["prompt_8_tokens"] = {"ms": round(min(tt) * 1e3, 3), "floor_ms_weight_stream_at_8TBps": round(wbytes_f32 / 8e12 * 1e3, 2),
                                              "note": "one llama.Eval of the 8-token prompt at past = 0 (server.go:185-192), host graph build + logits D2H included"}
+                by_len = {}
+                for n_p in (16, 32, 64):   # longer prompts of the same kind (ids cycled from the fixed prompt): the streaming MFMA kernel up to 32 rows, the tile GEMM above
+                    toks = [PROMPT[i % len(PROMPT)] for i in range(n_p)]
+                    ct.Eval(toks, 0)
+                    tl = []
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t_p = time.perf_counter()
+                        ct.Eval(toks, 0)
+                        tl.append(time.perf_counter() - t_p)
+                    by_len[str(n_p)] = round(min(tl) * 1e3, 3)
+                result["prompt_8_tokens"]["ms_by_prompt_length"] = by_len
                 ct.free()
                 mt.QuantizeQ8()
                 cq = mt.NewContext(ctx_size, 1)

@@ -36,10 +36,18 @@ struct StreamArgs {
 #ifdef STREAM_TRACE
     unsigned long long* trace;   // tools/stream_mm_check: [4 waves][8] shader-clock totals of workgroup 0's loop phases
 #endif
+    // fused epilogues of k_stream_mm2 (the launches llama.Eval makes, llama.go:255-297 and :346-361)
+    uint32_t epi;        // ST_EPI_*
+    float* q_out;        // ST_EPI_QKV_ROPE: roped Q [n][d]; the roped K rows and the V rows go to the cache at positions past + c
+    float* k_cache;      //   this layer's slot [ctx][d]
+    float* v_cache;
+    const double2* rope; //   [pos][hd / 2] (cos, sin)
+    uint32_t hd, past;
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
 
+enum { ST_EPI_STORE = 0, ST_EPI_SILU_MUL = 1, ST_EPI_QKV_ROPE = 2 };   // plain (+ residual) | y[0] = silu(w[0] x) * (w[1] x) | RoPE + cache append
 constexpr int ST_TH = 256;   // threads; the K-chunk KC (floats per row and step) is a template parameter, LDS row pitch KC + 4 floats
 
 __host__ __device__ inline size_t stream_lds_bytes(int maxt, int nct, int kc) { return (size_t)(maxt + nct) * 16 * (kc + 4) * 4; }
@@ -270,8 +278,15 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
-    const uint32_t t0 = (uint32_t)(((uint64_t)blockIdx.x * T) / gridDim.x), t1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * T) / gridDim.x);
+    // ST_EPI_SILU_MUL: virtual tile v = (tile v >> 1 of matrix v & 1), dealt in PAIRS, so a workgroup holds w1 and w3 of the same rows
+    const bool pairs = a.epi == ST_EPI_SILU_MUL;
+    const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
+    const uint32_t t0 = um * (uint32_t)(((uint64_t)blockIdx.x * units) / gridDim.x), t1 = um * (uint32_t)(((uint64_t)(blockIdx.x + 1) * units) / gridDim.x);
     if (t1 <= t0) return;
+    auto tile_of = [&](uint32_t v, uint32_t* g, uint32_t* tile) {   // virtual tile -> (matrix, 16-row tile in it)
+        if (pairs) { *g = v & 1u; *tile = v >> 1; }
+        else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
+    };
     const uint32_t nt = t1 - t0;
     const uint32_t nch = a.K / KC;
     typedef const f4 __attribute__((address_space(1))) gf4;
@@ -287,7 +302,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         for (int i = 0; i < NW; ++i) {
             uint32_t rr = (uint32_t)i * RPP + rsub;
             rr = rr < nt * 16 ? rr : nt * 16 - 1;
-            const uint32_t v = t0 * 16 + rr, g = v / a.M, row = v - g * a.M;
+            uint32_t g, tile;
+            tile_of(t0 + (rr >> 4), &g, &tile);
+            const uint32_t row = tile * 16 + (rr & 15);
             const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
             wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
         }
@@ -386,11 +403,23 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         }
     }
     __syncthreads();
-    // ---- epilogue: as in k_stream_mm, the partial tiles of the four compute waves
+    // ---- epilogue: the partial tiles of the four compute waves meet in LDS (as in k_stream_mm), thread (column, row quad) adds them in
+    // wave order and applies the launch's epilogue: + residual | silu(w1 h) * (w3 h) on a (w1, w3) tile pair | RoPE + cache append
     constexpr int NC = NCT * 16;
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
-    const uint32_t batch = (uint32_t)(2 * IMG / TILE_FLOATS);
+    const uint32_t batch = ((uint32_t)(2 * IMG / TILE_FLOATS)) & ~1u;   // even: a pair never straddles two batches
+    const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
+    auto tile_sum = [&](uint32_t slot_in_batch) {
+        const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
+        f4 s = *(const f4*)p;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+        return s;
+    };
     for (uint32_t tb = 0; tb < nt; tb += batch) {
         if (wave >= 4) {
 #pragma unroll
@@ -407,25 +436,44 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             }
         }
         __syncthreads();
-        const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
-        if (col < (uint32_t)NC && col < a.n) {
-            for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
-                const float* p = part + (size_t)(t - tb) * TILE_FLOATS + (size_t)col * 16 + quad * 4;
-                f4 s = *(const f4*)p;
-#pragma unroll
-                for (int w = 1; w < 4; ++w) {
-                    const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
-                    s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        if (tid < 4 * NC && col < a.n) {
+            if (a.epi == ST_EPI_SILU_MUL) {
+                for (uint32_t t = tb; t + 1 < tb + batch && t + 1 < nt; t += 2) {   // (w1 tile, w3 tile) of the same rows
+                    const f4 s1 = tile_sum(t - tb), s3 = tile_sum(t + 1 - tb);
+                    const uint32_t row = ((t0 + t) >> 1) * 16 + quad * 4;
+                    f4 o;   // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+                    o.x = __fmul_rn(silu_ref(s1.x), s3.x); o.y = __fmul_rn(silu_ref(s1.y), s3.y);
+                    o.z = __fmul_rn(silu_ref(s1.z), s3.z); o.w = __fmul_rn(silu_ref(s1.w), s3.w);
+                    *(f4*)(a.y[0] + (size_t)col * a.ldy + row) = o;
                 }
-                const uint32_t v = (t0 + t) * 16 + quad * 4, g = v / a.M, row = v - g * a.M;
-                const size_t o = (size_t)col * a.ldy + row;
-                const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
-                float* yp = g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2]);
-                if (rp) {
-                    const f4 rv = *(const f4*)(rp + o);
-                    s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
+            } else {
+                for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
+                    f4 s = tile_sum(t - tb);
+                    uint32_t g, tile;
+                    tile_of(t0 + t, &g, &tile);
+                    const uint32_t row = tile * 16 + quad * 4;
+                    if (a.epi == ST_EPI_QKV_ROPE) {   // Rope mode 0 on Q / mode 1 on the new K rows (ml.go:2253-2328), K, V appended (llama.go:274-278)
+                        const uint32_t pos = a.past + col, half = a.hd >> 1;
+                        if (g < 2) {
+                            const double2 c0 = a.rope[(size_t)pos * half + ((row % a.hd) >> 1)], c1 = a.rope[(size_t)pos * half + (((row + 2) % a.hd) >> 1)];
+                            float o0, o1, o2, o3;
+                            rope_rotate(s.x, s.y, c0, &o0, &o1);
+                            rope_rotate(s.z, s.w, c1, &o2, &o3);
+                            s = f4{o0, o1, o2, o3};
+                        }
+                        float* dst = g == 0 ? a.q_out + (size_t)col * a.M + row : (g == 1 ? a.k_cache : a.v_cache) + (size_t)pos * a.M + row;
+                        *(f4*)dst = s;
+                    } else {
+                        const size_t o = (size_t)col * a.ldy + row;
+                        const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
+                        float* yp = g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2]);
+                        if (rp) {
+                            const f4 rv = *(const f4*)(rp + o);
+                            s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
+                        }
+                        *(f4*)(yp + o) = s;
+                    }
                 }
-                *(f4*)(yp + o) = s;
             }
         }
         __syncthreads();

@@ -453,15 +453,23 @@ static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
 }
 // returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
-                             uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
+                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr) {
     if (!stream_mm_on() || n > STREAM_MAX_ROWS || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
-    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups, maxt = (T + ncu - 1) / ncu;
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
+    // ST_EPI_SILU_MUL deals (w1, w3) tile pairs: twice the pairs' ceiling
+    const uint32_t maxt = (fused && fused->epi == ST_EPI_SILU_MUL) ? 2 * ((M / 16 + ncu - 1) / ncu) : (T + ncu - 1) / ncu;
     if (maxt > 8) return -1;
+    if (fused && fused->epi != ST_EPI_STORE) {   // the fused epilogues live in the wave-specialised variant only: its two images must fit
+        const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8), nct = n <= 16 ? 1 : 2;
+        if (env_int("LLAMAHIP_STREAM_MM", 2) == 1 || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, nct, 128) > 160 * 1024) return -1;
+        if (fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return -1;
+    }
     StreamArgs a = {};
+    if (fused) a = *fused;
     a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) {
-        a.w[g] = w[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr;
-        if (((uintptr_t)w[g] & 15) || ((uintptr_t)y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15))) return -1;
+        a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr;
+        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15))) return -1;
     }
     switch (maxt) {
         case 1: return launch_stream_n<1>(ctx, a, name);
@@ -1174,6 +1182,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         // grouped MFMA launches: from 9 rows (tile GEMM), and from 2 rows when the streaming MFMA kernel takes them (<= 64 rows)
         const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && stream_mm_on() && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;
         const bool q8 = m.wtype == 7;
+        bool qkv_roped = false, gated = false;
         if (q8) {
             const float* ws[3] = {L.wq, L.wk, L.wv};
             const float* sc[3] = {L.s_wq, L.s_wk, L.s_wv};
@@ -1182,13 +1191,18 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (mfma) {
             const float* ws[3] = {L.wq, L.wk, L.wv};
             float* ys[3] = {p->qraw, p->kraw, p->vraw};
-            if ((rc = gemm_mfma_group(ctx, p->h, d, 3, ws, ys, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
+            StreamArgs fa = {};   // short prompts: RoPE + cache append in the GEMM's epilogue (no rope_store pass, no raw q/k/v round trip)
+            fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
+            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
+            if (rs > 0) return rs;
+            qkv_roped = rs == 0;
+            if (!qkv_roped && (rc = gemm_mfma_group(ctx, p->h, d, 3, ws, ys, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
         } else {
             if ((rc = gemm_small_n(ctx, L.wq, p->h, p->qraw, nullptr, d, d, n, d, d, "gemm_wq"))) return rc;
             if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
             if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
         }
-        { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
+        if (!qkv_roped) { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
                            m.vc + slot, rope, d, m.hd, past); }
         if (mfma && n >= 32 && m.hd == FA_HD && flash_on()) {   // single pass, online softmax
             if ((rc = attention_flash(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
@@ -1210,12 +1224,18 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (mfma) {
             const float* ws[2] = {L.w1, L.w3};
             float* ys[2] = {p->a1, p->a3};
-            if ((rc = gemm_mfma_group(ctx, p->h, d, 2, ws, ys, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
+            StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
+            fa.epi = ST_EPI_SILU_MUL;
+            float* yg[2] = {p->g, nullptr};
+            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
+            if (rs > 0) return rs;
+            gated = rs == 0;
+            if (!gated && (rc = gemm_mfma_group(ctx, p->h, d, 2, ws, ys, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
         } else {
             if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
             if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
         }
-        { TraceScope ts_(ctx->stream, "silu_mul"); hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
+        if (!gated) { TraceScope ts_(ctx->stream, "silu_mul"); hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
                            (const float*)p->a3, p->g, (uint64_t)n * F); }
         const bool last = il + 1 == m.layer1;
         float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
