@@ -31,6 +31,7 @@ struct StreamArgs {
     const float* w[3];   // matrices of the group, each [M][K] row-major
     float* y[3];         // outputs, y[g][c * ldy + row]
     const float* r[3];   // optional residuals, same layout as y
+    const float* ws[3];  // block-int8 models (k_stream_mm2<.., true>): w[] are the int8 planes [M][K], ws[] the fp32 scales [M][K / 32]
     const float* x;      // activations [n][K], row c at x + c * ldx
     uint32_t groups, M, K, n, ldx, ldy;
 #ifdef STREAM_TRACE
@@ -267,7 +268,9 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
 // the memory pipeline accepts at once, the issue blocks, and with one wave per SIMD a blocked wave also stops feeding its matrix
 // core.  Here a loader wave that blocks costs nothing (that is its job) and the MFMA waves never touch global memory.
 // Same image layout, operand mapping and summation structure as k_stream_mm (4 compute waves x k-blocks, wave order in the epilogue).
-template <int MAXT, int NCT, int KC>
+// Q8: block-int8 weights (format of kernels_q8.h).  The loader waves fetch 16 quants + their block's scale per 16-byte load and write
+// fl32(d * q) into the image - literally the checker's dequantise-then-fp32 semantics, like k_gemm_q8 - the compute waves see fp32.
+template <int MAXT, int NCT, int KC, bool Q8 = false>
 __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     static_assert(KC == 128 || KC == 256, "chunk");
     constexpr int ST_PITCH = KC + 4, RPP = 1024 / KC;
@@ -297,6 +300,95 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     if (wave < 4) {
         // ---- loader waves
         const uint32_t rsub = (uint32_t)tid / (KC / 4), seg = (uint32_t)tid % (KC / 4);
+        const float* xp[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            uint32_t c = (uint32_t)i * RPP + rsub;
+            c = c < a.n ? c : a.n - 1;
+            xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
+        }
+        constexpr int NS = 2;            // register sets = chunks in flight (four measured no better than two for single-tile workgroups)
+        auto stash_x = [&](const f4 (&xr)[NX], float* im) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) *(f4*)(im + (size_t)(MAXT * 16 + i * RPP + rsub) * ST_PITCH + seg * 4) = xr[i];
+        };
+        if constexpr (Q8) {
+            constexpr int GPR = KC / 16;                            // 16-quant groups per row and chunk
+            constexpr int ITEMS = MAXT * 16 * GPR, NQ = (ITEMS + 255) / 256;
+            const signed char* qp[NQ];
+            const float* sp[NQ];
+            uint32_t irow[NQ], igrp[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                uint32_t e = (uint32_t)tid + (uint32_t)i * 256;
+                e = e < (uint32_t)ITEMS ? e : (uint32_t)ITEMS - 1;  // surplus threads repeat the last item (same bytes to the same place)
+                irow[i] = e / GPR; igrp[i] = e % GPR;
+                const uint32_t rr = irow[i] < nt * 16 ? irow[i] : nt * 16 - 1;
+                uint32_t g, tile;
+                tile_of(t0 + (rr >> 4), &g, &tile);
+                const uint32_t row = tile * 16 + (rr & 15);
+                const uint64_t qb = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
+                const uint64_t sb = (uint64_t)a.ws[0] + (g >= 1 ? (uint64_t)a.ws[1] - (uint64_t)a.ws[0] : 0) + (g == 2 ? (uint64_t)a.ws[2] - (uint64_t)a.ws[1] : 0);
+                qp[i] = (const signed char*)qb + (size_t)row * a.K + igrp[i] * 16;
+                sp[i] = (const float*)sb + (size_t)row * (a.K / 32) + igrp[i] / 2;
+            }
+            typedef const u4 __attribute__((address_space(1))) gu4;
+            typedef const float __attribute__((address_space(1))) gfl;
+            u4 qs[NS][NQ];
+            float ds[NS][NQ];
+            f4 xs[NS][NX];
+            auto issue = [&](u4 (&qr)[NQ], float (&dr)[NQ], f4 (&xr)[NX], uint32_t ch) {
+                const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    qr[i] = __builtin_nontemporal_load((gu4*)(uintptr_t)(qp[i] + k0));
+                    dr[i] = __builtin_nontemporal_load((gfl*)(uintptr_t)(sp[i] + k0 / 32));
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
+            };
+            auto stash = [&](const u4 (&qr)[NQ], const float (&dr)[NQ], const f4 (&xr)[NX], float* im) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    float* dst = im + (size_t)irow[i] * ST_PITCH + igrp[i] * 16;
+                    const float d = dr[i];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned int pk = qr[i][w];
+                        f4 o;
+                        o.x = __fmul_rn(d, (float)(signed char)(pk & 255u));
+                        o.y = __fmul_rn(d, (float)(signed char)((pk >> 8) & 255u));
+                        o.z = __fmul_rn(d, (float)(signed char)((pk >> 16) & 255u));
+                        o.w = __fmul_rn(d, (float)(signed char)(pk >> 24));
+                        *(f4*)(dst + w * 4) = o;
+                    }
+                }
+                stash_x(xr, im);
+            };
+            constexpr int PER_SET = 2 * NQ + NX;
+            static_assert(PER_SET * (NS - 1) < 64, "vmcnt range");
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                issue(qs[q], ds[q], xs[q], (uint32_t)q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            uint32_t ch = 0;
+            for (; ch + NS <= nch; ch += NS) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    wait_vm<PER_SET * (NS - 1)>();
+                    stash(qs[q], ds[q], xs[q], (q & 1) ? img + IMG : img);
+                    issue(qs[q], ds[q], xs[q], ch + q + NS);
+                    __syncthreads();
+                }
+            }
+            if (ch < nch) {              // one chunk left (NS = 2), already requested into set 0
+                wait_vm<PER_SET * (NS - 1)>();
+                stash(qs[0], ds[0], xs[0], img);
+                __syncthreads();
+            }
+            wait_vm<0>();
+        } else {
         const float* wp[NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -308,17 +400,6 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
             wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
         }
-        const float* xp[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            uint32_t c = (uint32_t)i * RPP + rsub;
-            c = c < a.n ? c : a.n - 1;
-            xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
-        }
-        // NS register sets = chunks in flight.  Four instead of two for the single-tile workgroups (wo, w2: 8 KB of weights per chunk
-        // and CU) changed nothing (16.0 vs 16.2 us): those launches are not short of bytes in flight - their weight rate falls with
-        // the share of activation bytes every workgroup pulls out of L2 per weight byte (1 : 1 there, 1 : 6 for w1|w3).
-        constexpr int NS = 2;
         f4 ws[NS][NW], xs[NS][NX];
         auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], uint32_t ch) {
             const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
@@ -341,15 +422,25 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             __builtin_amdgcn_sched_barrier(0);   // keep the issue order (the waits below count on it)
         }
         uint32_t ch = 0;
+#ifdef STREAM_TRACE
+        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#endif
         for (; ch + NS <= nch; ch += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 wait_vm<PER_SET * (NS - 1)>();
+                ST_STAMP(0);
                 stash(ws[q], xs[q], (q & 1) ? img + IMG : img);   // chunk ch + q; NS is even, so its image is q & 1
+                ST_STAMP(1);
                 issue(ws[q], xs[q], ch + q + NS);
+                ST_STAMP(2);
                 __syncthreads();         // barrier `ch + q`: the image holds the chunk; the compute waves are done with what it held before
+                ST_STAMP(3);
             }
         }
+#ifdef STREAM_TRACE
+        if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
+#endif
         const uint32_t rem = nch - ch;   // < NS chunks left, already requested into sets 0..rem-1; nothing new is issued any more
 #pragma unroll
         for (int q = 0; q < NS - 1; ++q) {
@@ -362,6 +453,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             }
         }
         wait_vm<0>();                    // the clamped tail loads
+        }
     } else {
         // ---- compute waves
         const int cw = wave - 4;
@@ -397,10 +489,18 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                                 acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
             }
         };
+#ifdef STREAM_TRACE
+        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t ch = 0; ch < nch; ++ch) {
             __syncthreads();             // barrier `ch`
+            ST_STAMP(0);
             compute((ch & 1) ? img + IMG : img);
+            ST_STAMP(1);
         }
+#ifdef STREAM_TRACE
+        if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
+#endif
     }
     __syncthreads();
     // ---- epilogue: the partial tiles of the four compute waves meet in LDS (as in k_stream_mm), thread (column, row quad) adds them in

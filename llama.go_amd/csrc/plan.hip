@@ -283,10 +283,17 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
     return 0;
 }
 
+static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
+                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const lh::StreamArgs* fused, const float* const* wsc);
+
 // block-int8 weights, N >= 32: dequantising MFMA GEMM (k_gemm_q8), 128 x 128 tiles, persistent one workgroup per CU
 static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* wq, const float* const* wsc, float* const* y,
                          const float* const* r, uint32_t M, uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
     if (K % GBK || ldx % 4 || ((uintptr_t)x & 15)) LH_FAIL(ctx, LH_ESHAPE, "gemm_q8 %s: K=%u / ldx=%u / X alignment not supported", name, K, ldx);
+    {   // up to 32 rows: the streaming MFMA kernel with dequantising loader waves (kernels_stream.h)
+        const int rs = gemm_stream_group(ctx, x, ldx, groups, wq, y, r, M, K, n, ldy, name, nullptr, wsc);
+        if (rs >= 0) return rs;
+    }
     GemmArgs a = {};
     a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) { a.w[g] = wq[g]; a.ws[g] = wsc[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }
@@ -423,24 +430,29 @@ static constexpr uint32_t STREAM_MAX_ROWS = 32;
 
 template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    static bool flags[2][16] = {};
+    static bool flags[3][16] = {};
     // wave-specialised variant (loader waves + MFMA waves, two LDS images) whenever the two images fit; LLAMAHIP_STREAM_MM=1 forces the
-    // first variant (every wave loads and computes) for A/B runs
+    // first variant (every wave loads and computes) for A/B runs.  Block-int8 weights (a.ws set) exist in the specialised variant only.
     static const bool v1_only = env_int("LLAMAHIP_STREAM_MM", 2) == 1;
-    const bool v2 = !v1_only && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
+    const bool q8 = a.ws[0] != nullptr;
+    const bool v2 = (!v1_only || q8) && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
+    if (q8 && !v2) return -1;
+    constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
-    int rc = v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, (KC <= 256 ? KC : 256)>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT, KC>, lds, flags[0]);
+    int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, true>, lds, flags[2])
+                : v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, false>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT, KC>, lds, flags[0]);
     if (rc) return rc;
     if (g_prepare_only) return 0;
-    ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
-    if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, (KC <= 256 ? KC : 256)>), dim3(ctx->ds->num_cu), dim3(2 * ST_TH), lds, ctx->stream, a);
+    ProfScope ps(ctx->stream, name, q8 ? (uint64_t)a.groups * a.M * a.K / 32 * 36 : (uint64_t)a.groups * a.M * a.K * 4);
+    if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, true>), dim3(ctx->ds->num_cu), dim3(2 * ST_TH), lds, ctx->stream, a);
+    else if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, false>), dim3(ctx->ds->num_cu), dim3(2 * ST_TH), lds, ctx->stream, a);
     else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
 // K-chunk: 128 columns; 256 for single-tile workgroups on long rows (w2: 37.5 -> 34.9 us).  Longer chunks (a whole 1 KB of ONE row per
 // load instruction, more bytes in flight) measured slower on the other 7B shapes, and a chunk-major copy of the weights (contiguous
-// runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02b_stream_mm_check.txt.
+// runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02c_stream_mm_check.txt.
 template <int MAXT, int NCT>
 static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (MAXT == 1 && a.K > 4096 && a.K % 256 == 0) return launch_stream<MAXT, NCT, (MAXT == 1 ? 256 : 128)>(ctx, a, name);
@@ -453,7 +465,7 @@ static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
 }
 // returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
-                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr) {
+                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr, const float* const* wsc = nullptr) {
     if (!stream_mm_on() || n > STREAM_MAX_ROWS || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
     // ST_EPI_SILU_MUL deals (w1, w3) tile pairs: twice the pairs' ceiling
@@ -461,15 +473,15 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
     if (maxt > 8) return -1;
     if (fused && fused->epi != ST_EPI_STORE) {   // the fused epilogues live in the wave-specialised variant only: its two images must fit
         const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8), nct = n <= 16 ? 1 : 2;
-        if (env_int("LLAMAHIP_STREAM_MM", 2) == 1 || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, nct, 128) > 160 * 1024) return -1;
+        if ((env_int("LLAMAHIP_STREAM_MM", 2) == 1 && !wsc) || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, nct, 128) > 160 * 1024) return -1;
         if (fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return -1;
     }
     StreamArgs a = {};
     if (fused) a = *fused;
     a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) {
-        a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr;
-        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15))) return -1;
+        a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; a.ws[g] = wsc ? wsc[g] : nullptr;
+        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || (a.ws[g] && ((uintptr_t)a.ws[g] & 3))) return -1;
     }
     switch (maxt) {
         case 1: return launch_stream_n<1>(ctx, a, name);
@@ -1083,7 +1095,9 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    if (m.wtype == 7 && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
+    const bool q8_stream = m.wtype == 7 && n >= 3 && n <= STREAM_MAX_ROWS && stream_mm_on() && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
+                           (3 * m.d / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu <= 8 && 2 * ((m.F / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu) <= 8;
+    if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
         // On a pipeline stage row i of the received / forwarded residual stream stands in for the token id / the logits row.
@@ -1187,7 +1201,12 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             const float* ws[3] = {L.wq, L.wk, L.wv};
             const float* sc[3] = {L.s_wq, L.s_wk, L.s_wv};
             float* ys[3] = {p->qraw, p->kraw, p->vraw};
-            if ((rc = gemm_q8_group(ctx, p->h, d, 3, ws, sc, ys, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
+            StreamArgs fa = {};
+            fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
+            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fa, sc) : -1;
+            if (rs > 0) return rs;
+            qkv_roped = rs == 0;
+            if (!qkv_roped && (rc = gemm_q8_group(ctx, p->h, d, 3, ws, sc, ys, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
         } else if (mfma) {
             const float* ws[3] = {L.wq, L.wk, L.wv};
             float* ys[3] = {p->qraw, p->kraw, p->vraw};
@@ -1220,7 +1239,13 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             const float* ws[2] = {L.w1, L.w3};
             const float* sc[2] = {L.s_w1, L.s_w3};
             float* ys[2] = {p->a1, p->a3};
-            if ((rc = gemm_q8_group(ctx, p->h, d, 2, ws, sc, ys, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
+            StreamArgs fa = {};
+            fa.epi = ST_EPI_SILU_MUL;
+            float* yg[2] = {p->g, nullptr};
+            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, sc) : -1;
+            if (rs > 0) return rs;
+            gated = rs == 0;
+            if (!gated && (rc = gemm_q8_group(ctx, p->h, d, 2, ws, sc, ys, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
         } else if (mfma) {
             const float* ws[2] = {L.w1, L.w3};
             float* ys[2] = {p->a1, p->a3};

@@ -33,6 +33,9 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC>), dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    { unsigned long long tr[64]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost)); const double nh = (double)(a.K / KC);
+      printf("   loader wave 0, shader clocks per chunk: wait loads %.0f | stash %.0f | issue %.0f | barrier %.0f\n", tr[0] / nh, tr[1] / nh, tr[2] / nh, tr[3] / nh);
+      printf("   MFMA wave 4:                            barrier %.0f | compute %.0f\n", tr[32] / nh, tr[33] / nh); }
     printf("k_stream_mm2<%d,%d,%d> (specialised waves): %.2f us per launch, %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
 }
 static int g_v2 = 0;
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
     } else
     CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dY, 0xFF, Y.size() * 4));
     StreamArgs a = {}; a.w[0] = dW; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
-    CK(hipMalloc(&a.trace, 256)); CK(hipMemset(a.trace, 0, 256));
+    CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
     const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
 #define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else run<MT, 2>(a, nCU); }
