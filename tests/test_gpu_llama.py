@@ -271,10 +271,11 @@ def test_resident_decode_kernel_matches_oracle(product, oracle, shape, prompt, m
     m.free()
 
 
-@pytest.mark.parametrize("n_prompt", [9, 17, 20, 33, 64, 100])
+@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 64, 100])
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
-    """N >= 32 tokens in one Eval run the fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) + blocked attention; the next decode steps
-    read the KV cache that prefill wrote."""
+    """One Eval of N tokens: 2..32 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
+    append / SiLU fused into its epilogues; one and two 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
+    (v_mfma_f32_32x32x2_f32) + blocked attention; the next decode steps read the KV cache that prefill wrote."""
     rng = np.random.default_rng(n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n_prompt)]
     out = decode_both(product, oracle, "small", 128, prompt, 4)
@@ -504,7 +505,8 @@ def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, lay
     assert th == to
 
 
-@pytest.mark.parametrize("shape,n_prompt", [("small", 20), ("small", 33), ("small", 100), ("small", 300), ("13B", 72)])
+@pytest.mark.parametrize("shape,n_prompt", [("small", 3), ("small", 8), ("small", 16), ("small", 20), ("small", 32), ("small", 33), ("small", 100), ("small", 300), ("13B", 72),
+                                            ("13B", 24)])
 def test_block_int8_prefill_gemm_matches_dequantised_oracle(product, oracle, shape, n_prompt):
     """Prompts of >= 32 tokens on a block-int8 model run the dequantising MFMA GEMM (k_gemm_q8: int8 + scale -> fl32(d*q) -> LDS ->
     exact-f32 MFMA); shorter ones and every decode step run the int8 GEMV stream.  Both must agree with the checker's
