@@ -45,7 +45,17 @@ struct GemmArgs {
     // two passes, fixed order, bit-reproducible — no atomics.
     uint32_t splits;
     float* part;
+    // Fused epilogues of k_gemm_glds (long prompts; the launches llama.Eval makes, llama.go:255-297 and :346-361):
+    //   GEMM_EPI_SILU_MUL  groups = 1, M = 2 F VIRTUAL rows: row v = row v >> 1 of w[v & 1] (w1, w3); y[0][n][v >> 1] = silu(w1 h) * (w3 h)
+    //   GEMM_EPI_QKV_ROPE  groups = 3 (wq, wk, wv), M = d: RoPE on Q and the new K rows, K / V rows appended to the cache at past + n
+    uint32_t epi;
+    float* q_out;
+    float* k_cache;
+    float* v_cache;
+    const double2* rope;
+    uint32_t hd;
 };
+enum { GEMM_EPI_STORE = 0, GEMM_EPI_SILU_MUL = 1, GEMM_EPI_QKV_ROPE = 2 };
 
 constexpr int GBK = 32;
 #ifndef LH_GST
@@ -81,6 +91,40 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& a, f16v (&acc)[TN][TM
         }
 }
 
+
+// Fused epilogues (GemmArgs::epi).  Partner rows (w1 / w3 of one ff row; the two rows of a RoPE pair) are adjacent D columns = adjacent
+// LANES (col = lane & 31), so the partner's value comes by one cross-lane exchange per element; every lane runs the exchange.
+template <int TN, int TM>
+__device__ __forceinline__ void gemm_store_fused(const GemmArgs& a, f16v (&acc)[TN][TM], uint32_t g, uint32_t nb, uint32_t mb, int li, int lh) {
+    const bool even = (li & 1) == 0;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const uint32_t m = mb + j * 32 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t n = nb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const float v = acc[i][j][e];
+                const float p = __shfl_xor(v, 1, 64);
+                const bool ok = n < a.N && m < a.M;
+                if (a.epi == GEMM_EPI_SILU_MUL) {
+                    // even lane: w1 row m >> 1, its partner: w3 row m >> 1.  Silu then Mul: ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+                    if (ok && even) a.y[0][(size_t)n * a.ldy + (m >> 1)] = __fmul_rn(silu_ref(v), p);
+                } else {
+                    const uint32_t pos = a.past + n;
+                    if (g < 2) {   // Rope mode 0 on Q / mode 1 on the new K rows (ml.go:2253-2328)
+                        const double2 cs = a.rope[(size_t)(ok ? pos : a.past) * (a.hd >> 1) + (((m < a.M ? m : 0) % a.hd) >> 1)];
+                        float o0, o1;
+                        rope_rotate(even ? v : p, even ? p : v, cs, &o0, &o1);
+                        if (ok) (g == 0 ? a.q_out + (size_t)n * a.M : a.k_cache + (size_t)pos * a.M)[m] = even ? o0 : o1;
+                    } else if (ok) {
+                        a.v_cache[(size_t)pos * a.M + m] = v;   // cache append llama.go:274-278
+                    }
+                }
+            }
+        }
+}
 
 template <int WN, int WM, int TN, int TM>
 __global__ __launch_bounds__(256) void k_gemm_mfma(const GemmArgs a) {
@@ -255,7 +299,11 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
             src[pp] = X + (size_t)(n < a.N ? n : a.N - 1) * a.ldx + 4 * gran;
         } else {
             const uint32_t m = m0 + row - BN;
-            src[pp] = W + (size_t)(m < a.M ? m : a.M - 1) * ldw + 4 * gran;
+            const uint32_t mm = m < a.M ? m : a.M - 1;
+            if (a.epi == GEMM_EPI_SILU_MUL)   // virtual row mm = row mm >> 1 of w1 (even) / w3 (odd); base + distance, never a pointer select
+                src[pp] = (const float*)((uint64_t)a.w[0] + ((mm & 1u) ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0)) + (size_t)(mm >> 1) * ldw + 4 * gran;
+            else
+                src[pp] = W + (size_t)mm * ldw + 4 * gran;
         }
     }
     auto issue = [&](int stage, uint32_t k0, int p0, int p1) {
@@ -344,7 +392,8 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
         mfmas(1, 2, 4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
-    gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, ldy);
+    if (a.epi != GEMM_EPI_STORE) gemm_store_fused<TN, TM>(a, acc, g, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+    else gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, ldy);
   }
 }
 

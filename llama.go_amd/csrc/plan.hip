@@ -493,20 +493,30 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
     }
 }
 
+// fused != nullptr: GEMM_EPI_SILU_MUL (w = {w1, w3}, y[0] = gated output [n][M]) or GEMM_EPI_QKV_ROPE (w = {wq, wk, wv}; outputs in *fused) in
+// the epilogue of the LDS-DMA tile GEMM; returns -1 when the launch cannot take it (short prompt, split-K, register-staged kernel) and
+// the caller runs the plain GEMM + the separate pass.
 int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
-                    uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
-    if (n <= STREAM_MAX_ROWS) {
+                    uint32_t K, uint32_t n, uint32_t ldy, const char* name, const GemmArgs* fused = nullptr) {
+    if (n <= STREAM_MAX_ROWS && !fused) {
         const int rs = gemm_stream_group(ctx, x, ldx, groups, w, y, r, M, K, n, ldy, name);
         if (rs >= 0) return rs;
     }
     GemmArgs a = {};
+    if (fused) a = *fused;
     a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
-    for (uint32_t g = 0; g < groups; ++g) { a.w[g] = w[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }
+    for (uint32_t g = 0; g < groups; ++g) { a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; }
+    if (fused && fused->epi == GEMM_EPI_SILU_MUL) { a.groups = 1; a.M = 2 * M; }   // one matrix of 2 M virtual rows (w1, w3 interleaved)
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, tn = (n + 127) / 128;
     auto cost = [&](uint32_t bm, double penalty) {
-        const uint32_t tiles = tn * ((M + bm - 1) / bm) * groups;
+        const uint32_t tiles = tn * ((a.M + bm - 1) / bm) * a.groups;
         return (double)((tiles + ncu - 1) / ncu) * bm * penalty;
     };
+    if (fused) {
+        // only where the epilogue exists: the DMA kernel, whole contraction per tile (no split-K: at least one tile per CU), long prompts
+        if (n <= 64 || env_int("LLAMAHIP_GEMM_FUSED", 1) == 0 || !gemm_dma_ok(a) || a.K < 16 * GBK || getenv("LLAMAHIP_GEMM_NO_DMA") || tn * ((a.M + 159) / 160) * a.groups < ncu) return -1;
+        if (fused->epi == GEMM_EPI_QKV_ROPE && (fused->hd % 2 || M % fused->hd)) return -1;
+    }
     // up to 64 rows: 64 x 128 tiles (half the matrix work of a 128-row tile whose upper half would be padding)
     if (n <= 64) return launch_gemm<2, 2, 1, 2>(ctx, a, name);
     const double c128 = cost(128, 1.0), c160 = cost(160, 1.03), c64 = cost(64, 1.10);
@@ -1212,7 +1222,12 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             float* ys[3] = {p->qraw, p->kraw, p->vraw};
             StreamArgs fa = {};   // short prompts: RoPE + cache append in the GEMM's epilogue (no rope_store pass, no raw q/k/v round trip)
             fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
+            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
+            if (rs < 0 && n > 64) {   // long prompts: the same epilogue in the tile GEMM
+                GemmArgs ga = {};
+                ga.epi = GEMM_EPI_QKV_ROPE; ga.q_out = p->q; ga.k_cache = m.kc + slot; ga.v_cache = m.vc + slot; ga.rope = rope; ga.hd = m.hd; ga.past = past;
+                rs = gemm_mfma_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "gemm_wqkv_rope", &ga);
+            }
             if (rs > 0) return rs;
             qkv_roped = rs == 0;
             if (!qkv_roped && (rc = gemm_mfma_group(ctx, p->h, d, 3, ws, ys, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
@@ -1252,7 +1267,12 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
             fa.epi = ST_EPI_SILU_MUL;
             float* yg[2] = {p->g, nullptr};
-            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
+            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
+            if (rs < 0 && n > 64) {
+                GemmArgs ga = {};
+                ga.epi = GEMM_EPI_SILU_MUL;
+                rs = gemm_mfma_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "gemm_w1w3_silu", &ga);
+            }
             if (rs > 0) return rs;
             gated = rs == 0;
             if (!gated && (rc = gemm_mfma_group(ctx, p->h, d, 2, ws, ys, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;

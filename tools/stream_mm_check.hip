@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
     const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
-#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else run<MT, 2>(a, nCU); }
+#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0; const uint32_t CT = (N + 15) / 16;
