@@ -351,15 +351,17 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
                     float* dst = im + (size_t)irow[i] * ST_PITCH + igrp[i] * 16;
-                    const float d = dr[i];
+                    // fl32(d * q) with q = u - 128, u = the byte with its sign bit flipped: one v_cvt_f32_ubyteN + one fma per value
+                    // (d * u - 128 d is exact before the fma's single rounding, so the result IS fl32(d * q))
+                    const float d = dr[i], nd = __fmul_rn(d, -128.0f);
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const unsigned int pk = qr[i][w];
+                        const unsigned int pk = qr[i][w] ^ 0x80808080u;
                         f4 o;
-                        o.x = __fmul_rn(d, (float)(signed char)(pk & 255u));
-                        o.y = __fmul_rn(d, (float)(signed char)((pk >> 8) & 255u));
-                        o.z = __fmul_rn(d, (float)(signed char)((pk >> 16) & 255u));
-                        o.w = __fmul_rn(d, (float)(signed char)(pk >> 24));
+                        o.x = fmaf(d, (float)(pk & 255u), nd);
+                        o.y = fmaf(d, (float)((pk >> 8) & 255u), nd);
+                        o.z = fmaf(d, (float)((pk >> 16) & 255u), nd);
+                        o.w = fmaf(d, (float)(pk >> 24), nd);
                         *(f4*)(dst + w * 4) = o;
                     }
                 }
@@ -373,15 +375,25 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             uint32_t ch = 0;
+#ifdef STREAM_TRACE
+            unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
+#endif
             for (; ch + NS <= nch; ch += NS) {
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
                     wait_vm<PER_SET * (NS - 1)>();
+                    ST_STAMP(0);
                     stash(qs[q], ds[q], xs[q], (q & 1) ? img + IMG : img);
+                    ST_STAMP(1);
                     issue(qs[q], ds[q], xs[q], ch + q + NS);
+                    ST_STAMP(2);
                     __syncthreads();
+                    ST_STAMP(3);
                 }
             }
+#ifdef STREAM_TRACE
+            if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
+#endif
             if (ch < nch) {              // one chunk left (NS = 2), already requested into set 0
                 wait_vm<PER_SET * (NS - 1)>();
                 stash(qs[0], ds[0], xs[0], img);

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <algorithm>
 using namespace lh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 static int g_kc = 128;
@@ -26,17 +27,20 @@ template <int MAXT, int NCT, int KC> static void run_kc(const StreamArgs& a, int
 template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, int nCU) {
     const size_t lds = std::max<size_t>(stream2_lds_bytes(MAXT, NCT, KC), 82 * 1024);
     if (lds > 160 * 1024) { printf("k_stream_mm2<%d,%d,%d>: images do not fit\n", MAXT, NCT, KC); return; }
-    CK(hipFuncSetAttribute((const void*)k_stream_mm2<MAXT, NCT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool q8 = a.ws[0] != nullptr;
+    auto kern = q8 ? k_stream_mm2<MAXT, NCT, KC, true> : k_stream_mm2<MAXT, NCT, KC, false>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC>), dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
+    hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC>), dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     { unsigned long long tr[64]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost)); const double nh = (double)(a.K / KC);
       printf("   loader wave 0, shader clocks per chunk: wait loads %.0f | stash %.0f | issue %.0f | barrier %.0f\n", tr[0] / nh, tr[1] / nh, tr[2] / nh, tr[3] / nh);
       printf("   MFMA wave 4:                            barrier %.0f | compute %.0f\n", tr[32] / nh, tr[33] / nh); }
-    printf("k_stream_mm2<%d,%d,%d> (specialised waves): %.2f us per launch, %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
+    printf("k_stream_mm2<%d,%d,%d%s> (specialised waves): %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, q8 ? ",int8" : "", ms * 200,
+           (double)a.M * a.K * (q8 ? 36.0 / 32 : 4.0) / (ms * 200) / 1e3);
 }
 static int g_v2 = 0;
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
@@ -50,7 +54,8 @@ int main(int argc, char** argv) {
     const uint32_t M = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 33;
     if (argc > 4) g_kc = atoi(argv[4]);
     const bool tiled = argc > 5 && atoi(argv[5]) == 1;
-    g_v2 = argc > 5 && atoi(argv[5]) == 2;
+    g_v2 = argc > 5 && (atoi(argv[5]) == 2 || atoi(argv[5]) == 3);
+    const bool q8 = argc > 5 && atoi(argv[5]) == 3;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); const int nCU = p.multiProcessorCount;
     std::vector<float> W((size_t)M * K), X((size_t)N * K), Y((size_t)N * M);
     unsigned s = 1; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); };
@@ -62,7 +67,18 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dW, Wt_.data(), W.size() * 4, hipMemcpyHostToDevice));
     } else
     CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice)); CK(hipMemset(dY, 0xFF, Y.size() * 4));
-    StreamArgs a = {}; a.w[0] = dW; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
+    float* dS = nullptr;
+    if (q8) {   // block-int8 planes of the same matrix; the reference product then uses the dequantised values
+        std::vector<signed char> Q((size_t)M * K); std::vector<float> S((size_t)M * K / 32);
+        for (size_t b = 0; b < S.size(); ++b) {
+            float mx = 0; for (int i = 0; i < 32; ++i) mx = std::max(mx, fabsf(W[b * 32 + i]));
+            const float dd = mx / 127.0f; S[b] = dd;
+            for (int i = 0; i < 32; ++i) { float t = dd > 0 ? rintf(W[b * 32 + i] / dd) : 0.f; t = std::min(std::max(t, -127.f), 127.f); Q[b * 32 + i] = (signed char)t; W[b * 32 + i] = dd * (float)(int)t; }
+        }
+        CK(hipMemcpy(dW, Q.data(), Q.size(), hipMemcpyHostToDevice));
+        CK(hipMalloc(&dS, S.size() * 4)); CK(hipMemcpy(dS, S.data(), S.size() * 4, hipMemcpyHostToDevice));
+    }
+    StreamArgs a = {}; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
     CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
     const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
