@@ -44,6 +44,11 @@ struct StreamArgs {
     float* v_cache;
     const double2* rope; //   [pos][hd / 2] (cos, sin)
     uint32_t hd, past;
+    // RMSNorm folded into the launch (k_stream_mm2): x is the RAW residual stream, gamma the norm weight [K].  The norm is linear in its
+    // per-token scale s = fl32(1 / sqrt(mean(x^2) + 1e-5)), so the kernel contracts W with gamma * x and multiplies the sums by s in the
+    // epilogue; s comes from the x chunks the loader waves stage anyway (fp32 squares, f64 sum, fixed order).  Rounding differs from
+    // the reference's fl(gamma * fl(x * s)) by two fp32 roundings per term (ml.go:1788-1808, 1906) - inside the GEMM's own 1e-6 noise.
+    const float* gamma;
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
@@ -308,9 +313,35 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
         }
         constexpr int NS = 2;            // register sets = chunks in flight (four measured no better than two for single-tile workgroups)
-        auto stash_x = [&](const f4 (&xr)[NX], float* im) {
+        // gamma chunk: fetched with every set (from x itself when the launch has no norm: the count of loads per set stays a constant)
+        const float* gp = (a.gamma ? a.gamma : a.x) + seg * 4;
+        const bool norm = a.gamma != nullptr;
+        double ssq[NX];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) *(f4*)(im + (size_t)(MAXT * 16 + i * RPP + rsub) * ST_PITCH + seg * 4) = xr[i];
+        for (int i = 0; i < NX; ++i) ssq[i] = 0.0;
+        auto stash_x = [&](const f4 (&xr)[NX], const f4& gq, float* im) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                f4 v = xr[i];
+                if (norm) {
+                    // fp32 squares; four of them meet in fp32 (one more rounding of relative 6e-8 per group), the groups add up in f64:
+                    // a quarter of the f64 work of adding every square in f64, which at 32 rows made the loader waves the slower side
+                    ssq[i] += (double)__fadd_rn(__fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y)), __fadd_rn(__fmul_rn(v.z, v.z), __fmul_rn(v.w, v.w)));
+                    v.x = __fmul_rn(gq.x, v.x); v.y = __fmul_rn(gq.y, v.y); v.z = __fmul_rn(gq.z, v.z); v.w = __fmul_rn(gq.w, v.w);
+                }
+                *(f4*)(im + (size_t)(MAXT * 16 + i * RPP + rsub) * ST_PITCH + seg * 4) = v;
+            }
+        };
+        auto publish_scales = [&]() {    // after the last chunk: per-column sum over the lanes that share a row, then 1 / sqrt(mean + eps)
+            if (!norm) return;
+            float* scl = img + 2 * IMG;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double t = ssq[i];
+#pragma unroll
+                for (int o = KC / 8; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+                if (seg == 0) scl[i * RPP + rsub] = (float)(1.0 / sqrt(t / (double)a.K + 1e-5));
+            }
         };
         if constexpr (Q8) {
             constexpr int GPR = KC / 16;                            // 16-quant groups per row and chunk
@@ -336,9 +367,10 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             typedef const float __attribute__((address_space(1))) gfl;
             u4 qs[NS][NQ];
             float ds[NS][NQ];
-            f4 xs[NS][NX];
-            auto issue = [&](u4 (&qr)[NQ], float (&dr)[NQ], f4 (&xr)[NX], uint32_t ch) {
+            f4 xs[NS][NX], gs[NS];
+            auto issue = [&](u4 (&qr)[NQ], float (&dr)[NQ], f4 (&xr)[NX], f4& gq, uint32_t ch) {
                 const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
+                gq = *(gf4*)(uintptr_t)(gp + k0);
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
                     qr[i] = __builtin_nontemporal_load((gu4*)(uintptr_t)(qp[i] + k0));
@@ -347,7 +379,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
 #pragma unroll
                 for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
             };
-            auto stash = [&](const u4 (&qr)[NQ], const float (&dr)[NQ], const f4 (&xr)[NX], float* im) {
+            auto stash = [&](const u4 (&qr)[NQ], const float (&dr)[NQ], const f4 (&xr)[NX], const f4& gq, float* im) {
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
                     float* dst = im + (size_t)irow[i] * ST_PITCH + igrp[i] * 16;
@@ -365,13 +397,13 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                         *(f4*)(dst + w * 4) = o;
                     }
                 }
-                stash_x(xr, im);
+                stash_x(xr, gq, im);
             };
-            constexpr int PER_SET = 2 * NQ + NX;
+            constexpr int PER_SET = 2 * NQ + NX + 1;
             static_assert(PER_SET * (NS - 1) < 64, "vmcnt range");
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                issue(qs[q], ds[q], xs[q], (uint32_t)q);
+                issue(qs[q], ds[q], xs[q], gs[q], (uint32_t)q);
                 __builtin_amdgcn_sched_barrier(0);
             }
             uint32_t ch = 0;
@@ -383,9 +415,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 for (int q = 0; q < NS; ++q) {
                     wait_vm<PER_SET * (NS - 1)>();
                     ST_STAMP(0);
-                    stash(qs[q], ds[q], xs[q], (q & 1) ? img + IMG : img);
+                    stash(qs[q], ds[q], xs[q], gs[q], (q & 1) ? img + IMG : img);
                     ST_STAMP(1);
-                    issue(qs[q], ds[q], xs[q], ch + q + NS);
+                    issue(qs[q], ds[q], xs[q], gs[q], ch + q + NS);
                     ST_STAMP(2);
                     __syncthreads();
                     ST_STAMP(3);
@@ -396,10 +428,11 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
 #endif
             if (ch < nch) {              // one chunk left (NS = 2), already requested into set 0
                 wait_vm<PER_SET * (NS - 1)>();
-                stash(qs[0], ds[0], xs[0], img);
+                stash(qs[0], ds[0], xs[0], gs[0], img);
                 __syncthreads();
             }
             wait_vm<0>();
+            publish_scales();
         } else {
         const float* wp[NW];
 #pragma unroll
@@ -412,25 +445,25 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
             wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
         }
-        f4 ws[NS][NW], xs[NS][NX];
-        auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], uint32_t ch) {
+        f4 ws[NS][NW], xs[NS][NX], gs[NS];
+        auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], f4& gq, uint32_t ch) {
             const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
 #pragma unroll
             for (int i = 0; i < NW; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0));
 #pragma unroll
             for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
+            gq = *(gf4*)(uintptr_t)(gp + k0);
         };
-        auto stash = [&](const f4 (&wr)[NW], const f4 (&xr)[NX], float* im) {
+        auto stash = [&](const f4 (&wr)[NW], const f4 (&xr)[NX], const f4& gq, float* im) {
 #pragma unroll
             for (int i = 0; i < NW; ++i) *(f4*)(im + (size_t)(i * RPP + rsub) * ST_PITCH + seg * 4) = wr[i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) *(f4*)(im + (size_t)(MAXT * 16 + i * RPP + rsub) * ST_PITCH + seg * 4) = xr[i];
+            stash_x(xr, gq, im);
         };
-        constexpr int PER_SET = NW + NX;
+        constexpr int PER_SET = NW + NX + 1;
         static_assert(PER_SET * (NS - 1) < 64, "vmcnt range");
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            issue(ws[q], xs[q], (uint32_t)q);
+            issue(ws[q], xs[q], gs[q], (uint32_t)q);
             __builtin_amdgcn_sched_barrier(0);   // keep the issue order (the waits below count on it)
         }
         uint32_t ch = 0;
@@ -442,9 +475,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             for (int q = 0; q < NS; ++q) {
                 wait_vm<PER_SET * (NS - 1)>();
                 ST_STAMP(0);
-                stash(ws[q], xs[q], (q & 1) ? img + IMG : img);   // chunk ch + q; NS is even, so its image is q & 1
+                stash(ws[q], xs[q], gs[q], (q & 1) ? img + IMG : img);   // chunk ch + q; NS is even, so its image is q & 1
                 ST_STAMP(1);
-                issue(ws[q], xs[q], ch + q + NS);
+                issue(ws[q], xs[q], gs[q], ch + q + NS);
                 ST_STAMP(2);
                 __syncthreads();         // barrier `ch + q`: the image holds the chunk; the compute waves are done with what it held before
                 ST_STAMP(3);
@@ -460,11 +493,12 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 if (q == 0) wait_vm<PER_SET * (NS - 1)>();
                 else if (q == 1) wait_vm<PER_SET * (NS > 2 ? NS - 2 : 0)>();
                 else wait_vm<PER_SET * (NS > 3 ? NS - 3 : 0)>();
-                stash(ws[q], xs[q], (q & 1) ? img + IMG : img);
+                stash(ws[q], xs[q], gs[q], (q & 1) ? img + IMG : img);
                 __syncthreads();
             }
         }
         wait_vm<0>();                    // the clamped tail loads
+        publish_scales();
         }
     } else {
         // ---- compute waves
@@ -522,6 +556,8 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
     const uint32_t batch = ((uint32_t)(2 * IMG / TILE_FLOATS)) & ~1u;   // even: a pair never straddles two batches
     const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
+    // the folded RMSNorm's per-token scale (written by the loader waves behind the image memory; read before `part` is touched)
+    const float nscale = (a.gamma && col < (uint32_t)NC) ? ((const float*)smem_raw)[2 * IMG + col] : 1.0f;
     auto tile_sum = [&](uint32_t slot_in_batch) {
         const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
         f4 s = *(const f4*)p;
@@ -530,6 +566,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
+        if (a.gamma) { s.x = __fmul_rn(s.x, nscale); s.y = __fmul_rn(s.y, nscale); s.z = __fmul_rn(s.z, nscale); s.w = __fmul_rn(s.w, nscale); }
         return s;
     };
     for (uint32_t tb = 0; tb < nt; tb += batch) {
@@ -591,6 +628,6 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         __syncthreads();
     }
 }
-__host__ __device__ inline size_t stream2_lds_bytes(int maxt, int nct, int kc) { return 2 * stream_lds_bytes(maxt, nct, kc); }
+__host__ __device__ inline size_t stream2_lds_bytes(int maxt, int nct, int kc) { return 2 * stream_lds_bytes(maxt, nct, kc) + 256; }   // + per-column norm scales
 
 }  // namespace lh

@@ -436,7 +436,7 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     static const bool v1_only = env_int("LLAMAHIP_STREAM_MM", 2) == 1;
     const bool q8 = a.ws[0] != nullptr;
     const bool v2 = (!v1_only || q8) && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
-    if (q8 && !v2) return -1;
+    if ((q8 || a.gamma) && !v2) return -1;
     constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
     int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, true>, lds, flags[2])
@@ -1202,35 +1202,44 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
-        { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
-        // grouped MFMA launches: from 9 rows (tile GEMM), and from 2 rows when the streaming MFMA kernel takes them (<= 64 rows)
-        const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && stream_mm_on() && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;
+        const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && stream_mm_on() && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;   // grouped MFMA launches: from 9 rows (tile GEMM), from 2 rows on the streaming MFMA kernel
         const bool q8 = m.wtype == 7;
         bool qkv_roped = false, gated = false;
-        if (q8) {
-            const float* ws[3] = {L.wq, L.wk, L.wv};
-            const float* sc[3] = {L.s_wq, L.s_wk, L.s_wv};
-            float* ys[3] = {p->qraw, p->kraw, p->vraw};
+        const float* wqkv[3] = {L.wq, L.wk, L.wv};
+        const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
+        float* yqkv[3] = {p->qraw, p->kraw, p->vraw};
+        if (n <= STREAM_MAX_ROWS && (q8 || mfma)) {
+            // short prompts: ONE launch for RMSNorm (folded: gamma at staging, the per-token scale in the epilogue) -> wq|wk|wv -> RoPE -> cache append
             StreamArgs fa = {};
             fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fa, sc) : -1;
+            // (folded up to 16 rows: -3..5 % per Eval; at 17..32 rows the extra staging work of the loader waves eats the saved launch)
+            fa.gamma = (n <= 16 && env_int("LLAMAHIP_STREAM_NORM", 1)) ? L.attn_norm : nullptr;
+            int rs = -1;
+            if (fa.gamma) rs = gemm_stream_group(ctx, x, d, 3, wqkv, nullptr, nullptr, d, d, n, d, q8 ? "stream_q8_norm_wqkv_rope" : "stream_norm_wqkv_rope", &fa, q8 ? sqkv : nullptr);
             if (rs > 0) return rs;
             qkv_roped = rs == 0;
-            if (!qkv_roped && (rc = gemm_q8_group(ctx, p->h, d, 3, ws, sc, ys, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
+        }
+        if (!qkv_roped) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
+        if (qkv_roped) {
+        } else if (q8) {
+            StreamArgs fa = {};
+            fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
+            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fa, sqkv) : -1;
+            if (rs > 0) return rs;
+            qkv_roped = rs == 0;
+            if (!qkv_roped && (rc = gemm_q8_group(ctx, p->h, d, 3, wqkv, sqkv, yqkv, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
         } else if (mfma) {
-            const float* ws[3] = {L.wq, L.wk, L.wv};
-            float* ys[3] = {p->qraw, p->kraw, p->vraw};
             StreamArgs fa = {};   // short prompts: RoPE + cache append in the GEMM's epilogue (no rope_store pass, no raw q/k/v round trip)
             fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
+            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
             if (rs < 0 && n > 64) {   // long prompts: the same epilogue in the tile GEMM
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_QKV_ROPE; ga.q_out = p->q; ga.k_cache = m.kc + slot; ga.v_cache = m.vc + slot; ga.rope = rope; ga.hd = m.hd; ga.past = past;
-                rs = gemm_mfma_group(ctx, p->h, d, 3, ws, nullptr, nullptr, d, d, n, d, "gemm_wqkv_rope", &ga);
+                rs = gemm_mfma_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "gemm_wqkv_rope", &ga);
             }
             if (rs > 0) return rs;
             qkv_roped = rs == 0;
-            if (!qkv_roped && (rc = gemm_mfma_group(ctx, p->h, d, 3, ws, ys, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
+            if (!qkv_roped && (rc = gemm_mfma_group(ctx, p->h, d, 3, wqkv, yqkv, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
         } else {
             if ((rc = gemm_small_n(ctx, L.wq, p->h, p->qraw, nullptr, d, d, n, d, d, "gemm_wq"))) return rc;
             if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
@@ -1249,33 +1258,40 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         if (q8) { if ((rc = gemm_q8(ctx, L.wo, L.s_wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_q8_wo"))) return rc; }
         else if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
-        { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
-        if (q8) {
-            const float* ws[2] = {L.w1, L.w3};
-            const float* sc[2] = {L.s_w1, L.s_w3};
-            float* ys[2] = {p->a1, p->a3};
+        const float* w13[2] = {L.w1, L.w3};
+        const float* s13[2] = {L.s_w1, L.s_w3};
+        float* y13[2] = {p->a1, p->a3};
+        float* yg[2] = {p->g, nullptr};
+        if (n <= STREAM_MAX_ROWS && (q8 || mfma)) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
-            float* yg[2] = {p->g, nullptr};
-            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, sc) : -1;
+            fa.gamma = (n <= 16 && env_int("LLAMAHIP_STREAM_NORM", 1)) ? L.ffn_norm : nullptr;
+            int rs = -1;
+            if (fa.gamma) rs = gemm_stream_group(ctx, p->xb, d, 2, w13, yg, nullptr, F, d, n, F, q8 ? "stream_q8_norm_w1w3_silu" : "stream_norm_w1w3_silu", &fa, q8 ? s13 : nullptr);
             if (rs > 0) return rs;
             gated = rs == 0;
-            if (!gated && (rc = gemm_q8_group(ctx, p->h, d, 2, ws, sc, ys, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
+        }
+        if (!gated) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
+        if (gated) {
+        } else if (q8) {
+            StreamArgs fa = {};
+            fa.epi = ST_EPI_SILU_MUL;
+            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, s13) : -1;
+            if (rs > 0) return rs;
+            gated = rs == 0;
+            if (!gated && (rc = gemm_q8_group(ctx, p->h, d, 2, w13, s13, y13, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
         } else if (mfma) {
-            const float* ws[2] = {L.w1, L.w3};
-            float* ys[2] = {p->a1, p->a3};
             StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
             fa.epi = ST_EPI_SILU_MUL;
-            float* yg[2] = {p->g, nullptr};
-            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
+            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
             if (rs < 0 && n > 64) {
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_SILU_MUL;
-                rs = gemm_mfma_group(ctx, p->h, d, 2, ws, yg, nullptr, F, d, n, F, "gemm_w1w3_silu", &ga);
+                rs = gemm_mfma_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "gemm_w1w3_silu", &ga);
             }
             if (rs > 0) return rs;
             gated = rs == 0;
-            if (!gated && (rc = gemm_mfma_group(ctx, p->h, d, 2, ws, ys, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
+            if (!gated && (rc = gemm_mfma_group(ctx, p->h, d, 2, w13, y13, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
         } else {
             if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
             if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
