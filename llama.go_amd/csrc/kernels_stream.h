@@ -49,6 +49,13 @@ struct StreamArgs {
     // epilogue; s comes from the x chunks the loader waves stage anyway (fp32 squares, f64 sum, fixed order).  Rounding differs from
     // the reference's fl(gamma * fl(x * s)) by two fp32 roundings per term (ml.go:1788-1808, 1906) - inside the GEMM's own 1e-6 noise.
     const float* gamma;
+    // K-split (k_stream_mm2, plain epilogue only): ksplit = S > 1 deals the workgroups in groups of S; group j owns a block of 16-row
+    // tiles like a whole workgroup does otherwise (so S times as many rows), member s contracts K-chunks [s nch / S, (s + 1) nch / S) and
+    // writes its partial sums to y[g] + s * ysplit (no residual); k_stream_reduce_norm adds the S partials in s order.  For the
+    // single-tile matrices (wo, w2: M / 16 = #CU tiles): every workgroup reads all of X out of L2, n / 16 bytes per weight byte, which at
+    // 17..32 rows is twice the weight stream; with S = 4 a workgroup reads a quarter of X for four tiles.
+    uint32_t ksplit;
+    uint64_t ysplit;     // floats between the partial outputs
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
@@ -289,14 +296,19 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     // ST_EPI_SILU_MUL: virtual tile v = (tile v >> 1 of matrix v & 1), dealt in PAIRS, so a workgroup holds w1 and w3 of the same rows
     const bool pairs = a.epi == ST_EPI_SILU_MUL;
     const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
-    const uint32_t t0 = um * (uint32_t)(((uint64_t)blockIdx.x * units) / gridDim.x), t1 = um * (uint32_t)(((uint64_t)(blockIdx.x + 1) * units) / gridDim.x);
+    const uint32_t S = a.ksplit > 1 ? a.ksplit : 1u, bg = (uint32_t)blockIdx.x / S, ks = (uint32_t)blockIdx.x - bg * S, ng = (uint32_t)gridDim.x / S;
+    if (bg >= ng) return;
+    const uint32_t t0 = um * (uint32_t)(((uint64_t)bg * units) / ng), t1 = um * (uint32_t)(((uint64_t)(bg + 1) * units) / ng);
     if (t1 <= t0) return;
     auto tile_of = [&](uint32_t v, uint32_t* g, uint32_t* tile) {   // virtual tile -> (matrix, 16-row tile in it)
         if (pairs) { *g = v & 1u; *tile = v >> 1; }
         else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
     };
     const uint32_t nt = t1 - t0;
-    const uint32_t nch = a.K / KC;
+    const uint32_t nch_all = a.K / KC, ch0 = (uint32_t)(((uint64_t)ks * nch_all) / S);
+    const uint32_t nch = (uint32_t)(((uint64_t)(ks + 1) * nch_all) / S) - ch0;      // this workgroup's K-chunks (all of them without a split)
+    const uint32_t kbase = ch0 * KC;
+    if (nch == 0) return;                                                           // (the host keeps S <= K / KC)
     typedef const f4 __attribute__((address_space(1))) gf4;
     constexpr int KB = KC / 64;
     constexpr int KA0 = (MAXT * NCT >= 4) ? 1 : (MAXT * NCT >= 2 ? 2 : 4), KA = KA0 < KB ? KA0 : KB;
@@ -310,11 +322,11 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         for (int i = 0; i < NX; ++i) {
             uint32_t c = (uint32_t)i * RPP + rsub;
             c = c < a.n ? c : a.n - 1;
-            xp[i] = a.x + (size_t)c * a.ldx + seg * 4;
+            xp[i] = a.x + (size_t)c * a.ldx + kbase + seg * 4;
         }
         constexpr int NS = 2;            // register sets = chunks in flight (four measured no better than two for single-tile workgroups)
         // gamma chunk: fetched with every set (from x itself when the launch has no norm: the count of loads per set stays a constant)
-        const float* gp = (a.gamma ? a.gamma : a.x) + seg * 4;
+        const float* gp = (a.gamma ? a.gamma : a.x) + kbase + seg * 4;
         const bool norm = a.gamma != nullptr;
         double ssq[NX];
 #pragma unroll
@@ -360,8 +372,8 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 const uint32_t row = tile * 16 + (rr & 15);
                 const uint64_t qb = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
                 const uint64_t sb = (uint64_t)a.ws[0] + (g >= 1 ? (uint64_t)a.ws[1] - (uint64_t)a.ws[0] : 0) + (g == 2 ? (uint64_t)a.ws[2] - (uint64_t)a.ws[1] : 0);
-                qp[i] = (const signed char*)qb + (size_t)row * a.K + igrp[i] * 16;
-                sp[i] = (const float*)sb + (size_t)row * (a.K / 32) + igrp[i] / 2;
+                qp[i] = (const signed char*)qb + (size_t)row * a.K + kbase + igrp[i] * 16;
+                sp[i] = (const float*)sb + (size_t)row * (a.K / 32) + kbase / 32 + igrp[i] / 2;
             }
             typedef const u4 __attribute__((address_space(1))) gu4;
             typedef const float __attribute__((address_space(1))) gfl;
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             tile_of(t0 + (rr >> 4), &g, &tile);
             const uint32_t row = tile * 16 + (rr & 15);
             const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
-            wp[i] = (const float*)base + (size_t)row * a.K + seg * 4;
+            wp[i] = (const float*)base + (size_t)row * a.K + kbase + seg * 4;
         }
         f4 ws[NS][NW], xs[NS][NX], gs[NS];
         auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], f4& gq, uint32_t ch) {
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                     } else {
                         const size_t o = (size_t)col * a.ldy + row;
                         const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
-                        float* yp = g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2]);
+                        float* yp = (g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2])) + (size_t)ks * a.ysplit;
                         if (rp) {
                             const f4 rv = *(const f4*)(rp + o);
                             s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
@@ -628,6 +640,77 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         __syncthreads();
     }
 }
+// Second half of a K-split launch: token row b of  y = resid + ((p_0 + p_1) + ...) + p_{S-1}  (fixed order: bit-reproducible; Add
+// ml.go:2515-2584), and - gamma != nullptr - the RMSNorm * weight of that row for the next matmul into h (ml.go:1753-1812, 1877-1914: fp32
+// squares, f64 sum, one fp32 scale, two roundings per element - k_rmsnorm_rows' arithmetic on a row that is in registers anyway, so the
+// split costs no launch: this kernel stands where the norm's stood).  One workgroup per row, rows of up to 8192 floats in registers.
+struct StreamReduceArgs {
+    const float* part;   // [S][n][ldy] partial products
+    uint64_t stride;     // floats between partials
+    const float* resid;  // [n][ldy] or nullptr
+    float* y;            // [n][ldy]
+    const float* gamma;  // [d] or nullptr: no norm output
+    float* h;            // [n][d] normalised rows
+    uint32_t S, d, ldy;
+};
+__global__ __launch_bounds__(256) void k_stream_reduce_norm(const StreamReduceArgs a) {
+    __shared__ double sred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NV = 8;
+    const uint32_t d4 = a.d / 4;
+    const size_t ro = (size_t)blockIdx.x * a.ldy;
+    f4 v[NV], g[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {       // unconditional loads from a clamped index
+        const uint32_t i = (uint32_t)tid + (uint32_t)j * 256, ic = i < d4 ? i : 0;
+        v[j] = ((const f4*)(a.part + ro))[ic];
+        g[j] = a.gamma ? ((const f4*)a.gamma)[ic] : f4{1.f, 1.f, 1.f, 1.f};
+    }
+    for (uint32_t s = 1; s < a.S; ++s) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)j * 256;
+            const f4 q = ((const f4*)(a.part + (size_t)s * a.stride + ro))[i < d4 ? i : 0];
+            v[j].x = __fadd_rn(v[j].x, q.x); v[j].y = __fadd_rn(v[j].y, q.y); v[j].z = __fadd_rn(v[j].z, q.z); v[j].w = __fadd_rn(v[j].w, q.w);
+        }
+    }
+    if (a.resid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)j * 256;
+            const f4 q = ((const f4*)(a.resid + ro))[i < d4 ? i : 0];
+            v[j].x = __fadd_rn(v[j].x, q.x); v[j].y = __fadd_rn(v[j].y, q.y); v[j].z = __fadd_rn(v[j].z, q.z); v[j].w = __fadd_rn(v[j].w, q.w);
+        }
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)j * 256;
+        if (i < d4) {
+            ((f4*)(a.y + ro))[i] = v[j];
+            ss += (double)__fmul_rn(v[j].x, v[j].x); ss += (double)__fmul_rn(v[j].y, v[j].y);
+            ss += (double)__fmul_rn(v[j].z, v[j].z); ss += (double)__fmul_rn(v[j].w, v[j].w);
+        }
+    }
+    if (!a.gamma) return;
+    ss = wave_sum_f64(ss);
+    if (lane == 0) sred[wave] = ss;
+    __syncthreads();
+    const double mean = (((sred[0] + sred[1]) + sred[2]) + sred[3]) / (double)a.d;
+    const float scale = (float)(1.0 / sqrt(mean + 1e-5));
+    float* hr = a.h + (size_t)blockIdx.x * a.d;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)j * 256;
+        if (i < d4) {
+            f4 o;
+            o.x = __fmul_rn(g[j].x, __fmul_rn(v[j].x, scale)); o.y = __fmul_rn(g[j].y, __fmul_rn(v[j].y, scale));
+            o.z = __fmul_rn(g[j].z, __fmul_rn(v[j].z, scale)); o.w = __fmul_rn(g[j].w, __fmul_rn(v[j].w, scale));
+            ((f4*)hr)[i] = o;
+        }
+    }
+}
+
 __host__ __device__ inline size_t stream2_lds_bytes(int maxt, int nct, int kc) { return 2 * stream_lds_bytes(maxt, nct, kc) + 256; }   // + per-column norm scales
 
 }  // namespace lh

@@ -436,7 +436,8 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     static const bool v1_only = env_int("LLAMAHIP_STREAM_MM", 2) == 1;
     const bool q8 = a.ws[0] != nullptr;
     const bool v2 = (!v1_only || q8) && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
-    if ((q8 || a.gamma) && !v2) return -1;
+    if ((q8 || a.gamma || a.ksplit > 1) && !v2) return -1;
+    const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
     int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, true>, lds, flags[2])
@@ -444,8 +445,8 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, q8 ? (uint64_t)a.groups * a.M * a.K / 32 * 36 : (uint64_t)a.groups * a.M * a.K * 4);
-    if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, true>), dim3(ctx->ds->num_cu), dim3(2 * ST_TH), lds, ctx->stream, a);
-    else if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, false>), dim3(ctx->ds->num_cu), dim3(2 * ST_TH), lds, ctx->stream, a);
+    if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, true>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
+    else if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, false>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -462,6 +463,16 @@ template <int MAXT>
 static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (a.n <= 16) return launch_stream_kc<MAXT, 1>(ctx, a, name);
     return launch_stream_kc<MAXT, 2>(ctx, a, name);
+}
+static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name, uint32_t maxt) {
+    switch (maxt) {
+        case 1: return launch_stream_n<1>(ctx, a, name);
+        case 2: return launch_stream_n<2>(ctx, a, name);
+        case 3: return launch_stream_n<3>(ctx, a, name);
+        case 4: return launch_stream_n<4>(ctx, a, name);
+        case 5: case 6: return launch_stream_n<6>(ctx, a, name);
+        default: return launch_stream_n<8>(ctx, a, name);
+    }
 }
 // returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
@@ -483,14 +494,45 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
         a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; a.ws[g] = wsc ? wsc[g] : nullptr;
         if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || (a.ws[g] && ((uintptr_t)a.ws[g] & 3))) return -1;
     }
-    switch (maxt) {
-        case 1: return launch_stream_n<1>(ctx, a, name);
-        case 2: return launch_stream_n<2>(ctx, a, name);
-        case 3: return launch_stream_n<3>(ctx, a, name);
-        case 4: return launch_stream_n<4>(ctx, a, name);
-        case 5: case 6: return launch_stream_n<6>(ctx, a, name);
-        default: return launch_stream_n<8>(ctx, a, name);
+    return launch_stream_maxt(ctx, a, name, maxt);
+}
+
+// Single-tile matrices (wo, w2: one 16-row tile per CU) at 17..32 rows: pairs of workgroups split the contraction (StreamArgs::ksplit), so a
+// workgroup re-reads half of X out of L2 for twice the rows, and k_stream_reduce_norm adds the two partials + the residual and
+// writes the RMSNorm * gamma rows the NEXT matmul reads - it stands where that norm's launch stood.  Standalone, 32 rows (tools/
+// stream_mm_check, profiles/r02d_stream_ksplit.txt): w2 55.6 -> 45.6 us, wo 23.9 -> 22.0 us; at 16 rows nothing (37.7 -> 37.0, 17.9 -> 21.1).
+// returns -1 when not applicable (the caller takes the one-launch path).  LLAMAHIP_STREAM_KSPLIT: bit 0 wo, bit 1 w2 (default 3).
+static int stream_ksplit_mask() { static const int v = env_int("LLAMAHIP_STREAM_KSPLIT", 3); return v; }
+static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, const float* x, uint32_t ldx, uint32_t M, uint32_t K, uint32_t n, const float* resid,
+                             float* y, const float* gamma, float* h, const char* name) {
+    constexpr uint32_t S = 2;
+    if (!stream_mm_on() || env_int("LLAMAHIP_STREAM_MM", 2) == 1 || n <= 16 || n > STREAM_MAX_ROWS || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return -1;
+    if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15) || ((uintptr_t)wsc & 3)) return -1;
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, ngrp = ncu / S;
+    if (ngrp == 0) return -1;
+    const uint32_t maxt = (M / 16 + ngrp - 1) / ngrp;
+    if (maxt > 8) return -1;
+    const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8);
+    if (stream2_lds_bytes(mt, 2, 128) > 160 * 1024) return -1;
+    const uint64_t need = (uint64_t)S * n * M;
+    if (need > ctx->splitk_floats) {
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
+        ctx->splitk = nullptr; ctx->splitk_floats = 0;
+        LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
+        ctx->splitk_floats = need;
     }
+    StreamArgs a = {};
+    a.x = x; a.groups = 1; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = M; a.w[0] = w; a.ws[0] = wsc; a.y[0] = ctx->splitk;
+    a.ksplit = S; a.ysplit = (uint64_t)n * M;
+    const int rs = launch_stream_maxt(ctx, a, name, maxt);
+    if (rs) return rs;
+    if (g_prepare_only) return 0;
+    StreamReduceArgs r = {};
+    r.part = ctx->splitk; r.stride = a.ysplit; r.resid = resid; r.y = y; r.gamma = gamma; r.h = h; r.S = S; r.d = M; r.ldy = M;
+    { TraceScope ts_(ctx->stream, "stream_reduce_norm"); hipLaunchKernelGGL(k_stream_reduce_norm, dim3(n), dim3(256), 0, ctx->stream, r); }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
 }
 
 // fused != nullptr: GEMM_EPI_SILU_MUL (w = {w1, w3}, y[0] = gated output [n][M]) or GEMM_EPI_QKV_ROPE (w = {wq, wk, wv}; outputs in *fused) in
@@ -1199,12 +1241,16 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     }
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
     const uint32_t d = m.d, F = m.F;
+    bool h_ready = false;   // p->h already holds this layer's RMSNorm * attn_norm rows (written by the previous layer's w2 reduce pass)
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
         const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && stream_mm_on() && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;   // grouped MFMA launches: from 9 rows (tile GEMM), from 2 rows on the streaming MFMA kernel
         const bool q8 = m.wtype == 7;
         bool qkv_roped = false, gated = false;
+        // 17..32 rows: wo / w2 as K-split pairs whose reduce pass also writes the next norm's rows into p->h (gemm_stream_split)
+        const int ksp = (n > 16 && n <= STREAM_MAX_ROWS && (q8 ? q8_stream : mfma)) ? stream_ksplit_mask() : 0;
+        bool hf_ready = false;
         const float* wqkv[3] = {L.wq, L.wk, L.wv};
         const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
         float* yqkv[3] = {p->qraw, p->kraw, p->vraw};
@@ -1219,7 +1265,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if (rs > 0) return rs;
             qkv_roped = rs == 0;
         }
-        if (!qkv_roped) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
+        if (!qkv_roped && !h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
+        h_ready = false;
         if (qkv_roped) {
         } else if (q8) {
             StreamArgs fa = {};
@@ -1256,7 +1303,14 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
             if ((rc = launch_attention(ctx, a, past + n))) return rc;
         }
-        if (q8) { if ((rc = gemm_q8(ctx, L.wo, L.s_wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_q8_wo"))) return rc; }
+        int wo_rs = -1;
+        if (ksp & 1) {
+            wo_rs = gemm_stream_split(ctx, L.wo, q8 ? L.s_wo : nullptr, p->attn, d, d, d, n, x, p->xb, L.ffn_norm, p->h, q8 ? "stream_q8_wo_ksplit" : "stream_wo_ksplit");
+            if (wo_rs > 0) return wo_rs;
+            hf_ready = wo_rs == 0;
+        }
+        if (wo_rs == 0) {
+        } else if (q8) { if ((rc = gemm_q8(ctx, L.wo, L.s_wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_q8_wo"))) return rc; }
         else if ((rc = gemm_small_n(ctx, L.wo, p->attn, p->xb, x, d, d, n, d, d, "gemm_wo"))) return rc;
         const float* w13[2] = {L.w1, L.w3};
         const float* s13[2] = {L.s_w1, L.s_w3};
@@ -1271,7 +1325,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if (rs > 0) return rs;
             gated = rs == 0;
         }
-        if (!gated) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
+        if (!gated && !hf_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
         if (gated) {
         } else if (q8) {
             StreamArgs fa = {};
@@ -1300,7 +1354,15 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                            (const float*)p->a3, p->g, (uint64_t)n * F); }
         const bool last = il + 1 == m.layer1;
         float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
-        if (q8) { if ((rc = gemm_q8(ctx, L.w2, L.s_w2, p->g, y, p->xb, d, F, n, F, d, "gemm_q8_w2"))) return rc; }
+        int w2_rs = -1;
+        if (ksp & 2) {
+            const float* next_gamma = last ? nullptr : m.layers[il + 1].attn_norm;   // the next layer's first norm rides on the reduce pass
+            w2_rs = gemm_stream_split(ctx, L.w2, q8 ? L.s_w2 : nullptr, p->g, F, d, F, n, p->xb, y, next_gamma, p->h, q8 ? "stream_q8_w2_ksplit" : "stream_w2_ksplit");
+            if (w2_rs > 0) return w2_rs;
+            h_ready = w2_rs == 0 && next_gamma != nullptr;
+        }
+        if (w2_rs == 0) {
+        } else if (q8) { if ((rc = gemm_q8(ctx, L.w2, L.s_w2, p->g, y, p->xb, d, F, n, F, d, "gemm_q8_w2"))) return rc; }
         else if ((rc = gemm_small_n(ctx, L.w2, p->g, y, p->xb, d, F, n, F, d, "gemm_w2"))) return rc;
         x = p->xa;
         LH_HIP(ctx, hipGetLastError());

@@ -1,5 +1,7 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
-// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC]   (N <= 32)
+// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit]]]
+// mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 3 specialised waves + block-int8; ksplit S > 1 (mode 2 / 3): groups of S
+// workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
 #define STREAM_TRACE
 #include "../llama.go_amd/csrc/kernels_stream.h"
 #include <cstdio>
@@ -10,6 +12,7 @@
 using namespace lh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 static int g_kc = 128;
+static float* g_yfinal = nullptr;
 template <int MAXT, int NCT, int KC> static void run_kc(const StreamArgs& a, int nCU) {
     const size_t lds = std::max<size_t>(stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);
     CK(hipFuncSetAttribute((const void*)k_stream_mm<MAXT, NCT, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -39,8 +42,17 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
     { unsigned long long tr[64]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost)); const double nh = (double)(a.K / KC);
       printf("   loader wave 0, shader clocks per chunk: wait loads %.0f | stash %.0f | issue %.0f | barrier %.0f\n", tr[0] / nh, tr[1] / nh, tr[2] / nh, tr[3] / nh);
       printf("   MFMA wave 4:                            barrier %.0f | compute %.0f\n", tr[32] / nh, tr[33] / nh); }
-    printf("k_stream_mm2<%d,%d,%d%s> (specialised waves): %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, q8 ? ",int8" : "", ms * 200,
+    printf("k_stream_mm2<%d,%d,%d%s> (specialised waves%s): %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, q8 ? ",int8" : "", a.ksplit > 1 ? ", K-split" : "", ms * 200,
            (double)a.M * a.K * (q8 ? 36.0 / 32 : 4.0) / (ms * 200) / 1e3);
+    if (a.ksplit > 1) {
+        StreamReduceArgs r = {}; r.part = a.y[0]; r.stride = a.ysplit; r.y = g_yfinal; r.S = a.ksplit; r.d = a.M; r.ldy = a.ldy;
+        hipLaunchKernelGGL(k_stream_reduce_norm, dim3(a.n), dim3(256), 0, 0, r);
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i) { hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), lds, 0, a); hipLaunchKernelGGL(k_stream_reduce_norm, dim3(a.n), dim3(256), 0, 0, r); }
+        CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("   with the reduce pass: %.2f us per pair of launches\n", ms * 200);
+    }
 }
 static int g_v2 = 0;
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
@@ -80,7 +92,11 @@ int main(int argc, char** argv) {
     }
     StreamArgs a = {}; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
     CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
-    const uint32_t T = M / 16, maxt = (T + nCU - 1) / nCU;
+    const uint32_t S = argc > 6 ? (uint32_t)atoi(argv[6]) : 1u;
+    float* dP = nullptr;
+    g_yfinal = dY;
+    if (S > 1) { CK(hipMalloc(&dP, (size_t)S * N * M * 4)); CK(hipMemset(dP, 0xFF, (size_t)S * N * M * 4)); a.y[0] = dP; a.ksplit = S; a.ysplit = (uint64_t)N * M; }
+    const uint32_t T = M / 16, ngrp = (uint32_t)nCU / S, maxt = (T + ngrp - 1) / ngrp;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
 #define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
