@@ -424,9 +424,11 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
 // ---- short prompts, 9..64 rows: the weight-streaming MFMA kernel (kernels_stream.h) ------------------------------------------------
 static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 1); return v != 0; }
-// 33..64 rows stay on the tile GEMM: with four column tiles every workgroup re-reads more activation bytes out of L2 per chunk than
-// it streams weight bytes from HBM, and the matrix pipe is the limit anyway (measured 11.4-11.9 ms either way at 33..64 rows)
-static constexpr uint32_t STREAM_MAX_ROWS = 32;
+// up to 48 rows = three column tiles (six row tiles + three column tiles, two images: 152 KB of LDS).  Four column tiles do not fit next
+// to six row tiles, and with the row tiles capped at three they measured 11.4-11.9 ms at 33..64 rows, no better than the tile GEMM.
+// LLAMAHIP_STREAM_MAX_ROWS lowers the limit for A/B runs.
+static constexpr uint32_t STREAM_ROWS_BUILT = 48;
+static uint32_t stream_max_rows() { static const int v = env_int("LLAMAHIP_STREAM_MAX_ROWS", (int)STREAM_ROWS_BUILT); return (uint32_t)std::min<int>(std::max(v, 0), (int)STREAM_ROWS_BUILT); }
 
 template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
@@ -440,14 +442,16 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
+    if (!v2 && NCT > 2) return -1;     // three column tiles (33..48 rows) exist in the specialised variant only
+    constexpr int NCT1 = NCT <= 2 ? NCT : 2;
     int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, true>, lds, flags[2])
-                : v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, false>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT, KC>, lds, flags[0]);
+                : v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, false>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT1, KC>, lds, flags[0]);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, q8 ? (uint64_t)a.groups * a.M * a.K / 32 * 36 : (uint64_t)a.groups * a.M * a.K * 4);
     if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, true>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     else if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, false>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT1, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -462,7 +466,8 @@ static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) 
 template <int MAXT>
 static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (a.n <= 16) return launch_stream_kc<MAXT, 1>(ctx, a, name);
-    return launch_stream_kc<MAXT, 2>(ctx, a, name);
+    if (a.n <= 32) return launch_stream_kc<MAXT, 2>(ctx, a, name);
+    return launch_stream_kc<MAXT, 3>(ctx, a, name);
 }
 static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name, uint32_t maxt) {
     switch (maxt) {
@@ -477,13 +482,13 @@ static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name
 // returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                              uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr, const float* const* wsc = nullptr) {
-    if (!stream_mm_on() || n > STREAM_MAX_ROWS || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
+    if (!stream_mm_on() || n > stream_max_rows() || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
     // ST_EPI_SILU_MUL deals (w1, w3) tile pairs: twice the pairs' ceiling
     const uint32_t maxt = (fused && fused->epi == ST_EPI_SILU_MUL) ? 2 * ((M / 16 + ncu - 1) / ncu) : (T + ncu - 1) / ncu;
     if (maxt > 8) return -1;
     if (fused && fused->epi != ST_EPI_STORE) {   // the fused epilogues live in the wave-specialised variant only: its two images must fit
-        const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8), nct = n <= 16 ? 1 : 2;
+        const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8), nct = n <= 16 ? 1 : (n <= 32 ? 2 : 3);
         if ((env_int("LLAMAHIP_STREAM_MM", 2) == 1 && !wsc) || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, nct, 128) > 160 * 1024) return -1;
         if (fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return -1;
     }
@@ -497,7 +502,7 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
     return launch_stream_maxt(ctx, a, name, maxt);
 }
 
-// Single-tile matrices (wo, w2: one 16-row tile per CU) at 17..32 rows: pairs of workgroups split the contraction (StreamArgs::ksplit), so a
+// Single-tile matrices (wo, w2: one 16-row tile per CU) at 17..48 rows: pairs of workgroups split the contraction (StreamArgs::ksplit), so a
 // workgroup re-reads half of X out of L2 for twice the rows, and k_stream_reduce_norm adds the two partials + the residual and
 // writes the RMSNorm * gamma rows the NEXT matmul reads - it stands where that norm's launch stood.  Standalone, 32 rows (tools/
 // stream_mm_check, profiles/r02d_stream_ksplit.txt): w2 55.6 -> 45.6 us, wo 23.9 -> 22.0 us; at 16 rows nothing (37.7 -> 37.0, 17.9 -> 21.1).
@@ -505,15 +510,18 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
 static int stream_ksplit_mask() { static const int v = env_int("LLAMAHIP_STREAM_KSPLIT", 3); return v; }
 static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, const float* x, uint32_t ldx, uint32_t M, uint32_t K, uint32_t n, const float* resid,
                              float* y, const float* gamma, float* h, const char* name) {
-    constexpr uint32_t S = 2;
-    if (!stream_mm_on() || env_int("LLAMAHIP_STREAM_MM", 2) == 1 || n <= 16 || n > STREAM_MAX_ROWS || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return -1;
+    // pairs: four-way splits measured no better, standalone (w2 at 32 / 48 rows: 45.6 / 62.2 us in pairs, 47.6 / 60.6 in fours, + a longer
+    // reduce pass) and in the model (40 / 48 tokens: 8.94 / 9.01 ms vs 9.08 / 9.24); LLAMAHIP_STREAM_KSPLIT_S overrides for A/B runs
+    static const int s_env = env_int("LLAMAHIP_STREAM_KSPLIT_S", 0);
+    const uint32_t S = s_env > 1 ? (uint32_t)s_env : 2u;
+    if (!stream_mm_on() || env_int("LLAMAHIP_STREAM_MM", 2) == 1 || n <= 16 || n > stream_max_rows() || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return -1;
     if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15) || ((uintptr_t)wsc & 3)) return -1;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, ngrp = ncu / S;
     if (ngrp == 0) return -1;
     const uint32_t maxt = (M / 16 + ngrp - 1) / ngrp;
     if (maxt > 8) return -1;
     const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8);
-    if (stream2_lds_bytes(mt, 2, 128) > 160 * 1024) return -1;
+    if (stream2_lds_bytes(mt, n <= 32 ? 2 : 3, 128) > 160 * 1024) return -1;
     const uint64_t need = (uint64_t)S * n * M;
     if (need > ctx->splitk_floats) {
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -540,7 +548,7 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
 // the caller runs the plain GEMM + the separate pass.
 int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                     uint32_t K, uint32_t n, uint32_t ldy, const char* name, const GemmArgs* fused = nullptr) {
-    if (n <= STREAM_MAX_ROWS && !fused) {
+    if (n <= stream_max_rows() && !fused) {
         const int rs = gemm_stream_group(ctx, x, ldx, groups, w, y, r, M, K, n, ldy, name);
         if (rs >= 0) return rs;
     }
@@ -1147,7 +1155,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    const bool q8_stream = m.wtype == 7 && n >= 3 && n <= STREAM_MAX_ROWS && stream_mm_on() && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
+    const bool q8_stream = m.wtype == 7 && n >= 3 && n <= stream_max_rows() && stream_mm_on() && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
                            (3 * m.d / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu <= 8 && 2 * ((m.F / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu) <= 8;
     if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
@@ -1249,12 +1257,12 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const bool q8 = m.wtype == 7;
         bool qkv_roped = false, gated = false;
         // 17..32 rows: wo / w2 as K-split pairs whose reduce pass also writes the next norm's rows into p->h (gemm_stream_split)
-        const int ksp = (n > 16 && n <= STREAM_MAX_ROWS && (q8 ? q8_stream : mfma)) ? stream_ksplit_mask() : 0;
+        const int ksp = (n > 16 && n <= stream_max_rows() && (q8 ? q8_stream : mfma)) ? stream_ksplit_mask() : 0;
         bool hf_ready = false;
         const float* wqkv[3] = {L.wq, L.wk, L.wv};
         const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
         float* yqkv[3] = {p->qraw, p->kraw, p->vraw};
-        if (n <= STREAM_MAX_ROWS && (q8 || mfma)) {
+        if (n <= stream_max_rows() && (q8 || mfma)) {
             // short prompts: ONE launch for RMSNorm (folded: gamma at staging, the per-token scale in the epilogue) -> wq|wk|wv -> RoPE -> cache append
             StreamArgs fa = {};
             fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
@@ -1271,14 +1279,14 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (q8) {
             StreamArgs fa = {};
             fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fa, sqkv) : -1;
+            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fa, sqkv) : -1;
             if (rs > 0) return rs;
             qkv_roped = rs == 0;
             if (!qkv_roped && (rc = gemm_q8_group(ctx, p->h, d, 3, wqkv, sqkv, yqkv, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
         } else if (mfma) {
             StreamArgs fa = {};   // short prompts: RoPE + cache append in the GEMM's epilogue (no rope_store pass, no raw q/k/v round trip)
             fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
+            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
             if (rs < 0 && n > 64) {   // long prompts: the same epilogue in the tile GEMM
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_QKV_ROPE; ga.q_out = p->q; ga.k_cache = m.kc + slot; ga.v_cache = m.vc + slot; ga.rope = rope; ga.hd = m.hd; ga.past = past;
@@ -1316,7 +1324,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const float* s13[2] = {L.s_w1, L.s_w3};
         float* y13[2] = {p->a1, p->a3};
         float* yg[2] = {p->g, nullptr};
-        if (n <= STREAM_MAX_ROWS && (q8 || mfma)) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
+        if (n <= stream_max_rows() && (q8 || mfma)) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
             fa.gamma = (n <= 16 && env_int("LLAMAHIP_STREAM_NORM", 1)) ? L.ffn_norm : nullptr;
@@ -1330,14 +1338,14 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (q8) {
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
-            const int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, s13) : -1;
+            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, s13) : -1;
             if (rs > 0) return rs;
             gated = rs == 0;
             if (!gated && (rc = gemm_q8_group(ctx, p->h, d, 2, w13, s13, y13, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
         } else if (mfma) {
             StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
             fa.epi = ST_EPI_SILU_MUL;
-            int rs = n <= STREAM_MAX_ROWS ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
+            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
             if (rs < 0 && n > 64) {
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_SILU_MUL;

@@ -271,10 +271,10 @@ def test_resident_decode_kernel_matches_oracle(product, oracle, shape, prompt, m
     m.free()
 
 
-@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 64, 100])
+@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 64, 100])
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
-    """One Eval of N tokens: 2..32 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
-    append / SiLU fused into its epilogues; one and two 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
+    """One Eval of N tokens: 2..48 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
+    append / SiLU fused into its epilogues; one, two and three 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
     (v_mfma_f32_32x32x2_f32) + blocked attention; the next decode steps read the KV cache that prefill wrote."""
     rng = np.random.default_rng(n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n_prompt)]
@@ -479,6 +479,21 @@ def test_7b_shape_slice_matches_oracle(product, oracle, layers):
     assert toks_h == toks_o
 
 
+@pytest.mark.parametrize("n_prompt", [12, 24, 40])
+def test_7b_shape_slice_short_prompts_match_oracle(product, oracle, n_prompt):
+    """The 7B layer shape at the prompt lengths where the stream kernel changes its launch shape: 12 rows (RMSNorm folded into the
+    GEMMs), 24 rows (two column tiles; wo / w2 as K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles,
+    four-way split) - 2 layers, then 2 decode steps on the cache the prompt wrote."""
+    rng = np.random.default_rng(100 + n_prompt)
+    prompt = [int(t) for t in rng.integers(0, SHAPES["7B"]["vocab"], n_prompt)]
+    out = decode_both(product, oracle, "7B", 64, prompt, 3, layers=2, threads=64)
+    toks_h, lg_h = out["hip"]
+    toks_o, lg_o = out["orc"]
+    assert out["fused"] == 1
+    assert rel(lg_h, lg_o) <= TOL
+    assert toks_h == toks_o
+
+
 @pytest.mark.parametrize("shape,layers,ctx", [("tiny", None, 32), ("small", None, 64), ("7B", 2, 32)])
 def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, layers, ctx):
     """BASELINE config 4: block-int8 weight matrices (format ours: the reference has none).  The checker runs the fp32 path on
@@ -505,7 +520,7 @@ def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, lay
     assert th == to
 
 
-@pytest.mark.parametrize("shape,n_prompt", [("small", 3), ("small", 8), ("small", 16), ("small", 20), ("small", 32), ("small", 33), ("small", 100), ("small", 300), ("13B", 72),
+@pytest.mark.parametrize("shape,n_prompt", [("small", 3), ("small", 8), ("small", 16), ("small", 20), ("small", 32), ("small", 33), ("small", 45), ("small", 48), ("small", 100), ("small", 300), ("13B", 72),
                                             ("13B", 24)])
 def test_block_int8_prefill_gemm_matches_dequantised_oracle(product, oracle, shape, n_prompt):
     """Prompts of >= 32 tokens on a block-int8 model run the dequantising MFMA GEMM (k_gemm_q8: int8 + scale -> fl32(d*q) -> LDS ->
