@@ -284,7 +284,7 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
 // fl32(d * q) into the image - literally the checker's dequantise-then-fp32 semantics, like k_gemm_q8 - the compute waves see fp32.
 template <int MAXT, int NCT, int KC, bool Q8 = false>
 __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
-    static_assert(KC == 128 || KC == 256, "chunk");
+    static_assert(KC == 64 || KC == 128 || KC == 256, "chunk");   // 64: four column tiles (49..64 rows) - half-length chunks make room for 6 + 4 tiles twice
     constexpr int ST_PITCH = KC + 4, RPP = 1024 / KC;
     constexpr int NW = MAXT * 16 / RPP, NX = NCT * 16 / RPP;
     constexpr size_t IMG = (size_t)(MAXT + NCT) * 16 * ST_PITCH;      // floats per image

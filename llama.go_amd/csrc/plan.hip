@@ -425,9 +425,12 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // ---- short prompts, 9..64 rows: the weight-streaming MFMA kernel (kernels_stream.h) ------------------------------------------------
 static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 1); return v != 0; }
 // up to 48 rows = three column tiles (six row tiles + three column tiles, two images: 152 KB of LDS).  Four column tiles do not fit next
-// to six row tiles, and with the row tiles capped at three they measured 11.4-11.9 ms at 33..64 rows, no better than the tile GEMM.
+// to six row tiles with 128-column chunks (with the row tiles capped at three they measured 11.4-11.9 ms at 33..64 rows, no better than
+// the tile GEMM): 49..64 rows run half-length chunks (KC = 64: 2 x (6 + 4) x 16 x 68 floats = 87 KB), fp32 weights only.
 // LLAMAHIP_STREAM_MAX_ROWS lowers the limit for A/B runs.
-static constexpr uint32_t STREAM_ROWS_BUILT = 48;
+static constexpr uint32_t STREAM_ROWS_BUILT = 64, STREAM_ROWS_Q8 = 48;
+static int stream_nct(uint32_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4)); }
+static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static uint32_t stream_max_rows() { static const int v = env_int("LLAMAHIP_STREAM_MAX_ROWS", (int)STREAM_ROWS_BUILT); return (uint32_t)std::min<int>(std::max(v, 0), (int)STREAM_ROWS_BUILT); }
 
 template <int MAXT, int NCT, int KC>
@@ -438,20 +441,21 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     static const bool v1_only = env_int("LLAMAHIP_STREAM_MM", 2) == 1;
     const bool q8 = a.ws[0] != nullptr;
     const bool v2 = (!v1_only || q8) && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
-    if ((q8 || a.gamma || a.ksplit > 1) && !v2) return -1;
+    if ((q8 || a.gamma || a.ksplit > 1 || NCT > 2) && !v2) return -1;   // block-int8, folded norm, K-split, 3 / 4 column tiles: specialised variant only
+    if (q8 && NCT > 3) return -1;
     const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
-    if (!v2 && NCT > 2) return -1;     // three column tiles (33..48 rows) exist in the specialised variant only
-    constexpr int NCT1 = NCT <= 2 ? NCT : 2;
-    int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, true>, lds, flags[2])
-                : v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, false>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT1, KC>, lds, flags[0]);
+    // instantiations outside a variant's range are never launched (returned above); the clamps only keep them from being compiled
+    constexpr int NCT1 = NCT <= 2 ? NCT : 2, KC1 = KC >= 128 ? KC : 128, NCTQ = NCT <= 3 ? NCT : 3, KCQ = KC2 >= 128 ? KC2 : 128;
+    int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCTQ, KCQ, true>, lds, flags[2])
+                : v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, false>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT1, KC1>, lds, flags[0]);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, q8 ? (uint64_t)a.groups * a.M * a.K / 32 * 36 : (uint64_t)a.groups * a.M * a.K * 4);
-    if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, true>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
+    if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCTQ, KCQ, true>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     else if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, false>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT1, KC>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT1, KC1>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -460,14 +464,18 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
 // runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02c_stream_mm_check.txt.
 template <int MAXT, int NCT>
 static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    if (MAXT == 1 && a.K > 4096 && a.K % 256 == 0) return launch_stream<MAXT, NCT, (MAXT == 1 ? 256 : 128)>(ctx, a, name);
-    return launch_stream<MAXT, NCT, 128>(ctx, a, name);
+    if constexpr (NCT == 4) return launch_stream<MAXT, NCT, 64>(ctx, a, name);
+    else {
+        if (MAXT == 1 && a.K > 4096 && a.K % 256 == 0) return launch_stream<MAXT, NCT, (MAXT == 1 ? 256 : 128)>(ctx, a, name);
+        return launch_stream<MAXT, NCT, 128>(ctx, a, name);
+    }
 }
 template <int MAXT>
 static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (a.n <= 16) return launch_stream_kc<MAXT, 1>(ctx, a, name);
     if (a.n <= 32) return launch_stream_kc<MAXT, 2>(ctx, a, name);
-    return launch_stream_kc<MAXT, 3>(ctx, a, name);
+    if (a.n <= 48) return launch_stream_kc<MAXT, 3>(ctx, a, name);
+    return launch_stream_kc<MAXT, 4>(ctx, a, name);
 }
 static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name, uint32_t maxt) {
     switch (maxt) {
@@ -482,14 +490,14 @@ static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name
 // returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                              uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr, const float* const* wsc = nullptr) {
-    if (!stream_mm_on() || n > stream_max_rows() || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
+    if (!stream_mm_on() || n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
     // ST_EPI_SILU_MUL deals (w1, w3) tile pairs: twice the pairs' ceiling
     const uint32_t maxt = (fused && fused->epi == ST_EPI_SILU_MUL) ? 2 * ((M / 16 + ncu - 1) / ncu) : (T + ncu - 1) / ncu;
     if (maxt > 8) return -1;
     if (fused && fused->epi != ST_EPI_STORE) {   // the fused epilogues live in the wave-specialised variant only: its two images must fit
-        const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8), nct = n <= 16 ? 1 : (n <= 32 ? 2 : 3);
-        if ((env_int("LLAMAHIP_STREAM_MM", 2) == 1 && !wsc) || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, nct, 128) > 160 * 1024) return -1;
+        const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8);
+        if ((env_int("LLAMAHIP_STREAM_MM", 2) == 1 && !wsc) || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, stream_nct(n), stream_kc(n)) > 160 * 1024) return -1;
         if (fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return -1;
     }
     StreamArgs a = {};
@@ -514,14 +522,14 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
     // reduce pass) and in the model (40 / 48 tokens: 8.94 / 9.01 ms vs 9.08 / 9.24); LLAMAHIP_STREAM_KSPLIT_S overrides for A/B runs
     static const int s_env = env_int("LLAMAHIP_STREAM_KSPLIT_S", 0);
     const uint32_t S = s_env > 1 ? (uint32_t)s_env : 2u;
-    if (!stream_mm_on() || env_int("LLAMAHIP_STREAM_MM", 2) == 1 || n <= 16 || n > stream_max_rows() || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return -1;
+    if (!stream_mm_on() || env_int("LLAMAHIP_STREAM_MM", 2) == 1 || n <= 16 || n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return -1;
     if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15) || ((uintptr_t)wsc & 3)) return -1;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, ngrp = ncu / S;
     if (ngrp == 0) return -1;
     const uint32_t maxt = (M / 16 + ngrp - 1) / ngrp;
     if (maxt > 8) return -1;
     const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8);
-    if (stream2_lds_bytes(mt, n <= 32 ? 2 : 3, 128) > 160 * 1024) return -1;
+    if (stream2_lds_bytes(mt, stream_nct(n), stream_kc(n)) > 160 * 1024) return -1;
     const uint64_t need = (uint64_t)S * n * M;
     if (need > ctx->splitk_floats) {
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1155,7 +1163,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    const bool q8_stream = m.wtype == 7 && n >= 3 && n <= stream_max_rows() && stream_mm_on() && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
+    const bool q8_stream = m.wtype == 7 && n >= 3 && n <= std::min(stream_max_rows(), STREAM_ROWS_Q8) && stream_mm_on() && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
                            (3 * m.d / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu <= 8 && 2 * ((m.F / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu) <= 8;
     if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode

@@ -56,7 +56,7 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
 }
 static int g_v2 = 0;
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
-    if (g_v2) { if (g_kc >= 256) run2_kc<MAXT, NCT, 256>(a, nCU); else run2_kc<MAXT, NCT, 128>(a, nCU); return; }
+    if (g_v2) { if (g_kc >= 256) run2_kc<MAXT, NCT, 256>(a, nCU); else if (g_kc == 64) run2_kc<MAXT, NCT, 64>(a, nCU); else run2_kc<MAXT, NCT, 128>(a, nCU); return; }
     constexpr int R = MAXT + NCT;
     if (g_kc == 512 && R * 512 <= 2048) run_kc<MAXT, NCT, (R * 512 <= 2048 ? 512 : 128)>(a, nCU);
     else if (g_kc >= 256 && R * 256 <= 2048) run_kc<MAXT, NCT, (R * 256 <= 2048 ? 256 : 128)>(a, nCU);
@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
     if (S > 1) { CK(hipMalloc(&dP, (size_t)S * N * M * 4)); CK(hipMemset(dP, 0xFF, (size_t)S * N * M * 4)); a.y[0] = dP; a.ksplit = S; a.ysplit = (uint64_t)N * M; }
     const uint32_t T = M / 16, ngrp = (uint32_t)nCU / S, maxt = (T + ngrp - 1) / ngrp;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
-#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
+#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0; const uint32_t CT = (N + 15) / 16;
