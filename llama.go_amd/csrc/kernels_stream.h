@@ -56,6 +56,12 @@ struct StreamArgs {
     // 17..32 rows is twice the weight stream; with S = 4 a workgroup reads a quarter of X for four tiles.
     uint32_t ksplit;
     uint64_t ysplit;     // floats between the partial outputs
+    // k_stream_mm2: s_setprio 3 in the loader waves.  A loader wave shares its SIMD with an MFMA wave whose next MFMA is always ready; the
+    // phase traces show the loader's ~20 load instructions per chunk being issued only when that burst ends ("issue" = MFMA burst +
+    // ~450 clocks at every row count, with or without memory traffic: profiles/r02d_stream_traffic_probe.txt), i.e. loading and
+    // computing alternate instead of overlapping.  Measured: the priority changes nothing (the vector adds that form each load's
+    // address are what waits - see probe 16 below); left as a switch, off (LLAMAHIP_STREAM_PRIO).
+    uint32_t prio;
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
     if (wave < 4) {
         // ---- loader waves
+        if (a.prio) __builtin_amdgcn_s_setprio(3);
         const uint32_t rsub = (uint32_t)tid / (KC / 4), seg = (uint32_t)tid % (KC / 4);
         const float* xp[NX];
 #pragma unroll
@@ -458,12 +465,59 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             wp[i] = (const float*)base + (size_t)row * a.K + kbase + seg * 4;
         }
         f4 ws[NS][NW], xs[NS][NX], gs[NS];
+        // tools/stream_mm_check builds timing-only variants (-DSTREAM_PROBE=bits; results are wrong on purpose) that take one traffic class
+        // out of the loop with the instruction stream otherwise unchanged: 1 = every X load re-reads chunk 0 (L1 hits: no L2 -> CU activation
+        // traffic), 2 = X loads non-temporal, 4 = W loads temporal, 8 = every W load re-reads chunk 0 (no HBM stream).  0 in the product.
+#if defined(STREAM_TRACE) && defined(STREAM_PROBE)
+        constexpr int PROBE = STREAM_PROBE;
+#else
+        constexpr int PROBE = 0;
+#endif
+        // 16 = addresses as a uniform (SGPR) base that advances per chunk + a constant 32-bit lane offset (single matrix only: the
+        // checker's case), so the ~20 loads of a chunk need no vector ALU instruction: tests whether the v_lshl_add_u64 in front of every
+        // load is what keeps the loader waves waiting for the MFMA waves' burst to end.  It is: issue phase 5544 -> 1700 clocks per chunk
+        // at 48 rows, launch 114.1 -> 103.5 us.  TIMING ONLY: the loads are inline asm, invisible to the compiler's bookkeeping of
+        // registers with loads in flight (a checked run faults); a product version uses buffer loads with a scalar offset.
+        uint32_t wv[NW], xv[NX];
+        if constexpr (PROBE & 16) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                uint32_t rr = (uint32_t)i * RPP + rsub;
+                rr = rr < nt * 16 ? rr : nt * 16 - 1;
+                wv[i] = (rr * a.K + seg * 4) * 4u;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                uint32_t c = (uint32_t)i * RPP + rsub;
+                c = c < a.n ? c : a.n - 1;
+                xv[i] = (c * a.ldx + seg * 4) * 4u;
+            }
+        }
         auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], f4& gq, uint32_t ch) {
-            const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
+            const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC, k0w = (PROBE & 8) ? 0u : k0, k0x = (PROBE & 1) ? 0u : k0;
+            if constexpr (PROBE & 16) {
+                const char* wb = (const char*)(a.w[0] + (size_t)t0 * 16 * a.K + kbase + k0w);   // uniform
+                const char* xb = (const char*)(a.x + kbase + k0x);
+                // written out: the compiler folds base + offset into a 64-bit VGPR address (one vector add per load) otherwise.  The waits
+                // for these loads are the explicit counted ones of the loop (the compiler does not see asm loads in its own counters).
+                const uint32_t gv = seg * 16;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0));
+                for (int i = 0; i < NW; ++i) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wr[i]) : "v"(wv[i]), "s"(wb) : "memory");
 #pragma unroll
-            for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
+                for (int i = 0; i < NX; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[i]) : "v"(xv[i]), "s"(xb) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gq) : "v"(gv), "s"(xb) : "memory");
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if constexpr (PROBE & 4) wr[i] = *(gf4*)(uintptr_t)(wp[i] + k0w);
+                else wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0w));
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if constexpr (PROBE & 2) xr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(xp[i] + k0x));
+                else xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0x);
+            }
             gq = *(gf4*)(uintptr_t)(gp + k0);
         };
         auto stash = [&](const f4 (&wr)[NW], const f4 (&xr)[NX], const f4& gq, float* im) {

@@ -1,0 +1,7 @@
+#!/bin/bash
+# Builds the standalone checker of the stream GEMM and its timing-only traffic probes (see tools/stream_mm_check.hip) for gfx950.
+cd "$(dirname "$0")/.."
+for p in "" 1 2 4 8 9 16; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 ${p:+-DSTREAM_PROBE=$p} -o tools/stream_mm_check${p:+_p$p} tools/stream_mm_check.hip || exit 1
+done
+ls -la tools/stream_mm_check*

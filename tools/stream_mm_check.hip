@@ -1,7 +1,9 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
-// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit]]]
+// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit [prio]]]]
 // mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 3 specialised waves + block-int8; ksplit S > 1 (mode 2 / 3): groups of S
 // workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
+// Built with -DSTREAM_PROBE=bits (tools/build_probes.sh -> stream_mm_check_p<bits>) the specialised kernel takes one traffic class out of
+// its loop (kernels_stream.h: 1 X from L1, 2 X non-temporal, 4 W temporal, 8 W from cache): timing only, run with STREAM_CHECK_SKIP=1.
 #define STREAM_TRACE
 #include "../llama.go_amd/csrc/kernels_stream.h"
 #include <cstdio>
@@ -93,6 +95,7 @@ int main(int argc, char** argv) {
     StreamArgs a = {}; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
     CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
     const uint32_t S = argc > 6 ? (uint32_t)atoi(argv[6]) : 1u;
+    a.prio = argc > 7 ? (uint32_t)atoi(argv[7]) : 0u;   // 1: loader waves at s_setprio 3
     float* dP = nullptr;
     g_yfinal = dY;
     if (S > 1) { CK(hipMalloc(&dP, (size_t)S * N * M * 4)); CK(hipMemset(dP, 0xFF, (size_t)S * N * M * 4)); a.y[0] = dP; a.ksplit = S; a.ysplit = (uint64_t)N * M; }
@@ -100,6 +103,7 @@ int main(int argc, char** argv) {
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
 #define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
+    if (getenv("STREAM_CHECK_SKIP")) return 0;   // timing-only runs (the -DSTREAM_PROBE builds compute wrong sums on purpose)
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0; const uint32_t CT = (N + 15) / 16;
     std::vector<double> blk((size_t)T * CT, 0.0);
