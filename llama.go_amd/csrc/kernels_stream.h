@@ -56,12 +56,6 @@ struct StreamArgs {
     // 17..32 rows is twice the weight stream; with S = 4 a workgroup reads a quarter of X for four tiles.
     uint32_t ksplit;
     uint64_t ysplit;     // floats between the partial outputs
-    // k_stream_mm2: s_setprio 3 in the loader waves.  A loader wave shares its SIMD with an MFMA wave whose next MFMA is always ready; the
-    // phase traces show the loader's ~20 load instructions per chunk being issued only when that burst ends ("issue" = MFMA burst +
-    // ~450 clocks at every row count, with or without memory traffic: profiles/r02d_stream_traffic_probe.txt), i.e. loading and
-    // computing alternate instead of overlapping.  Measured: the priority changes nothing (the vector adds that form each load's
-    // address are what waits - see probe 16 below); left as a switch, off (LLAMAHIP_STREAM_PRIO).
-    uint32_t prio;
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
 };
@@ -322,7 +316,8 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
     if (wave < 4) {
         // ---- loader waves
-        if (a.prio) __builtin_amdgcn_s_setprio(3);
+        // (s_setprio 3 here was measured: no effect on any phase, profiles/r02d_stream_traffic_probe.txt - it is the loads' vector address
+        // arithmetic that waits for the MFMA burst, see probe 16 below, not the arbitration between the two waves of a SIMD)
         const uint32_t rsub = (uint32_t)tid / (KC / 4), seg = (uint32_t)tid % (KC / 4);
         const float* xp[NX];
 #pragma unroll

@@ -429,7 +429,6 @@ static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 
 // the tile GEMM): 49..64 rows run half-length chunks (KC = 64: 2 x (6 + 4) x 16 x 68 floats = 87 KB), fp32 weights only.
 // LLAMAHIP_STREAM_MAX_ROWS lowers the limit for A/B runs.
 static constexpr uint32_t STREAM_ROWS_BUILT = 64, STREAM_ROWS_Q8 = 48;
-static uint32_t stream_prio() { static const int v = env_int("LLAMAHIP_STREAM_PRIO", 0); return v ? 1u : 0u; }
 static int stream_nct(uint32_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4)); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static uint32_t stream_max_rows() { static const int v = env_int("LLAMAHIP_STREAM_MAX_ROWS", (int)STREAM_ROWS_BUILT); return (uint32_t)std::min<int>(std::max(v, 0), (int)STREAM_ROWS_BUILT); }
@@ -503,7 +502,7 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
     }
     StreamArgs a = {};
     if (fused) a = *fused;
-    a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy; a.prio = stream_prio();
+    a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) {
         a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; a.ws[g] = wsc ? wsc[g] : nullptr;
         if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || (a.ws[g] && ((uintptr_t)a.ws[g] & 3))) return -1;
@@ -541,7 +540,7 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
     }
     StreamArgs a = {};
     a.x = x; a.groups = 1; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = M; a.w[0] = w; a.ws[0] = wsc; a.y[0] = ctx->splitk;
-    a.ksplit = S; a.ysplit = (uint64_t)n * M; a.prio = stream_prio();
+    a.ksplit = S; a.ysplit = (uint64_t)n * M;
     const int rs = launch_stream_maxt(ctx, a, name, maxt);
     if (rs) return rs;
     if (g_prepare_only) return 0;

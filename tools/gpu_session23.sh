@@ -1,5 +1,5 @@
 #!/bin/bash
-# Loader waves at s_setprio 3 (StreamArgs::prio): standalone A/B, one checked run, TTFT A/B, prefill parity with the switch on.
+# Loader waves at s_setprio 3 (a StreamArgs::prio switch that existed for this run only; measured without effect and removed): standalone A/B, one checked run, TTFT A/B, prefill parity with the switch on.
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/s23; mkdir -p $O
 { for cfg in "16 128" "32 128" "48 128" "64 64"; do for pr in 0 1; do

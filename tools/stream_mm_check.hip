@@ -1,5 +1,5 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
-// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit [prio]]]]
+// (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit]]]
 // mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 3 specialised waves + block-int8; ksplit S > 1 (mode 2 / 3): groups of S
 // workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
 // Built with -DSTREAM_PROBE=bits (tools/build_probes.sh -> stream_mm_check_p<bits>) the specialised kernel takes one traffic class out of
@@ -95,7 +95,6 @@ int main(int argc, char** argv) {
     StreamArgs a = {}; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
     CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
     const uint32_t S = argc > 6 ? (uint32_t)atoi(argv[6]) : 1u;
-    a.prio = argc > 7 ? (uint32_t)atoi(argv[7]) : 0u;   // 1: loader waves at s_setprio 3
     float* dP = nullptr;
     g_yfinal = dY;
     if (S > 1) { CK(hipMalloc(&dP, (size_t)S * N * M * 4)); CK(hipMemset(dP, 0xFF, (size_t)S * N * M * 4)); a.y[0] = dP; a.ksplit = S; a.ysplit = (uint64_t)N * M; }
