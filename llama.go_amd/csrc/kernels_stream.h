@@ -67,6 +67,21 @@ __host__ __device__ inline size_t stream_lds_bytes(int maxt, int nct, int kc) { 
 
 typedef float f4m __attribute__((ext_vector_type(4)));
 
+// STREAM_BUFFER_LOADS=1 (build flag, 0 in the shipped library): the fp32 loader waves of k_stream_mm2 fetch through buffer_load with a
+// uniform resource per register (base = first row of its 16-row tile), a constant lane offset and the chunk offset in an SGPR, so no
+// vector ALU instruction stands in front of a load.  Why: profiles/r02d_stream_traffic_probe.txt - from 17 rows on the launch is not
+// memory-bound; the loads' 64-bit vector address adds wait while the MFMA wave of the same SIMD issues back to back, loading and
+// computing alternate.  An inline-asm probe of the same addressing measured 114.1 -> 103.5 us on w1|w3 at 48 rows.  Written at the end of
+// round 2 with no GPU time left: NOT yet run on hardware - build the checker and the library with -DSTREAM_BUFFER_LOADS=1, run
+// tools/stream_mm_check and the GPU suite, then make it the default.
+#ifndef STREAM_BUFFER_LOADS
+#define STREAM_BUFFER_LOADS 0
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const void* base) {
+    // raw buffer (stride 0), no range limit in practice, 32-bit data format (gfx9 resource word 3)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
 // s_waitcnt vmcnt(N) as an instruction the compiler's counter bookkeeping understands (gfx9 encoding)
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -459,6 +474,30 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
             wp[i] = (const float*)base + (size_t)row * a.K + kbase + seg * 4;
         }
+        // STREAM_BUFFER_LOADS: all lanes of register i sit in ONE tile (a pass of the loader covers RPP <= 16 rows and 16 is a multiple
+        // of RPP), so the tile's first row is a uniform base; the lane keeps (row in tile) * K + its 16-byte segment as a byte offset
+        constexpr bool BUF = STREAM_BUFFER_LOADS != 0;
+        __amdgpu_buffer_rsrc_t wres[NW], xres = stream_rsrc(a.x + kbase), gres = stream_rsrc((a.gamma ? a.gamma : a.x) + kbase);
+        uint32_t wvo[NW], xvo[NX];
+        if constexpr (BUF) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint32_t ts0 = ((uint32_t)i * RPP) >> 4, ts = ts0 < nt ? ts0 : nt - 1;   // tile slot of this register: uniform
+                uint32_t g, tile;
+                tile_of(t0 + ts, &g, &tile);
+                const float* mb = g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2]);
+                wres[i] = stream_rsrc(mb + (size_t)tile * 16 * a.K + kbase);
+                uint32_t rr = (uint32_t)i * RPP + rsub;
+                rr = rr < nt * 16 ? rr : nt * 16 - 1;                                          // same clamp as the pointer path
+                wvo[i] = ((rr & 15u) * a.K + seg * 4u) * 4u;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                uint32_t c = (uint32_t)i * RPP + rsub;
+                c = c < a.n ? c : a.n - 1;
+                xvo[i] = (c * a.ldx + seg * 4u) * 4u;
+            }
+        }
         f4 ws[NS][NW], xs[NS][NX], gs[NS];
         // tools/stream_mm_check builds timing-only variants (-DSTREAM_PROBE=bits; results are wrong on purpose) that take one traffic class
         // out of the loop with the instruction stream otherwise unchanged: 1 = every X load re-reads chunk 0 (L1 hits: no L2 -> CU activation
@@ -490,6 +529,15 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         }
         auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], f4& gq, uint32_t ch) {
             const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC, k0w = (PROBE & 8) ? 0u : k0, k0x = (PROBE & 1) ? 0u : k0;
+            if constexpr (BUF) {
+                const uint32_t so = k0 * 4u;     // bytes, uniform: the soffset operand
+#pragma unroll
+                for (int i = 0; i < NW; ++i) wr[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(wres[i], wvo[i], so, 2 /* nt */));
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xr[i] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xres, xvo[i], so, 0));
+                gq = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(gres, seg * 16u, so, 0));
+                return;
+            }
             if constexpr (PROBE & 16) {
                 const char* wb = (const char*)(a.w[0] + (size_t)t0 * 16 * a.K + kbase + k0w);   // uniform
                 const char* xb = (const char*)(a.x + kbase + k0x);

@@ -4,4 +4,6 @@ cd "$(dirname "$0")/.."
 for p in "" 1 2 4 8 9 16; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 ${p:+-DSTREAM_PROBE=$p} -o tools/stream_mm_check${p:+_p$p} tools/stream_mm_check.hip || exit 1
 done
+# the loader on buffer loads (STREAM_BUFFER_LOADS, computes correct results: run WITH the check)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSTREAM_BUFFER_LOADS=1 -o tools/stream_mm_check_buf tools/stream_mm_check.hip || exit 1
 ls -la tools/stream_mm_check*
