@@ -77,6 +77,9 @@ typedef float f4m __attribute__((ext_vector_type(4)));
 #ifndef STREAM_BUFFER_LOADS
 #define STREAM_BUFFER_LOADS 0
 #endif
+#ifndef STREAM_LOADER_SLEEP
+#define STREAM_LOADER_SLEEP 0   // s_sleep argument (units of 64 clocks) of the loader waves behind every chunk barrier; 0 = none (shipped)
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const void* base) {
     // raw buffer (stride 0), no range limit in practice, 32-bit data format (gfx9 resource word 3)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -589,6 +592,13 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 issue(ws[q], xs[q], gs[q], ch + q + NS);
                 ST_STAMP(2);
                 __syncthreads();         // barrier `ch + q`: the image holds the chunk; the compute waves are done with what it held before
+#if STREAM_LOADER_SLEEP > 0
+                // experiment (next round, with STREAM_BUFFER_LOADS): right behind a barrier the MFMA waves' 18 operand reads and the
+                // loaders' 19 image writes per wave land in the CU's LDS queue together (the probe trace shows ~1200 clocks from the
+                // barrier to the 4th MFMA); a loader that has slack (it waits ~3300 clocks at the barrier once its loads issue freely)
+                // can let the reads go first
+                __builtin_amdgcn_s_sleep(STREAM_LOADER_SLEEP);
+#endif
                 ST_STAMP(3);
             }
         }
