@@ -53,7 +53,8 @@ struct StreamArgs {
     // tiles like a whole workgroup does otherwise (so S times as many rows), member s contracts K-chunks [s nch / S, (s + 1) nch / S) and
     // writes its partial sums to y[g] + s * ysplit (no residual); k_stream_reduce_norm adds the S partials in s order.  For the
     // single-tile matrices (wo, w2: M / 16 = #CU tiles): every workgroup reads all of X out of L2, n / 16 bytes per weight byte, which at
-    // 17..32 rows is twice the weight stream; with S = 4 a workgroup reads a quarter of X for four tiles.
+    // 17..32 rows is twice the weight stream; with S = 2 a workgroup stages half of X for two tiles.  (The later traffic probes,
+    // profiles/r02d_stream_traffic_probe.txt, show the gain is in loader instructions per weight byte rather than in L2 traffic.)
     uint32_t ksplit;
     uint64_t ysplit;     // floats between the partial outputs
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
