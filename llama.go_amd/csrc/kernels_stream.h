@@ -207,7 +207,10 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #ifdef STREAM_TRACE
     unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-#define ST_STAMP(i) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[i] += tn_ - tl; tl = tn_; } while (0)
+// (sched_barrier on both sides: without it the compiler samples the clock in the middle of a phase - the MFMA waves' "compute" stamp of
+// the round-2 traces sits behind the 4th of 144 MFMAs, profiles/r02d_stream_traffic_probe.txt: only per-chunk SUMS of those are meaningful)
+#define ST_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[i] += tn_ - tl; tl = tn_; \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define ST_STAMP(i) do { } while (0)
 #endif

@@ -4,6 +4,7 @@ cd "$(dirname "$0")/.."
 for p in "" 1 2 4 8 9 16; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 ${p:+-DSTREAM_PROBE=$p} -o tools/stream_mm_check${p:+_p$p} tools/stream_mm_check.hip || exit 1
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/valu_mfma_probe tools/valu_mfma_probe.hip || exit 1
 # the loader on buffer loads (STREAM_BUFFER_LOADS, computes correct results: run WITH the check)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSTREAM_BUFFER_LOADS=1 -o tools/stream_mm_check_buf tools/stream_mm_check.hip || exit 1
 # ... and with the loaders sleeping 6 x 64 clocks behind every chunk barrier (STREAM_LOADER_SLEEP): LDS queue goes to the operand reads first
