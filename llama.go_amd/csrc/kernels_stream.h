@@ -78,6 +78,9 @@ typedef float f4m __attribute__((ext_vector_type(4)));
 #ifndef STREAM_BUFFER_LOADS
 #define STREAM_BUFFER_LOADS 0
 #endif
+#ifndef STREAM_MFMA_PACE
+#define STREAM_MFMA_PACE -1     // >= 0: s_nop <value> behind every MFMA of k_stream_mm2's compute waves (experiment, see there); -1 = none (shipped)
+#endif
 #ifndef STREAM_LOADER_SLEEP
 #define STREAM_LOADER_SLEEP 0   // s_sleep argument (units of 64 clocks) of the loader waves behind every chunk barrier; 0 = none (shipped)
 #endif
@@ -655,7 +658,18 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                         for (int t = 0; t < MAXT; ++t)
 #pragma unroll
                             for (int c = 0; c < NCT; ++c)
+                            {
                                 acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
+#if STREAM_MFMA_PACE >= 0
+                                // experiment (next round): the MFMA wave idles in s_nop instead of presenting its next MFMA to the issue
+                                // arbiter while the pipe is still busy - next to a wave that always has an MFMA ready the loader wave of the
+                                // SIMD gets one instruction issued per 100-190 clocks, next to a paced one it issues at full speed
+                                // (tools/valu_mfma_probe, profiles/r02d_valu_mfma_probe.txt; s_nop 15 was too long: tune 8..11)
+                                __builtin_amdgcn_sched_barrier(0);
+                                asm volatile("s_nop %0" : : "n"(STREAM_MFMA_PACE));
+                                __builtin_amdgcn_sched_barrier(0);
+#endif
+                            }
             }
         };
 #ifdef STREAM_TRACE

@@ -8,7 +8,7 @@
 //   kinds: 0 v_add_u32 (dependent chain)   1 v_lshl_add_u64 (independent)   2 global_load_dwordx4, VGPR address, L1-resident
 //          3 ds_write_b128                 4 s_add_u32 chain                 5 buffer_load_dwordx4, SGPR offset, L1-resident
 //          6 v_lshl_add_u64 + global_load_dwordx4 pairs (the shipped loader's instruction mix)
-// usage: valu_mfma_probe [side_iters [mfma_iters]]        (not run yet: written at the end of round 2 without GPU time left)
+// usage: valu_mfma_probe [side_iters [mfma_iters [nop_lo [nop_hi]]]]   (nop range: s_nop arguments tried behind every MFMA)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +16,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-struct Args { const float* buf; unsigned long long* out; unsigned side_iters, mfma_iters, kind, mfma_on; };
+struct Args { const float* buf; unsigned long long* out; unsigned side_iters, mfma_iters, kind, mfma_on, pace; };
 
 template <int KIND>
 __device__ __forceinline__ void side_loop(const Args& a, unsigned long long* clocks) {
@@ -72,6 +72,17 @@ __device__ __forceinline__ void side_loop(const Args& a, unsigned long long* clo
     if (v0 == 0xdeadbeefu || p1 == 1 || p2 == 1 || p3 == 1 || d0.x == 1.2345f || d1.x == 1.2345f || d2.x == 1.2345f || d3.x == 1.2345f) a.out[1023] = v0;
 }
 
+template <int NOP>
+__device__ __forceinline__ void mfma_loop(const Args& a, f4 (&acc)[16], float x, float y) {
+    for (unsigned it = 0; it < a.mfma_iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[i], 0, 0, 0);
+            if constexpr (NOP >= 0) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" : : "n"(NOP)); __builtin_amdgcn_sched_barrier(0); }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void k_probe(const Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned long long clocks = 0;
@@ -91,9 +102,16 @@ __global__ __launch_bounds__(512) void k_probe(const Args a) {
         for (int i = 0; i < 16; ++i) acc[i] = f4{0, 0, 0, 0};
         const float x = (float)threadIdx.x, y = 1.0f;
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        for (unsigned it = 0; it < a.mfma_iters; ++it) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[i], 0, 0, 0);
+        // pace = N > 0: s_nop N - 1 behind every MFMA - the MFMA wave idles instead of presenting its next MFMA (which cannot start before
+        // the pipe frees, 32 clocks) to the issue arbiter right away.  Measured (profiles/r02d_valu_mfma_probe.txt): s_nop 15 lets the
+        // other wave issue at full speed but costs 38 clocks (MFMA every 70.6): the length to find is the longest that keeps ~32.
+        switch (a.pace) {
+            case 0: mfma_loop<-1>(a, acc, x, y); break;
+#define PACE_CASE(N) case N + 1: mfma_loop<N>(a, acc, x, y); break;
+            PACE_CASE(0) PACE_CASE(1) PACE_CASE(2) PACE_CASE(3) PACE_CASE(4) PACE_CASE(5) PACE_CASE(6) PACE_CASE(7)
+            PACE_CASE(8) PACE_CASE(9) PACE_CASE(10) PACE_CASE(11) PACE_CASE(12) PACE_CASE(13) PACE_CASE(14) PACE_CASE(15)
+#undef PACE_CASE
+            default: mfma_loop<-1>(a, acc, x, y); break;
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -117,10 +135,16 @@ int main(int argc, char** argv) {
                             "v_lshl_add_u64 + global_load pairs"};
     const double per_iter[7] = {8, 12 /* 8 adds + the 4 v_mov_b64 the loop-carried values cost */, 8, 8, 8, 8, 16};
     printf("%-38s %22s %22s %18s\n", "side instruction (waves 0-3)", "clocks/instr, MFMA idle", "clocks/instr, MFMA busy", "clocks/MFMA (busy)");
+    // argv[3], argv[4]: range of s_nop arguments to try behind every MFMA (e.g. "6 12"); none by default
+    const int nop_lo = argc > 3 ? atoi(argv[3]) : -1, nop_hi = argc > 4 ? atoi(argv[4]) : nop_lo;
+    for (int nop = nop_lo < 0 ? -1 : nop_lo - 1; nop <= nop_hi; ++nop) {
+    const unsigned pace = (nop < nop_lo) ? 0u : (unsigned)nop + 1u;
+    if (pace) printf("-- MFMA waves paced: s_nop %d behind every MFMA\n", nop);
     for (unsigned kind = 0; kind < 7; ++kind) {
         double res[2] = {0, 0}, mf = 0;
         for (unsigned on = 0; on < 2; ++on) {
-            Args a = {buf, out, side_iters, mfma_iters, kind, on};
+            if (pace && !on) continue;
+            Args a = {buf, out, side_iters, mfma_iters, kind, on, pace};
             hipLaunchKernelGGL(k_probe, dim3(p.multiProcessorCount), dim3(512), lds, 0, a);
             CK(hipDeviceSynchronize());
             unsigned long long h[8]; CK(hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost));
@@ -128,6 +152,7 @@ int main(int argc, char** argv) {
             if (on) mf = (double)h[4] / ((double)mfma_iters * 16);
         }
         printf("%-38s %22.1f %22.1f %18.1f\n", names[kind], res[0], res[1], mf);
+    }
     }
     printf("(the MFMA waves must outlast the side loop for the 'busy' column to mean anything: raise mfma_iters if clocks/MFMA x mfma_iters x 16 < side clocks)\n");
     return 0;
