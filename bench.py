@@ -12,13 +12,16 @@ token ids evaluated as one prefill, then greedy decode at positions P = 8, 9, ..
 
 N = 1: one stream; steps run device-resident (argmax on the GPU feeds the next step, hipGraph replay).
 N > 1: layers are sharded in contiguous blocks over the ranks (SURVEY §8e); `--pods` independent streams (server.go:88-101;
-       default 4 N) keep the pipeline full: in one step every stream advances one token, so per-GPU work per step is constant
-       (scaling: weak) and value = pods*K tokens / time.  The residual stream [4096 f32] hops rank r -> r+1 and the sampled token
-       id returns from the last rank to rank 0 as RCCL send/recv issued by the library itself (lh_pipeline_run: schedule, stages
-       and p2p all below the C-ABI); torch.distributed (gloo) only carries the control plane here: the 128-byte RCCL id, the
-       barriers around the timed region and the max-over-ranks of the time.  `--pods 1` is the single greedy stream walking
-       through the stages (the latency curve of SURVEY §8e).  Started without torch.distributed.run, `--gpus N` spawns its own
-       N ranks.
+       default 4 N) keep the pipeline full: they form N groups of 4, a group takes a tick on one rank as ONE 4-row pass over
+       that rank's weights (lh_batch), and in one step every stream advances one token, so per-GPU work per step is constant
+       (scaling: weak) and value = pods*K tokens / time.  The residual rows [4 x 4096 f32] hop rank r -> r+1 and the token ids
+       return from the last rank to rank 0 as RCCL send/recv issued by the library itself (lh_pipeline_run: schedule, stages
+       and p2p all below the C-ABI); torch.distributed (gloo) only carries the control plane here: the 128-byte RCCL ids, the
+       barriers around the timed regions and the max-over-ranks of the times.  The SAME invocation then times the second curve
+       of SURVEY §8e - one greedy stream walking through the stages - as the side object "single_stream", and checks stream 0's
+       ids against the committed single-GPU ids (tests/golden/7b_seed1234_ids.json) -> "parity".  `--pods P` overrides the
+       stream count of the first phase.  Started without torch.distributed.run, `--gpus N` spawns its own N ranks.  A rank
+       that fails prints {"error": ...} and exits non-zero; control-plane waits time out after 120 s.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed live), "cpu_baseline" (oracle on the host cores,
 N = 1 only), "parity" (token ids / logits vs that oracle run).
@@ -72,15 +75,29 @@ def spawn_ranks(n):
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
     sk.close()
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out or "")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    # a rank that dies takes its siblings with it (exactly the PIDs started here): nobody waits for a peer that is gone
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.kill()
+                    rcs[i] = pr.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -120,8 +137,10 @@ def main():
     os.environ["LLAMAGO_DEVICE"] = str(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")  # control plane only; the data path is RCCL inside libllamahip.so
+        # control plane only; the data path is RCCL inside libllamahip.so.  120 s: a rank that crashed must not hold the others for gloo's default half hour
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("BENCH_CONTROL_TIMEOUT_S", "120"))))
 
     import __graft_entry__ as graft
     if rank == 0:
@@ -295,6 +314,30 @@ def main():
                             "scalar_go_order_vs_f64": relerr(ologits, flogits), "avx_order_vs_f64": relerr(np.stack(avx_logits), flogits),
                             "note": "float64-accumulated dot products, one rounding (checker mode useAVX=2); max over steps of max|delta|/max|truth|"},
             }
+        # ---- the reference's --pods on ONE GPU (server.go:88-101: MaxPods concurrent Do() over one Model): P streams whose decode
+        # steps share one pass over the weights (lh_batch through the pipeline scheduler, world = 1) - aggregate tokens/s, not `value`
+        if not args.no_prefill:
+            try:
+                from llama_go_amd.mlapi import Pipeline
+                pb = {}
+                for P in (4, 8, 16, 32):
+                    plb = Pipeline(model, ctx_size, P, 0, 1)
+                    plb.run([PROMPT] * P, max(W, 1))
+                    torch.cuda.synchronize()
+                    t_b = time.perf_counter()
+                    plb.run(None, K)
+                    torch.cuda.synchronize()
+                    d_b = time.perf_counter() - t_b
+                    ids_b = [plb.tokens(i) for i in range(P)]
+                    plb.free()
+                    solo = [first] + toks   # the single stream's ids from the same prompt (timed region above)
+                    n_c = min(len(solo), len(ids_b[0]))
+                    pb[str(P)] = {"tokens_per_s": round(P * K / d_b, 1), "ms_per_tick": round(d_b / K * 1e3, 4),
+                                  "ids_match_single_stream": all(t[:n_c] == solo[:n_c] for t in ids_b)}
+                result["pods_batched"] = dict(pb, note="P independent greedy streams on ONE GPU, one pass over the weights per tick for all of them "
+                                                       "(rows = pods: stream-GEMM kernels, per-row KV cache and position); aggregate tokens/s")
+            except Exception as e:  # a side measurement must never take the headline line down
+                result["pods_batched"] = {"error": str(e)}
         ctx.free()
         model.free()
         # ---- BASELINE config 3 beside the headline (not `value`): LLaMA-13B fp32, ONE Eval of 1024 tokens at past = 0 -> TFLOP/s on
@@ -372,39 +415,62 @@ def main():
                 result["int8_decode"] = {"error": str(e)}
         parallelism = "single GPU, device-resident decode loop (hipGraph replay)"
         pods = 1
+        groups = 1
         timed_pos0 = P0
     else:
         # ---------------- layer-sharded pipeline over `world` ranks ----------------
         R = world
-        # streams in flight: a phase of K steps costs K * pods / R + (R - 1) ticks, so with pods = R and K = 16 pipeline fill + drain
-        # alone cap the efficiency at K / (K + R - 1) (70 % for R = 8); 4 R streams amortise it to 4K / (4K + R - 1) (90 %).
-        # The reference's own knob for this is --pods (server.go:88-101).  pods = 1: one stream, sequential through the stages.
+        # streams in flight: R groups of 4 keep every rank busy every tick, each tick one 4-row pass over the rank's weights; a phase
+        # of K steps costs K + (R - 1) ticks per rank (pipeline fill + drain included in the timed region).  The reference's own knob
+        # for this is --pods (server.go:88-101).
         pods = args.pods or 4 * R
         from llama_go_amd.mlapi import Pipeline, comm_unique_id
         from llama_go_amd.pipeline import gloo_comm_hooks, layer_range
         l0, l1 = layer_range(rank, R, L)
-        model = prod.NewSyntheticModel(hp, SEED, l0, l1)
-        if args.int8:
-            model.QuantizeQ8()
+
+        def fail(stage, e):   # a failing rank says so and leaves: the launcher (or spawn_ranks) takes the others down
+            msg = {"error": f"rank {rank}: {stage}: {e}", "n_gpus": world}
+            print(json.dumps(msg), file=sys.stderr if rank else sys.stdout, flush=True)
+            os._exit(1)
+
+        try:
+            model = prod.NewSyntheticModel(hp, SEED, l0, l1)
+            if args.int8:
+                model.QuantizeQ8()
+        except Exception as e:
+            fail("model", e)
         F = model.ffSize
-        comm_id, hooks = None, None
-        if shared_gpu:
-            hooks = gloo_comm_hooks(dist)
-        else:
-            obj = [comm_unique_id(prod) if rank == 0 else None]   # ncclGetUniqueId on rank 0; any channel may carry the 128 bytes
+
+        def new_pipeline(n_streams):
+            comm_id, hooks = None, None
+            if shared_gpu:
+                hooks = gloo_comm_hooks(dist)
+            else:
+                obj = [comm_unique_id(prod) if rank == 0 else None]   # ncclGetUniqueId on rank 0; any channel may carry the 128 bytes
+                dist.broadcast_object_list(obj, src=0)
+                comm_id = obj[0]
+            return Pipeline(model, ctx_size, n_streams, rank, R, comm_id=comm_id, hooks=hooks)   # ncclCommInitRank + per-stream stages, one HIP stream
+
+        def timed_phase(n_streams):
+            pl = new_pipeline(n_streams)
+            pl.run([PROMPT] * n_streams, W)   # prefill + W warm-up decode steps per stream (lh_pipeline_run); the pipeline drains at the end
+            sync_all()
+            t0 = time.perf_counter()
+            pl.run(None, K)                   # K decode steps per stream, continuing each stream: includes pipeline fill + drain
+            sync_all()
+            tdt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            # ids rank 0 received for stream 0: [prefill argmax, then the id produced at positions P0, P0+1, ...]
+            obj = [[pl.tokens(i) for i in range(n_streams)] if rank == 0 else None]
             dist.broadcast_object_list(obj, src=0)
-            comm_id = obj[0]
-        pl = Pipeline(model, ctx_size, pods, rank, R, comm_id=comm_id, hooks=hooks)   # ncclCommInitRank + per-stream stages, one HIP stream
-        pl.run([PROMPT] * pods, W)   # prefill + W warm-up decode steps per stream (lh_pipeline_run); the pipeline drains at the end
-        sync_all()
-        t0 = time.perf_counter()
-        pl.run(None, K)              # K decode steps per stream, continuing each stream: includes pipeline fill + drain
-        sync_all()
-        dt = time.perf_counter() - t0
+            return pl, float(tdt.item()), obj[0]
+
+        try:
+            pl, dt, all_ids = timed_phase(pods)
+        except Exception as e:
+            fail(f"pipeline phase with {pods} streams", e)
         tokens_total = K * pods
-        tdt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
+        groups = pl.groups
         prof = pl.profile_decode(1, P0, repeats=2)
         b2b = {k["name"][:-4]: k for k in prof if k["name"].endswith("/b2b")}
         prof = [k for k in prof if not k["name"].endswith("/b2b")]
@@ -413,19 +479,39 @@ def main():
             dom = dict(b2b[dom["name"]], name=dom["name"])
         result["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": dom["bytes_per_launch"],
-                              "avg_us": round(dom["avg_us"], 2)}
-        # ids rank 0 received for stream 0: [prefill argmax, then the id produced at positions P0, P0+1, ...]
-        allt = pl.tokens(0) if rank == 0 else None
-        obj = [allt]
-        dist.broadcast_object_list(obj, src=0)
-        allt = obj[0]
+                              "avg_us": round(dom["avg_us"], 2),
+                              "note": "the rank's batch-1 weight-stream kernel, HIP-event timed (the timed ticks evaluate several rows per pass with the stream-GEMM kernels)"}
+        allt = all_ids[0]
         assert len(allt) == 1 + W + K, (len(allt), W, K)
+        pl.free()
+        # ---- second curve of SURVEY §8e in the same invocation: ONE greedy stream walking through the stages (latency, not throughput)
+        if pods != 1:
+            try:
+                pl1, dt1, ids1 = timed_phase(1)
+                pl1.free()
+                result["single_stream"] = {"tokens_per_s": round(K / dt1, 2), "ms_per_token": round(dt1 / K * 1e3, 4), "steps": K,
+                                           "ids_match_batched_stream0": ids1[0] == allt,
+                                           "note": "pods = 1: every token passes the stages one after the other (R weight-stream stages + R hops per token); not `value`"}
+            except Exception as e:
+                fail("single-stream phase", e)
+        # ---- parity: every stream saw the same prompt, so all of them must produce the ids of the single-GPU run (committed with the
+        # checker's verdict on them: tests/golden/7b_seed1234_ids.json, written by tools/make_golden_ids.py from a bench.py --gpus 1 run)
+        par = {"all_streams_equal": all(t == allt for t in all_ids), "ids_match_single_gpu": None}
+        gpath = os.path.join(ROOT, "tests", "golden", "7b_seed1234_ids.json")
+        if args.shape == "7B" and not args.layers and not args.int8 and os.path.exists(gpath):
+            gold = json.load(open(gpath))
+            n_cmp = min(len(allt), len(gold["ids"]))
+            par.update(ids_match_single_gpu=allt[:n_cmp] == gold["ids"][:n_cmp], ids_compared=n_cmp, golden="tests/golden/7b_seed1234_ids.json",
+                       golden_checked_against_oracle=gold.get("oracle_ids_match"))
+        else:
+            par["reason"] = "golden ids exist for the full fp32 7B model only"
+        result["parity"] = par
         produced = allt[1:]          # ids produced by the decode steps at positions P0.. (the first W of them by the warm-up)
         timed_pos0 = P0 + W
-        parallelism = (f"layer-shard pp{R} ({l1 - l0} layers on this rank), {pods} independent greedy stream{'s' if pods > 1 else ''} in flight"
-                       f"{' (single-stream latency curve)' if pods == 1 else ''}, RCCL send/recv of the residual stream issued below the C-ABI (lh_pipeline_run)"
+        parallelism = (f"layer-shard pp{R} ({l1 - l0} layers on this rank), {pods} independent greedy stream{'s' if pods > 1 else ''} in flight as {groups} "
+                       f"group{'s' if groups > 1 else ''} of {pods // groups} (one pass over the rank's weights per group and tick)"
+                       f"{' (single-stream latency curve)' if pods == 1 else ''}, RCCL send/recv of the residual rows issued below the C-ABI (lh_pipeline_run)"
                        f"{'; SHARED-GPU functional mode (host-staged p2p)' if shared_gpu else ''}")
-        pl.free()
         model.free()
 
     Tbar = timed_pos0 + (K + 1) / 2.0
@@ -434,17 +520,20 @@ def main():
         mat = 4 * (L * (4 * d * d + 3 * d * F) + V * d)
         wbytes = (wbytes - mat) + mat * 36 // 128
     tok_s = tokens_total / dt
+    rows_per_pass = max(1, pods // groups)   # streams that share one pass over a rank's weights (1: batch-1 decode)
     line = {
         "metric": "decode tokens/s LLaMA-7B fp32; % HBM-read roofline" if not args.int8 else "decode tokens/s LLaMA-7B block-int8 weights (config 4); % HBM-read roofline",
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if not args.int8 else "f32 activations/accumulation, int8 block-quantised weights", "data": "synthetic (random-init weights, counter-based generator seed 1234; fixed 8-token prompt)",
         "config": {"workload": f"LLaMA-{args.shape} fp32 greedy decode, context {ctx_size}, positions {timed_pos0}..{timed_pos0 + K - 1}, batch 1 per stream",
-                   "layers": L, "embd": d, "ff": F, "vocab": V, "streams": pods, "parallelism": parallelism},
+                   "layers": L, "embd": d, "ff": F, "vocab": V, "streams": pods, "groups": groups, "parallelism": parallelism},
         "roofline_token": {
             "bytes_per_token": int(wbytes + kvbytes), "weights_bytes": int(wbytes),
             "roofline_tok_s_per_gpu_stream": round(HBM_PEAK_GBPS * 1e9 / (wbytes + kvbytes), 2),
-            "frac_of_hbm_roofline": round(tok_s * (wbytes + kvbytes) / (HBM_PEAK_GBPS * 1e9 * world), 4),
+            # a pass streams the weights once for all its rows and each row's own KV: bytes per pass / rows = bytes per token
+            "rows_per_weight_pass": rows_per_pass,
+            "frac_of_hbm_roofline": round(tok_s * (wbytes / rows_per_pass + kvbytes) / (HBM_PEAK_GBPS * 1e9 * world), 4),
         },
         "tokens_stream0": produced[: min(K, 16)],
     }

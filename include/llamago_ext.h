@@ -1,0 +1,82 @@
+/* include/llamago_ext.h — the llamago_* exports of the host libraries: entry points with NO counterpart in the reference
+ * (gotzmann/llama.go), needed by harnesses (tests/, bench.py), by the device-resident loops and by the multi-GPU / multi-pod
+ * paths.  include/llamago.h stays the mirror of the reference's own names; everything else a host library exports is declared
+ * HERE, and tests/test_abi.py diffs `nm -D` of both libraries against the two headers in both directions, so that the hand-written
+ * ctypes / cgo bindings cannot drift from the C++ definitions unnoticed (the product host includes this header: signatures are
+ * compiler-checked).
+ *
+ *   [both]     exported by llama.go_amd/lib/libllamago.so AND by the checker library oracle/liboracle.so
+ *   [product]  libllamago.so only (needs the MI355X backend)
+ */
+#ifndef LLAMAGO_EXT_H
+#define LLAMAGO_EXT_H
+#include "llamago.h"
+#include "llamahip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- [both] harness helpers ------------------------------------------------------------------------------------------- */
+/* Releases every tensor the calling thread's constructors made and no graph freed: stands where the reference forces
+ * runtime.GC() after each Eval (llama.go:423). */
+void llamago_CollectGarbage(void);
+/* The graph llama.Eval builds for a model of shape hp, as numbers (needs no GPU): per tensor 11 int32 = op, ne[4], nb[4], src0, src1
+ * (indices into the same list, leafs first then nodes in ml.GraphCompute's order, -1 = nil).  Returns the tensor count. */
+int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_t N, uint32_t pastCount, int32_t* out, uint32_t cap_tensors, uint32_t* n_leafs);
+/* llama_SampleTopPTopK that also returns the kept candidates in rank order after the topP rescale (the reference's logitsID / probs
+ * right before the random pick, llama.go:639-661). */
+int llamago_SampleDebug(ml_context* ctx, const float* logits, uint32_t logitsCount, const uint32_t* lastNTokens, uint32_t lastNTokensSize, uint32_t topK, float topP,
+                        float temp, float repeatPenalty, uint64_t seed, uint64_t draw, uint32_t* token, uint32_t* cand_ids, float* cand_probs, uint32_t* n_keep);
+/* Block-int8 weight matrices (ML_TYPE_Q8_0, format ours: SURVEY §8a row 22).  Product: quantises every matrix in HBM and releases the
+ * f32 copies; checker: replaces its weights by the dequantised values.  Before any context of the model exists. */
+int llamago_QuantizeModelQ8(llama_model* m);
+
+/* ---- [product] device plumbing ---------------------------------------------------------------------------------------- */
+int llamago_DeviceCount(void);                       /* lh_device_count */
+void llamago_SetStream(void* hip_stream);            /* HIP stream for contexts created from now on (NULL: a private one each) */
+int llamago_Sync(llama_context* c);                  /* waits for the context's stream */
+int llamago_LastGraphFused(ml_context* ctx);         /* 1 if the last ml_GraphCompute ran as the fused LLaMA plan */
+int llamago_GraphComputeNoFusion(ml_context* ctx, ml_graph* g);   /* ml_GraphCompute node by node with the generic kernels (op-level parity) */
+
+/* ---- [product] device-resident loops on a llama.Context --------------------------------------------------------------- */
+/* n_steps greedy decode steps without host round trips (lh_llama_decode_greedy). */
+int llamago_DecodeGreedyResident(llama_context* c, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last);
+/* HIP-event timing of every kernel class of one decode step (lh_llama_profile_decode); returns the class count. */
+int llamago_ProfileDecode(llama_context* c, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap);
+/* One pipeline stage of Eval on the context's own KV cache (lh_llama_stage). */
+int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_dev, const void* x_in_dev, void* x_out_dev, uint32_t n, uint32_t past,
+                  void* logits_dev, void* argmax_dev);
+
+/* ---- [product] the pods of one GPU in ONE weight pass (lh_batch; server.go:88-101, 151) ------------------------------- */
+typedef struct llama_batch llama_batch;
+/* `pods` llama.Contexts (one KV cache each, llama.go:91-103) over one whole Model on one stream, bound into an lh_batch. */
+llama_batch* llamago_NewBatch(llama_model* m, uint32_t ctxSize, uint32_t pods);
+void llamago_FreeBatch(llama_batch* b);
+int llamago_BatchBatched(llama_batch* b);            /* lh_batch_batched */
+/* Every pod: its prompt as one Eval, then n_predict - 1 greedy steps of ALL pods per weight pass.  out[i * n_predict + s] = s-th id
+ * of pod i (= llama_GreedyDecode of that prompt alone); logits (optional): [pods][vocab] of the last tick. */
+int llamago_BatchGreedyDecode(llama_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t n_predict, uint32_t* out, float* logits);
+
+/* ---- [product] pods as pipeline streams over a layer-sharded model ---------------------------- */
+typedef struct llama_pipeline llama_pipeline;
+int llamago_CommUniqueId(uint8_t* id /* [LH_COMM_ID_BYTES] */);   /* lh_comm_unique_id on this process's device: rank 0 calls, any channel distributes */
+/* This rank's stages of `pods` independent streams over the model's [layer0, layer1) (llama_NewSyntheticModel / loader with a layer
+ * range), one KV cache per stream, one HIP stream per rank.  id = the 128 bytes from rank 0 (RCCL), or NULL with hooks (host-staged
+ * transport), or both NULL for an unsharded model (world 1).  maxRows (Grouped): streams one tick evaluates together in one pass over
+ * the rank's weights; 0 = as many as fit, 1 = every stream on its own. */
+llama_pipeline* llamago_NewPipeline(llama_model* m, uint32_t ctxSize, uint32_t pods, int rank, int world, const uint8_t* id, const lh_comm_hooks* hooks);
+llama_pipeline* llamago_NewPipelineGrouped(llama_model* m, uint32_t ctxSize, uint32_t pods, int rank, int world, const uint8_t* id, const lh_comm_hooks* hooks,
+                                           uint32_t maxRows);
+void llamago_FreePipeline(llama_pipeline* p);
+uint32_t llamago_PipelineGroups(llama_pipeline* p);
+int llamago_PipelineRun(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps);             /* lh_pipeline_run */
+int llamago_PipelineRunSample(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, uint32_t topK, float topP, float temp,
+                              float repeatPenalty, uint64_t seed, uint32_t ringSize);                                            /* lh_pipeline_run_sample */
+int llamago_PipelineTokens(llama_pipeline* p, uint32_t pod, uint32_t* out, uint32_t cap);                                        /* lh_pipeline_tokens */
+int llamago_PipelineProfileDecode(llama_pipeline* p, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap);
+int llamago_PipelineSync(llama_pipeline* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

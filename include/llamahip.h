@@ -160,6 +160,48 @@ int lh_sample_top_p_top_k(lh_ctx* ctx, const float* logits, uint32_t n_logits, c
 int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t ring_size,
                            const lh_sample_params* sp, uint32_t* out_tokens);
 
+/* ---- pods in ONE weight pass (batched decode) ---------------------------------------------------------------------
+ * The reference's only parallelism is request-level: Engine() starts up to MaxPods concurrent Do() goroutines
+ * (pkg/server/server.go:84-106), each with its own llama.Context over the shared Model (server.go:151).  On the CPU they share
+ * the cores.  On the GPU every N = 1 Eval streams all weights, so P pods decoding on their own read P x 26.4 GB per round of
+ * tokens for the bandwidth of one.  An lh_batch binds the stages of P streams (lh_llama_create with the SAME weights and layer
+ * range and ONE KV cache each, all on one lh_ctx) and evaluates a decode step of all of them as one P-row pass: weights read
+ * once, RoPE / cache append / attention per row at the row's own position of its own cache.  A row's result does not depend on
+ * its index or on the other rows.  Shapes the P-row kernels are not built for run row by row (same results, P passes):
+ * lh_batch_batched() tells.  1 <= P <= 64.  The pods must outlive the batch; while it exists use them only through it or for
+ * whole-prompt Evals (lh_llama_stage / lh_llama_eval with n > 1 rows).
+ * Token ids, positions and residual rows of a tick live at fixed device addresses and the tick is ONE captured hipGraph that
+ * also moves the positions on: a tick costs the host one graph launch whatever the stage's length. */
+typedef struct lh_batch lh_batch;
+int lh_batch_create(lh_ctx* ctx, lh_llama* const* pods, uint32_t n_pods, lh_batch** out);
+void lh_batch_destroy(lh_batch* b);
+uint32_t lh_batch_rows(const lh_batch* b);
+int lh_batch_batched(const lh_batch* b);          /* 1: the rows share one weight pass; 0: row by row */
+/* Device arrays a transport delivers into / reads from: [rows] ids evaluated by the next tick (first stage) and [rows] ids the
+ * last tick produced (last stage).  On a whole-model batch a tick feeds the second into the first itself. */
+uint32_t* lh_batch_tokens_dev(lh_batch* b);
+uint32_t* lh_batch_ids_dev(lh_batch* b);
+int lh_batch_read_ids(lh_batch* b, uint32_t* ids_host);   /* waits for the stream, then copies the [rows] produced ids to the host */
+/* Position (= llama.Eval's pastCount) of every row's next token and, tokens != NULL, the ids themselves (first stage), from the
+ * host; the rows' output lists restart. */
+int lh_batch_set(lh_batch* b, const uint32_t* tokens_or_null, const uint32_t* past);
+/* server.Do's prompt Eval (server.go:185-192) for every row, each on its own cache at position 0: prompts[i][0..n_prompt[i])
+ * (host; first stage only, n_prompt on every stage).  Later stages read / earlier stages write the rows of all prompts one after
+ * the other in x_in_dev / x_out_dev (sum(n_prompt) x embd floats).  The last stage leaves each row's next id (argmax of its last
+ * prompt row, or the first sampler draw) in lh_batch_ids_dev; every stage then stands at position n_prompt[i] per row. */
+int lh_batch_prompt(lh_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, const float* x_in_dev, float* x_out_dev);
+/* One decode tick for every row (llama.Eval with N = 1 per stream, llama.go:211-426): x_in_dev / x_out_dev = [rows][embd]
+ * residual rows from the previous / for the next stage (NULL on the first / last stage).  Optional device copies of the
+ * [rows][vocab] logits and the [rows] produced ids.  Asynchronous on the context's stream; positions advance by one. */
+int lh_batch_stage(lh_batch* b, const float* x_in_dev, float* x_out_dev, float* logits_dev, uint32_t* ids_dev);
+/* From now on the last stage draws every row's id with SampleTopPTopK (llama.go:455-707; same device sampler and counter-based
+ * uniforms as lh_llama_decode_sample, every row seeded like a solo run) instead of the argmax.  ring_init[i][0..n_init[i]) = ids
+ * already appended to row i's lastNTokens ring of ring_size slots (the prompt, server.go:193-197).  sp = NULL: back to greedy. */
+int lh_batch_set_sampler(lh_batch* b, const lh_sample_params* sp, uint32_t ring_size, const uint32_t* const* ring_init, const uint32_t* n_init);
+/* Whole-model pods: n_steps device-resident ticks from (first_tokens[i], past[i]); out_tokens[i * n_steps + s] = id row i
+ * produced at step s; logits_last_host (optional) = [rows][vocab] logits of the final tick. */
+int lh_batch_decode(lh_batch* b, const uint32_t* first_tokens, const uint32_t* past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host);
+
 /* ---- multi-GPU: layer shard over RCCL point-to-point ------------------------------------------------
  * The reference's only parallel dimension is request-level "pods" (pkg/server/server.go:84-106: Engine() starts up to
  * MaxPods concurrent Do() goroutines; server.go:151: each with its own llama.Context over the shared Model).  Layers
@@ -181,6 +223,9 @@ typedef struct lh_comm_hooks {
 } lh_comm_hooks;
 int lh_comm_init_hooks(lh_ctx* ctx, int rank, int world, const lh_comm_hooks* hooks, lh_comm** out);
 void lh_comm_destroy(lh_comm* comm);
+/* Tear the communicator down without waiting for the peers (ncclCommAbort): what they have pending against this rank fails instead
+ * of blocking.  Used by lh_pipeline_run when a rank fails mid-run; afterwards only lh_comm_destroy is valid. */
+int lh_comm_abort(lh_comm* comm);
 int lh_comm_rank(const lh_comm* comm);
 int lh_comm_world(const lh_comm* comm);
 /* One grouped send + receive of device buffers, asynchronous on the context's stream (ncclGroupStart / ncclSend /
@@ -206,14 +251,25 @@ int lh_pipeline_run_hooks(uint32_t rank, uint32_t world, uint32_t pods, uint32_t
 
 typedef struct lh_pipeline lh_pipeline;
 /* pods[i]: this rank's stage of stream i (lh_llama_create with the rank's [layer0, layer1) and the stream's own KV
- * cache), all on `ctx` (one stream orders compute and p2p).  comm may be NULL when the model is not sharded. */
+ * cache), all on `ctx` (one stream orders compute and p2p).  comm may be NULL when the model is not sharded.
+ * The streams are dealt into G = min(pods, world) groups (more when a group would exceed the rows one weight pass takes: 64 fp32,
+ * 48 block-int8); a group is an lh_batch - its streams advance together in ONE pass over the rank's weights - and the schedule
+ * above runs over groups instead of single streams.  pods = 4 world: every tick evaluates 4 rows.  max_rows_per_tick (grouped
+ * variant; 0 = as many as fit) bounds the rows of a group: 1 puts every stream into its own tick (one weight pass per stream). */
 int lh_pipeline_create(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, lh_pipeline** out);
+int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, uint32_t max_rows_per_tick, lh_pipeline** out);
 void lh_pipeline_destroy(lh_pipeline* pl);
+uint32_t lh_pipeline_groups(const lh_pipeline* pl);
 /* server.Do for every stream at once, greedy: if n_prompt != NULL, unit 0 evaluates prompts[i][0..n_prompt[i]) at
  * position 0 (prompts is read on rank 0 only; n_prompt on every rank); then `steps` decode units follow, each feeding
  * the argmax of the previous unit.  State (position, next token) persists across calls, so run(prompts, n, W) followed
  * by run(NULL, NULL, K) continues the same streams.  Returns after the rank's stream has drained. */
 int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps);
+/* The same loop as the reference runs it (pkg/server/server.go:201-204: SampleTopPTopK after every Eval): the last rank draws every
+ * stream's id with the device sampler (lh_sample_params, ring of ring_size slots seeded with the prompt ids, every stream like a solo
+ * lh_llama_decode_sample with the same seed) instead of the argmax.  prompts must be given on rank 0 AND on the last rank (the
+ * repeat penalty needs the ring there).  run_sample(NULL, NULL, K, sp, ring) continues sampled streams. */
+int lh_pipeline_run_sample(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, const lh_sample_params* sp, uint32_t ring_size);
 /* Token ids this rank knows for a stream since creation (rank 0: received from the last rank; last rank: produced). */
 int lh_pipeline_tokens(lh_pipeline* pl, uint32_t pod, uint32_t* out, uint32_t cap);
 

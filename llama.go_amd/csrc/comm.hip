@@ -19,6 +19,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -43,6 +44,7 @@ static Rccl* rccl(lh_ctx* ctx) {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");   // optional
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
@@ -105,28 +107,33 @@ struct lh_comm {
     Rccl* r = nullptr;
     lh_comm_hooks hooks = {};
     bool use_hooks = false;
+    bool aborted = false;
     // host staging of the hooks transport (pinned)
     char *send_host = nullptr, *recv_host = nullptr;
     uint64_t send_cap = 0, recv_cap = 0;
 };
 
-struct PodState {
-    lh_llama* m = nullptr;
-    float *x_in = nullptr, *x_out = nullptr;  // residual stream received / produced, rows_cap x embd
+// One scheduling unit of the pipeline: the pods of a rank that take a tick together (lh_batch: one weight pass for all of them).
+struct Group {
+    std::vector<uint32_t> pods;     // stream indices, ascending
+    lh_batch* batch = nullptr;
+    float *x_in = nullptr, *x_out = nullptr;   // residual rows received / produced, rows_cap x embd
     uint32_t rows_cap = 0;
-    uint32_t* recv_ids = nullptr;  // rank 0: ids received from the last rank, in order
-    uint32_t* prod_ids = nullptr;  // last rank: ids produced, in order
-    uint32_t n_recv = 0, n_prod = 0, ids_cap = 0;
-    uint32_t past = 0;             // position of the next unit
-    uint32_t pending_rows = 0;     // rows of the unit in flight (bookkeeping of the current run)
+    uint32_t* hist = nullptr;       // first / last rank: ids per unit [units][B] (rank 0: received from the last rank; last rank: produced)
+    uint32_t n_hist = 0, hist_cap = 0;   // units recorded / capacity in units
 };
 
 struct lh_pipeline {
     lh_ctx* ctx = nullptr;
     lh_comm* comm = nullptr;
     int rank = 0, world = 1;
-    std::vector<PodState> pods;
-    uint32_t d = 0, ctx_size = 0;
+    std::vector<lh_llama*> pods;
+    std::vector<uint32_t> past;     // per stream: position of the next unit (host mirror; every rank keeps the same values)
+    std::vector<uint32_t> group_of, row_of;
+    std::vector<Group> groups;
+    uint32_t d = 0, ctx_size = 0, vocab = 0;
+    bool started = false;           // a prompt has been run: there is a token to continue from (the same on every rank)
+    bool sampling = false;
 };
 
 extern "C" {
@@ -179,6 +186,15 @@ void lh_comm_destroy(lh_comm* cm) {
     delete cm;
 }
 
+// Tear the communicator down without waiting for peers (ncclCommAbort): operations the peers have pending against this rank fail
+// instead of blocking.  The handle stays valid for lh_comm_destroy only.
+int lh_comm_abort(lh_comm* cm) {
+    if (!cm) return LH_EINVAL;
+    if (cm->nccl && cm->r->CommAbort) { cm->r->CommAbort(cm->nccl); cm->nccl = nullptr; }
+    cm->aborted = true;
+    return LH_OK;
+}
+
 int lh_comm_rank(const lh_comm* cm) { return cm ? cm->rank : 0; }
 int lh_comm_world(const lh_comm* cm) { return cm ? cm->world : 1; }
 
@@ -190,6 +206,7 @@ int lh_comm_exchange(lh_comm* cm, const void* send_dev, uint64_t send_bytes, int
     if ((snd && (send_peer < 0 || send_peer >= cm->world)) || (rcv && (recv_peer < 0 || recv_peer >= cm->world)))
         LH_FAIL(ctx, LH_EINVAL, "lh_comm_exchange: peer outside the world of %d", cm->world);
     LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (cm->aborted) LH_FAIL(ctx, LH_EHIP, "lh_comm_exchange: the communicator was aborted");
     if (!cm->use_hooks) {
         Rccl* r = cm->r;
         LH_NCCL(ctx, r, r->GroupStart());
@@ -245,139 +262,235 @@ int lh_pipeline_run_hooks(uint32_t rank, uint32_t world, uint32_t pods, uint32_t
 }
 
 // ---- the product pipeline -------------------------------------------------------------------------------------------------
-int lh_pipeline_create(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, lh_pipeline** out) {
+// Grouping: G = min(pods, world) groups keep every rank busy (a group is in flight on one rank at a time); more when a group would
+// exceed max_rows rows.  Stream p belongs to group p * G / pods (contiguous blocks).
+static uint32_t group_count(uint32_t pods, uint32_t world, uint32_t max_rows) {
+    uint32_t G = std::min(pods, world);
+    while ((pods + G - 1) / G > max_rows) ++G;
+    return G;
+}
+
+int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, uint32_t max_rows, lh_pipeline** out) {
     if (!ctx || !pods || !n_pods || !out) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: NULL argument");
     *out = nullptr;
     if (comm && comm->ctx != ctx) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: the communicator belongs to another context (one stream must order compute and p2p)");
     const int rank = comm ? comm->rank : 0, world = comm ? comm->world : 1;
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    auto pl = std::make_unique<lh_pipeline>();
+    lh_pipeline* pl = new lh_pipeline();
     pl->ctx = ctx; pl->comm = comm; pl->rank = rank; pl->world = world;
+    int wtype = 0;
     for (uint32_t i = 0; i < n_pods; ++i) {
         lh_llama* m = pods[i];
-        if (!m || m->ctx != ctx) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: pod %u lives on another context", i);
+        if (!m || m->ctx != ctx) { delete pl; LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: pod %u lives on another context", i); }
         const ModelDesc& md = m->plan->md;
-        if (md.first_stage() != (rank == 0) || md.last_stage() != (rank == world - 1))
+        if (md.first_stage() != (rank == 0) || md.last_stage() != (rank == world - 1)) {
+            delete pl;
             LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: pod %u holds layers [%u,%u) of %u, which is not rank %d of %d in a contiguous layer shard", i, md.layer0, md.layer1, md.L, rank, world);
-        if (i == 0) { pl->d = md.d; pl->ctx_size = md.ctx; }
-        else if (md.d != pl->d || md.ctx != pl->ctx_size) LH_FAIL(ctx, LH_ESHAPE, "lh_pipeline_create: pods differ in shape");
-        PodState ps;
-        ps.m = m;
-        pl->pods.push_back(ps);
+        }
+        if (i == 0) { pl->d = md.d; pl->ctx_size = md.ctx; pl->vocab = md.V; wtype = md.wtype; }
+        else if (md.d != pl->d || md.ctx != pl->ctx_size) { delete pl; LH_FAIL(ctx, LH_ESHAPE, "lh_pipeline_create: pods differ in shape"); }
+        pl->pods.push_back(m);
     }
-    for (PodState& ps : pl->pods) {
-        ps.ids_cap = pl->ctx_size + 1;
-        if (rank == 0) { LH_HIP(ctx, hipMalloc((void**)&ps.recv_ids, (size_t)ps.ids_cap * 4)); LH_HIP(ctx, hipMemsetAsync(ps.recv_ids, 0, (size_t)ps.ids_cap * 4, ctx->stream)); }
-        if (rank == world - 1) { LH_HIP(ctx, hipMalloc((void**)&ps.prod_ids, (size_t)ps.ids_cap * 4)); LH_HIP(ctx, hipMemsetAsync(ps.prod_ids, 0, (size_t)ps.ids_cap * 4, ctx->stream)); }
+    pl->past.assign(n_pods, 0);
+    // rows per tick: as many as the P-row kernels take (64 fp32 / 48 block-int8) unless the caller asks for fewer; 1 = every stream on its own
+    const uint32_t cap = wtype == 7 ? 48u : 64u;
+    const uint32_t mr = max_rows ? std::min(max_rows, cap) : cap;
+    const uint32_t G = group_count(n_pods, (uint32_t)world, mr);
+    pl->groups.resize(G);
+    pl->group_of.resize(n_pods); pl->row_of.resize(n_pods);
+    for (uint32_t p = 0; p < n_pods; ++p) {
+        const uint32_t g = (uint32_t)(((uint64_t)p * G) / n_pods);
+        pl->group_of[p] = g;
+        pl->row_of[p] = (uint32_t)pl->groups[g].pods.size();
+        pl->groups[g].pods.push_back(p);
     }
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *out = pl.release();
+    for (Group& gr : pl->groups) {
+        std::vector<lh_llama*> members;
+        for (uint32_t p : gr.pods) members.push_back(pl->pods[p]);
+        int rc = lh_batch_create(ctx, members.data(), (uint32_t)members.size(), &gr.batch);
+        if (rc) { lh_pipeline_destroy(pl); return rc; }
+        if (rank == 0 || rank == world - 1) {
+            gr.hist_cap = pl->ctx_size + 1;
+            const size_t bytes = (size_t)gr.hist_cap * gr.pods.size() * 4;
+            if (hipMalloc((void**)&gr.hist, bytes) != hipSuccess || hipMemsetAsync(gr.hist, 0, bytes, ctx->stream) != hipSuccess) {
+                (void)hipGetLastError();
+                lh_pipeline_destroy(pl);
+                LH_FAIL(ctx, LH_ENOMEM, "lh_pipeline_create: device allocation failed");
+            }
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { lh_pipeline_destroy(pl); LH_FAIL(ctx, LH_EHIP, "lh_pipeline_create: stream synchronisation failed"); }
+    *out = pl;
     return LH_OK;
+}
+
+int lh_pipeline_create(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, lh_pipeline** out) {
+    return lh_pipeline_create_grouped(ctx, comm, pods, n_pods, 0, out);
 }
 
 void lh_pipeline_destroy(lh_pipeline* pl) {
     if (!pl) return;
     hipSetDevice(pl->ctx->device);
     hipStreamSynchronize(pl->ctx->stream);
-    for (PodState& ps : pl->pods) {
-        if (ps.x_in) hipFree(ps.x_in);
-        if (ps.x_out) hipFree(ps.x_out);
-        if (ps.recv_ids) hipFree(ps.recv_ids);
-        if (ps.prod_ids) hipFree(ps.prod_ids);
+    for (Group& gr : pl->groups) {
+        if (gr.batch) lh_batch_destroy(gr.batch);
+        if (gr.x_in) hipFree(gr.x_in);
+        if (gr.x_out) hipFree(gr.x_out);
+        if (gr.hist) hipFree(gr.hist);
     }
     delete pl;
 }
 
-static int pod_ensure_rows(lh_pipeline* pl, PodState& ps, uint32_t rows) {
-    if (rows <= ps.rows_cap) return 0;
+uint32_t lh_pipeline_groups(const lh_pipeline* pl) { return pl ? (uint32_t)pl->groups.size() : 0; }
+
+static int group_ensure_rows(lh_pipeline* pl, Group& gr, uint32_t rows) {
+    if (rows <= gr.rows_cap) return 0;
     lh_ctx* ctx = pl->ctx;
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ps.x_in) LH_HIP(ctx, hipFree(ps.x_in));
-    if (ps.x_out) LH_HIP(ctx, hipFree(ps.x_out));
-    ps.x_in = ps.x_out = nullptr; ps.rows_cap = 0;
-    if (pl->rank != 0) LH_HIP(ctx, hipMalloc((void**)&ps.x_in, (size_t)rows * pl->d * 4));
-    if (pl->rank != pl->world - 1) LH_HIP(ctx, hipMalloc((void**)&ps.x_out, (size_t)rows * pl->d * 4));
-    ps.rows_cap = rows;
+    if (gr.x_in) LH_HIP(ctx, hipFree(gr.x_in));
+    if (gr.x_out) LH_HIP(ctx, hipFree(gr.x_out));
+    gr.x_in = gr.x_out = nullptr; gr.rows_cap = 0;
+    if (pl->rank != 0) LH_HIP(ctx, hipMalloc((void**)&gr.x_in, (size_t)rows * pl->d * 4));
+    if (pl->rank != pl->world - 1) LH_HIP(ctx, hipMalloc((void**)&gr.x_out, (size_t)rows * pl->d * 4));
+    gr.rows_cap = rows;   // (the groups' captured ticks notice the new addresses: lh_batch re-captures)
     return 0;
 }
 
-int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps) {
+static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, const lh_sample_params* smp, uint32_t ring_size) {
     if (!pl) return LH_EINVAL;
     lh_ctx* ctx = pl->ctx;
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t P = (uint32_t)pl->pods.size(), R = (uint32_t)pl->world, r = (uint32_t)pl->rank;
+    const uint32_t P = (uint32_t)pl->pods.size(), G = (uint32_t)pl->groups.size(), R = (uint32_t)pl->world, r = (uint32_t)pl->rank;
     const bool first = r == 0, last = r == R - 1, prefill = n_prompt != nullptr;
     const uint32_t units = steps + (prefill ? 1 : 0);
     if (!units) return LH_OK;
-    if (prefill && first && !prompts) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: rank 0 needs the prompts");
-    int rc;
+    // ---- validation: rank-independent conditions only (every rank takes the same decision, so no rank is left waiting in a
+    // receive for a peer that returned), all of it before any state changes.  prompts themselves exist on rank 0 only: their ids
+    // are checked there by lh_batch_prompt before rank 0 launches anything of the run.
+    if (!prefill && !pl->started) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: no token to continue from (run a prompt first)");
+    if (!prefill && (smp != nullptr) != pl->sampling)
+        LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: streams whose prompt ran %s the sampler continue with %s", pl->sampling ? "with" : "without", pl->sampling ? "lh_pipeline_run_sample" : "lh_pipeline_run");
     for (uint32_t p = 0; p < P; ++p) {
-        PodState& ps = pl->pods[p];
         const uint32_t np = prefill ? n_prompt[p] : 0;
-        if (prefill) {
-            if (!np) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u has an empty prompt", p);
-            if (first && !prompts[p]) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u has no prompt", p);
-            ps.past = 0; ps.n_recv = 0; ps.n_prod = 0;
-        } else if (first && ps.n_recv == 0) {
-            LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u has no token to continue from (run a prompt first)", p);
-        }
-        if ((uint64_t)ps.past + np + steps > pl->ctx_size) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u would leave the context window of %u", p, pl->ctx_size);
-        if ((rc = pod_ensure_rows(pl, ps, std::max(np, 1u)))) return rc;
+        if (prefill && !np) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u has an empty prompt", p);
+        if ((uint64_t)(prefill ? 0 : pl->past[p]) + np + steps > pl->ctx_size) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u would leave the context window of %u", p, pl->ctx_size);
     }
-    auto rows_of = [&](uint32_t p, uint32_t u) -> uint32_t { return (prefill && u == 0) ? n_prompt[p] : 1u; };
-    auto stage = [&](uint32_t p, uint32_t u) -> int {
-        PodState& ps = pl->pods[p];
-        const uint32_t n = rows_of(p, u);
-        const uint32_t* tok_host = nullptr;
-        const uint32_t* tok_dev = nullptr;
-        if (first) {
-            if (n > 1 || (prefill && u == 0)) tok_host = prompts[p];
-            else tok_dev = ps.recv_ids + (ps.n_recv - 1);  // the id the last rank produced for the previous unit
+    // what only ONE rank can see (the prompts live on rank 0, and on the last rank of a sampled run): that rank tears the communicator
+    // down before it returns, so the others' first receive fails instead of waiting for it
+    auto local_fail = [&](const char* what, uint32_t p, uint32_t v) -> int {
+        if (pl->comm && R > 1) lh_comm_abort(pl->comm);
+        LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u: %s (%u)", p, what, v);
+    };
+    if (prefill && (first || (smp && last))) {
+        if (!prompts) return local_fail("this rank needs the prompts", 0, r);
+        for (uint32_t p = 0; p < P; ++p) {
+            if (!prompts[p]) return local_fail("no prompt", p, 0);
+            for (uint32_t j = 0; j < n_prompt[p]; ++j)
+                if (prompts[p][j] >= pl->vocab) return local_fail("token id outside the vocabulary", p, prompts[p][j]);
         }
-        uint32_t* amax = last ? ps.prod_ids + ps.n_prod : nullptr;
-        int rc2 = lh_llama_stage(ps.m, tok_host, tok_dev, first ? nullptr : ps.x_in, last ? nullptr : ps.x_out, n, ps.past, nullptr, amax);
+    }
+    int rc;
+    for (Group& gr : pl->groups) {
+        uint32_t rows = (uint32_t)gr.pods.size();
+        if (prefill) { uint32_t t = 0; for (uint32_t p : gr.pods) t += n_prompt[p]; rows = std::max(rows, t); }
+        if ((rc = group_ensure_rows(pl, gr, rows))) return rc;
+        if (prefill) {
+            gr.n_hist = 0;
+            // sampler state of the group's rows: ring = the prompt ids (server.go:193-197); NULL = greedy
+            std::vector<const uint32_t*> init;
+            std::vector<uint32_t> ninit;
+            for (uint32_t p : gr.pods) { init.push_back(first && smp ? prompts[p] : nullptr); ninit.push_back(first && smp ? n_prompt[p] : 0); }
+            if (smp && last && !first) {
+                // the last rank samples: the repeat penalty runs over the lastNTokens ring, which starts as the prompt ids - a sharded sampled run
+                // needs the prompts on the last rank too (checked above)
+                init.clear(); ninit.clear();
+                for (uint32_t p : gr.pods) { init.push_back(prompts[p]); ninit.push_back(n_prompt[p]); }
+            }
+            if ((rc = lh_batch_set_sampler(gr.batch, smp, ring_size, smp ? init.data() : nullptr, smp ? ninit.data() : nullptr))) return rc;
+        }
+    }
+    if (prefill) { pl->sampling = smp != nullptr; std::fill(pl->past.begin(), pl->past.end(), 0u); }
+    auto rows_of = [&](uint32_t g, uint32_t u) -> uint32_t {
+        const Group& gr = pl->groups[g];
+        if (!(prefill && u == 0)) return (uint32_t)gr.pods.size();
+        uint32_t t = 0;
+        for (uint32_t p : gr.pods) t += n_prompt[p];
+        return t;
+    };
+    // ids of a finished unit: a copy into the group's history (what lh_pipeline_tokens reads)
+    auto record = [&](Group& gr, const uint32_t* ids_dev) -> int {
+        if (gr.n_hist >= gr.hist_cap) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: id history full");
+        LH_HIP(ctx, hipMemcpyAsync(gr.hist + (size_t)gr.n_hist * gr.pods.size(), ids_dev, gr.pods.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        gr.n_hist++;
+        return 0;
+    };
+    auto stage = [&](uint32_t g, uint32_t u) -> int {
+        Group& gr = pl->groups[g];
+        int rc2;
+        if (prefill && u == 0) {
+            std::vector<const uint32_t*> pr;
+            std::vector<uint32_t> np;
+            for (uint32_t p : gr.pods) { pr.push_back(first ? prompts[p] : nullptr); np.push_back(n_prompt[p]); pl->past[p] = n_prompt[p]; }
+            rc2 = lh_batch_prompt(gr.batch, first ? pr.data() : nullptr, np.data(), first ? nullptr : gr.x_in, last ? nullptr : gr.x_out);
+        } else {
+            rc2 = lh_batch_stage(gr.batch, first ? nullptr : gr.x_in, last ? nullptr : gr.x_out, nullptr, nullptr);
+            for (uint32_t p : gr.pods) pl->past[p] += 1;
+        }
         if (rc2) return rc2;
-        if (last) ps.n_prod++;
-        ps.past += n;
-        ps.pending_rows = n;
+        if (last) return record(gr, lh_batch_ids_dev(gr.batch));
         return 0;
     };
     auto exchange = [&](int32_t s, int32_t u, int32_t rs, int32_t ru) -> int {
+        if (R == 1 && !pl->comm) return 0;   // unsharded: a whole-model batch feeds the produced ids back by itself
         const void* sb = nullptr; uint64_t sbytes = 0;
         void* rb = nullptr; uint64_t rbytes = 0;
         if (s >= 0) {
-            PodState& ps = pl->pods[s];
-            if (last) { sb = ps.prod_ids + (ps.n_prod - 1); sbytes = 4; }
-            else { sb = ps.x_out; sbytes = (uint64_t)rows_of((uint32_t)s, (uint32_t)u) * pl->d * 4; }
+            Group& gr = pl->groups[s];
+            if (last) { sb = lh_batch_ids_dev(gr.batch); sbytes = gr.pods.size() * 4; }
+            else { sb = gr.x_out; sbytes = (uint64_t)rows_of((uint32_t)s, (uint32_t)u) * pl->d * 4; }
         }
         if (rs >= 0) {
-            PodState& ps = pl->pods[rs];
-            if (first) { rb = ps.recv_ids + ps.n_recv; rbytes = 4; ps.n_recv++; }
-            else { rb = ps.x_in; rbytes = (uint64_t)rows_of((uint32_t)rs, (uint32_t)ru) * pl->d * 4; }
+            Group& gr = pl->groups[rs];
+            if (first) { rb = lh_batch_tokens_dev(gr.batch); rbytes = gr.pods.size() * 4; }
+            else { rb = gr.x_in; rbytes = (uint64_t)rows_of((uint32_t)rs, (uint32_t)ru) * pl->d * 4; }
         }
-        if (R == 1 && !pl->comm) {  // unsharded: the produced id is the received id
-            if (sb && rb) LH_HIP(ctx, hipMemcpyAsync(rb, sb, 4, hipMemcpyDeviceToDevice, ctx->stream));
-            return 0;
-        }
-        return lh_comm_exchange(pl->comm, sb, sbytes, (int)((r + 1) % R), rb, rbytes, (int)((r + R - 1) % R));
+        int rc2 = lh_comm_exchange(pl->comm, sb, sbytes, (int)((r + 1) % R), rb, rbytes, (int)((r + R - 1) % R));
+        if (rc2) return rc2;
+        if (rs >= 0 && first && !last) return record(pl->groups[rs], lh_batch_tokens_dev(pl->groups[rs].batch));
+        return 0;
     };
-    if ((rc = run_ticks(r, R, P, units, stage, exchange))) return rc;
+    rc = run_ticks(r, R, G, units, stage, exchange);
+    if (rc) {
+        // a rank that fails mid-run must not leave its peers waiting in a receive: tear the communicator down (RCCL: abort; the peers'
+        // pending operations then fail instead of blocking).  The pipeline is unusable afterwards.
+        if (pl->comm) lh_comm_abort(pl->comm);
+        return rc;
+    }
+    if (prefill) pl->started = true;
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;
+}
+
+int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps) {
+    return pipeline_run(pl, prompts, n_prompt, steps, nullptr, 0);
+}
+
+int lh_pipeline_run_sample(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, const lh_sample_params* sp, uint32_t ring_size) {
+    if (!pl) return LH_EINVAL;
+    if (!sp) LH_FAIL(pl->ctx, LH_EINVAL, "lh_pipeline_run_sample: null sampler parameters");
+    return pipeline_run(pl, prompts, n_prompt, steps, sp, ring_size);
 }
 
 int lh_pipeline_tokens(lh_pipeline* pl, uint32_t pod, uint32_t* out, uint32_t cap) {
     if (!pl || pod >= pl->pods.size()) return LH_EINVAL;
     lh_ctx* ctx = pl->ctx;
-    PodState& ps = pl->pods[pod];
-    const uint32_t* src = pl->rank == 0 ? ps.recv_ids : ps.prod_ids;
-    const uint32_t n = pl->rank == 0 ? ps.n_recv : ps.n_prod;
-    if (!src) return 0;  // a middle rank sees no ids
-    const uint32_t m = std::min(n, cap);
+    Group& gr = pl->groups[pl->group_of[pod]];
+    if (!gr.hist) return 0;  // a middle rank sees no ids
+    const uint32_t n = gr.n_hist, m = std::min(n, cap), B = (uint32_t)gr.pods.size();
     if (m && out) {
         LH_HIP(ctx, hipSetDevice(ctx->device));
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        LH_HIP(ctx, hipMemcpy(out, src, (size_t)m * 4, hipMemcpyDeviceToHost));
+        LH_HIP(ctx, hipMemcpy2D(out, 4, gr.hist + pl->row_of[pod], (size_t)B * 4, 4, m, hipMemcpyDeviceToHost));
     }
     return (int)n;
 }

@@ -58,12 +58,6 @@ struct DeviceState {
     // small), so a pointer handed out by ensure_rope_table stays valid for the positions it was asked for.
     struct RopeTable { double2* dev = nullptr; uint32_t positions = 0; };
     std::unordered_map<uint32_t, RopeTable> rope;
-    // Contexts with a fused LLaMA plan alive on this device (a context that only registers weights does not count).  The resident decode kernel (plan.hip: k_decode_persist) occupies every CU and its workgroups
-    // wait for each other: two of them from two streams can interleave their workgroups and starve each other, so it is used only
-    // while ONE context exists.  The count changes and the resident launches are serialised by `resident_mu`; the context that makes it two
-    // drains the device before it goes on (plan.hip: plan_create).
-    std::mutex resident_mu;
-    int live_ctx = 0;
 };
 DeviceState* device_state(int device);
 Buffer* find_buffer(DeviceState* ds, lh_buf id);
@@ -90,10 +84,11 @@ struct lh_ctx {
     int last_fused = 0;
     // fused plans cached by structural signature
     std::vector<lh::Plan*> plans;
-    bool counted_for_resident = false;   // this context has created a plan: it is part of DeviceState::live_ctx
-    // split-K partial products of the prefill GEMM (short prompts); grows, never shrinks
+    // split-K partial products of the prefill GEMM (short prompts); grows, never shrinks.  splitk_gen counts the re-allocations: a
+    // captured graph that holds the address (lh_batch ticks) is re-captured when it changed
     float* splitk = nullptr;
     uint64_t splitk_floats = 0;
+    uint64_t splitk_gen = 0;
 };
 
 namespace lh {

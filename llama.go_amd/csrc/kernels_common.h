@@ -17,6 +17,16 @@ struct StepParams {
     uint32_t pad;
 };
 
+// One row of a BATCHED Eval (lh_batch: the pods of a rank evaluated in one weight pass, server.go:88-101 runs them as independent
+// llama.Contexts): the row's own KV cache (llama.go:173-178; base of the stage's first layer slot) and its position = pastCount.
+// The table lives in device memory so that one captured hipGraph serves every tick; k_batch_argmax / k_batch_advance move `pos`.
+struct BatchRow {
+    float* kc;       // this pod's K cache [layers of the stage][ctx][d]
+    float* vc;
+    uint32_t pos;    // position of the row's token (= keys already cached for its stream)
+    uint32_t pad;
+};
+
 // Weights are read exactly once per token and shared by no other CU: stream them with the
 // non-temporal policy (MI355X_MICROARCH "nt-weights": +10-20 % on this access pattern, see
 // profiles/r01_gemv_probe.txt).

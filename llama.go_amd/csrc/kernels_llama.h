@@ -39,18 +39,6 @@ struct GemvArgs {
     const StepParams* sp;   // past
 };
 
-template <int MAP>
-__device__ __forceinline__ const f4* row_ptr(const GemvArgs& a, uint32_t v, uint32_t K4) {
-    if (MAP == MAP_SINGLE) return (const f4*)a.w[0] + (size_t)v * K4;
-    if (MAP == MAP_BLOCK) {
-        const uint32_t m = v / a.rows_per_mat;
-        return (const f4*)a.w[m] + (size_t)(v - m * a.rows_per_mat) * K4;
-    }
-    return (const f4*)a.w[v & 1] + (size_t)(v >> 1) * K4;
-}
-
-// RMSNorm + weight multiply on the thread's own columns (ml.go:1753-1812 then ml.go:1877-1914):
-//   mean = (sum_f64 fl32(x*x)) / K ; scale = fl32(1/sqrt(mean + 1e-5)) ; t = fl32(x*scale) ; h = fl32(gamma*t)
 template <int KI, int TH>
 __device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)[KI], const f4 (&gr)[KI], uint32_t K, double* sred) {
     constexpr int NW = TH / 64;
@@ -146,87 +134,9 @@ __device__ __forceinline__ void gemv_prefetch_fin(const GemvArgs& a, uint32_t r0
     }
 }
 
-template <int KI, int U, int TH, int PRO, int EPI, int MAP>
-__global__ __launch_bounds__(TH) void k_gemv(const GemvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NW = TH / 64;
-    double* sred = (double*)smem_raw;                // [NW]
-    float* red = (float*)(smem_raw + NW * 8);        // [rows of this workgroup][NW] per-wave partial dot products
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t K4 = a.K >> 2;
-    const uint32_t nwg = gridDim.x;
-    // rows are dealt in pairs so RoPE / SiLU partners share a workgroup
-    const uint32_t npairs = a.M >> 1;
-    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
-    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
-
-    f4 xr[KI];
-    f4 gr[KI];
-    bool act[KI];
-#pragma unroll
-    for (int j = 0; j < KI; ++j) {
-        act[j] = (uint32_t)(tid + j * TH) < K4;
-        xr[j] = act[j] ? ((const f4*)a.x)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
-        if (PRO == PRO_RMSNORM) gr[j] = act[j] ? ((const f4*)a.gamma)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
-    }
-    // Epilogue operands of this workgroup's rows are fetched now (one finishing thread per row or row pair), so their
-    // latency hides under the weight stream.
-    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;  // row offset this thread finishes
-    float resid_pre;
-    double2 cs_pre;
-    uint32_t past_pre;
-    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
-    // first U rows are requested before the prologue so HBM latency overlaps the norm
-    // Every load is UNCONDITIONAL: out-of-range rows / inactive lanes read a cache-resident dummy address instead of
-    // branching.  Loads inside exec-masked branches make hipcc fall back to s_waitcnt vmcnt(0) right after the refills
-    // (it cannot count them), which serialises the stream with the arithmetic.
-    const f4* dummy = (const f4*)a.x;
-    f4 w[U][KI];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const bool rv = r0 + u < r1;
-        const f4* p = row_ptr<MAP>(a, rv ? r0 + u : r0, K4);
-#pragma unroll
-        for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((rv && act[j]) ? p + tid + j * TH : dummy);
-    }
-    if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, gr, a.K, sred);
-
-    // Main stream: no workgroup barrier inside.  At the latency/bandwidth knee (U x 16 KiB in flight per CU) every stall
-    // that delays the next load request costs throughput (tools/kernel_ablate: a per-batch barrier + epilogue = 3-4 %),
-    // so waves run free and park their per-row partial sums in LDS.
-    for (uint32_t r = r0; r < r1; r += U) {
-        float acc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t nr = r + U + u;
-            const bool nv = nr < r1;
-            const f4* p = row_ptr<MAP>(a, nv ? nr : r0, K4);
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < KI; ++j) {
-                const f4 c = w[u][j];
-                s = fmaf(c.x, xr[j].x, s);
-                s = fmaf(c.y, xr[j].y, s);
-                s = fmaf(c.z, xr[j].z, s);
-                s = fmaf(c.w, xr[j].w, s);
-                w[u][j] = ld_nt((nv && act[j]) ? p + tid + j * TH : dummy);
-            }
-            acc[u] = s;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = wave_sum(acc[u]);
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (r + u < r1) red[(r - r0 + u) * NW + wave] = acc[u];
-        }
-    }
-    __syncthreads();
-    gemv_finish<EPI, NW>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
-}
-
 // ---------------------------------------------------------------------------------------------------
-// k_gemv with SCALAR row addressing.  In k_gemv above every weight load takes a per-lane 64-bit pointer that is selected
+// k_gemv_sa: the fp32 weight stream with SCALAR row addressing.  In its predecessor (k_gemv, round 1; kept in tools/legacy_kernels.h for
+// the ablation probe) every weight load takes a per-lane 64-bit pointer that is selected
 // (v_cndmask x2), offset (v_lshl_add_u64) and, for grouped matrices, rebuilt from a pointer fetched out of the kernel arguments
 // per row: ~24 VALU instructions per row pair next to 32 FMAs, and the compiler parks all refills behind them at the end of
 // the iteration.  Here the row base is a wave-uniform (SGPR) pointer — matrix bases hoisted into registers once, row index
@@ -423,6 +333,10 @@ struct AttnArgs {
     float scale;           // fl32(1/sqrt(hd)) llama.go:306
     const StepParams* sp;  // past (device) ...
     uint32_t past_host;    // ... or host value when sp == nullptr
+    // batched Eval (lh_batch): query row j belongs to its own stream: keys 0..rows[j].pos of the cache rows[j].kc / .vc (+ kv_off floats: the
+    // layer's slot); k_cache, v_cache, sp and past_host are then unused
+    const BatchRow* rows;
+    uint64_t kv_off;
 };
 
 constexpr int ATT_TH = 1024;
@@ -432,16 +346,16 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
     constexpr int NWV = ATT_TH / 64, NG = ATT_TH / 32;  // waves, 32-lane key groups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t h = blockIdx.x, j = blockIdx.y;
-    const uint32_t past = a.sp ? a.sp->past : a.past_host;
-    const uint32_t T = past + j + 1;  // keys 0..past+j are visible to query j (mask: i > past + j, ml.go:2401-2404)
+    const uint32_t past = a.rows ? a.rows[j].pos : (a.sp ? a.sp->past : a.past_host);
+    const uint32_t T = a.rows ? past + 1 : past + j + 1;  // keys 0..past+j are visible to query j (mask: i > past + j, ml.go:2401-2404)
     const uint32_t Tp = (T + 63) & ~63u;
     float* sc = (float*)smem_raw;     // [Tp] scaled scores
     float* pr = sc + Tp;              // [Tp] un-normalised probabilities
     float* scratch = pr + Tp;         // [ATT_TH] PV partials / reduction scratch
     const uint32_t d = a.d, hd = a.hd;
     const float* q = a.q + (size_t)j * d + h * hd;
-    const float* Kc = a.k_cache + h * hd;
-    const float* Vc = a.v_cache + h * hd;
+    const float* Kc = (a.rows ? a.rows[j].kc + a.kv_off : a.k_cache) + h * hd;
+    const float* Vc = (a.rows ? a.rows[j].vc + a.kv_off : a.v_cache) + h * hd;
     // The cache rows of one head are 512 B segments strided by embd: every loop below keeps several INDEPENDENT row
     // loads in flight per lane (a dependent one-row-per-iteration loop costs a full L2 latency per key: 0.27 us/key measured).
     const uint32_t phases = ATT_TH / hd;  // hd = 128 -> 8 key phases in the PV step
@@ -576,15 +490,15 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
     __shared__ float scratch[ATT_TH];
     constexpr int NG = ATT_TH / 32;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t h = blockIdx.x, ch = blockIdx.y, nch = gridDim.y;
-    const uint32_t past = a.sp ? a.sp->past : a.past_host;
+    const uint32_t h = blockIdx.x, ch = blockIdx.y, nch = gridDim.y, j = blockIdx.z;   // j: row of a batched Eval (0 otherwise)
+    const uint32_t past = a.rows ? a.rows[j].pos : (a.sp ? a.sp->past : a.past_host);
     const uint32_t T = past + 1, c0 = ch * ATT_TC;
     if (c0 >= T) return;
     const uint32_t Tl = (T - c0 < (uint32_t)ATT_TC) ? T - c0 : (uint32_t)ATT_TC;  // keys of this chunk
     const uint32_t d = a.d, hd = a.hd;
-    const float* q = a.q + h * hd;
-    const float* Kc = a.k_cache + (size_t)c0 * d + h * hd;
-    const float* Vc = a.v_cache + (size_t)c0 * d + h * hd;
+    const float* q = a.q + (size_t)j * d + h * hd;
+    const float* Kc = (a.rows ? a.rows[j].kc + a.kv_off : a.k_cache) + (size_t)c0 * d + h * hd;
+    const float* Vc = (a.rows ? a.rows[j].vc + a.kv_off : a.v_cache) + (size_t)c0 * d + h * hd;
     const uint32_t phases = ATT_TH / hd, c = tid % hd, ph = tid / hd;
     constexpr int VP = ATT_TC / 8;  // hd = 128: 8 phases x 16 keys = the whole chunk in flight
     float vpre[VP];
@@ -632,7 +546,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
     }
     scratch[tid] = acc;
     __syncthreads();
-    float* dst = part + ((size_t)h * nch + ch) * (hd + 2);
+    float* dst = part + (((size_t)j * gridDim.x + h) * nch + ch) * (hd + 2);
     if (tid < (int)hd) {
         float o = scratch[tid];
         for (uint32_t p2 = 1; p2 < phases; ++p2) o += scratch[tid + p2 * hd];
@@ -642,10 +556,10 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
 }
 
 __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, const float* __restrict__ part, uint32_t nch) {
-    const uint32_t h = blockIdx.x, hd = a.hd;
-    const uint32_t past = a.sp ? a.sp->past : a.past_host;
+    const uint32_t h = blockIdx.x, hd = a.hd, j = blockIdx.y;
+    const uint32_t past = a.rows ? a.rows[j].pos : (a.sp ? a.sp->past : a.past_host);
     const uint32_t T = past + 1, n = (T + ATT_TC - 1) / ATT_TC;  // active chunks
-    const float* base = part + (size_t)h * nch * (hd + 2);
+    const float* base = part + ((size_t)j * gridDim.x + h) * nch * (hd + 2);
     float M = -INFINITY;
     for (uint32_t s = 0; s < n; ++s) M = fmaxf(M, base[(size_t)s * (hd + 2) + hd]);
     float l = 0.f;
@@ -660,7 +574,7 @@ __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, con
             const float w = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
             o = fmaf(base[(size_t)s * (hd + 2) + c], w, o);
         }
-        a.out[h * hd + c] = __fmul_rn(o, inv);
+        a.out[(size_t)j * a.d + h * hd + c] = __fmul_rn(o, inv);
     }
 }
 
@@ -796,8 +710,10 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const float* __restrict__ 
 // RoPE on Q (mode 0) and on the new K rows, K/V append into the cache (prefill): qkv rows [N][3][d] -> q [N][d], caches.
 __global__ __launch_bounds__(256) void k_rope_store(const float* __restrict__ qraw, const float* __restrict__ kraw, const float* __restrict__ vraw,
                                                      float* __restrict__ q, float* __restrict__ k_cache, float* __restrict__ v_cache,
-                                                     const double2* __restrict__ rope, uint32_t d, uint32_t hd, uint32_t past) {
-    const uint32_t row = blockIdx.x, pos = past + row;
+                                                     const double2* __restrict__ rope, uint32_t d, uint32_t hd, uint32_t past,
+                                                     const BatchRow* __restrict__ rows = nullptr, uint64_t kv_off = 0) {
+    const uint32_t row = blockIdx.x, pos = rows ? rows[row].pos : past + row;
+    if (rows) { k_cache = rows[row].kc + kv_off; v_cache = rows[row].vc + kv_off; }   // batched Eval: the row's own cache
     for (uint32_t e = threadIdx.x * 2; e < d; e += 512) {
         const double2 cs = rope[(size_t)pos * (hd >> 1) + ((e % hd) >> 1)];
         float o0, o1;
@@ -810,6 +726,59 @@ __global__ __launch_bounds__(256) void k_rope_store(const float* __restrict__ qr
         v_cache[(size_t)pos * d + e] = vraw[(size_t)row * d + e];
         v_cache[(size_t)pos * d + e + 1] = vraw[(size_t)row * d + e + 1];
     }
+}
+
+// ---- batched decode (lh_batch): bookkeeping of the row table ---------------------------------------------------------------------
+// One thread per row: position and (first stage) token of the next tick, from kernel arguments (<= 64 rows: 2 x 256 B of arguments).
+struct BatchSetArgs { uint32_t pos[64]; uint32_t tok[64]; };
+__global__ void k_batch_set(BatchRow* rows, uint32_t* tok, uint32_t n, int set_tok, const BatchSetArgs v, StepParams* sp, uint32_t* step, uint32_t step0) {
+    const uint32_t i = threadIdx.x;
+    if (i == 0) *step = step0;
+    if (i >= n) return;
+    rows[i].pos = v.pos[i];
+    sp[i].step = step0;
+    if (set_tok && tok) tok[i] = v.tok[i];
+}
+// Greedy argmax of every row's logits (strict >, lowest index on ties: SURVEY §8c) -> ids_out[row]; `advance`: the id becomes the row's
+// next token, is appended to the row's output list out[row * out_cap + *step] and the row's position moves on (the resident loop).
+// grid = rows, 1024 threads.  *step is only read here; k_batch_advance (the next launch) moves it on.
+__global__ __launch_bounds__(1024) void k_batch_argmax(const float* __restrict__ logits, uint32_t V, BatchRow* rows, uint32_t* tok, uint32_t* __restrict__ ids_out,
+                                                       uint32_t* __restrict__ out, uint32_t out_cap, const uint32_t* __restrict__ step, int advance) {
+    __shared__ float sv[16];
+    __shared__ uint32_t si[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t row = blockIdx.x;
+    const float* lg = logits + (size_t)row * V;
+    float bv = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < V; i += 1024) {   // ascending i inside a thread: the first maximum is kept
+        const float v = lg[i];
+        if (v > bv || bi == 0xFFFFFFFFu) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const uint32_t oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (ids_out) ids_out[row] = bi;
+        if (advance) {
+            if (out && *step < out_cap) out[(size_t)row * out_cap + *step] = bi;
+            tok[row] = bi;
+            rows[row].pos += 1;
+        }
+    }
+}
+// every row's position moves on by one (ranks that do not sample: the last rank's argmax does it there); *step += 1 when given
+__global__ void k_batch_advance(BatchRow* rows, uint32_t n, uint32_t* step) {
+    const uint32_t i = threadIdx.x;
+    if (i < n && rows) rows[i].pos += 1;
+    if (i == 0 && step) *step += 1;
 }
 
 // silu(a) * b elementwise (prefill FFN gate).

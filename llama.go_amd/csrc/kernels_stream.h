@@ -44,6 +44,10 @@ struct StreamArgs {
     float* v_cache;
     const double2* rope; //   [pos][hd / 2] (cos, sin)
     uint32_t hd, past;
+    // batched Eval (rows of DIFFERENT streams, lh_batch): column c is at position rows[c].pos of ITS OWN cache rows[c].kc / .vc (+ kv_off floats:
+    // this layer's slot); past, k_cache and v_cache above are then unused
+    const BatchRow* rows;
+    uint64_t kv_off;
     // RMSNorm folded into the launch (k_stream_mm2): x is the RAW residual stream, gamma the norm weight [K].  The norm is linear in its
     // per-token scale s = fl32(1 / sqrt(mean(x^2) + 1e-5)), so the kernel contracts W with gamma * x and multiplies the sums by s in the
     // epilogue; s comes from the x chunks the loader waves stage anyway (fp32 squares, f64 sum, fixed order).  Rounding differs from
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                     tile_of(t0 + t, &g, &tile);
                     const uint32_t row = tile * 16 + quad * 4;
                     if (a.epi == ST_EPI_QKV_ROPE) {   // Rope mode 0 on Q / mode 1 on the new K rows (ml.go:2253-2328), K, V appended (llama.go:274-278)
-                        const uint32_t pos = a.past + col, half = a.hd >> 1;
+                        const uint32_t pos = a.rows ? a.rows[col].pos : a.past + col, half = a.hd >> 1;
                         if (g < 2) {
                             const double2 c0 = a.rope[(size_t)pos * half + ((row % a.hd) >> 1)], c1 = a.rope[(size_t)pos * half + (((row + 2) % a.hd) >> 1)];
                             float o0, o1, o2, o3;
@@ -747,7 +751,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                             rope_rotate(s.z, s.w, c1, &o2, &o3);
                             s = f4{o0, o1, o2, o3};
                         }
-                        float* dst = g == 0 ? a.q_out + (size_t)col * a.M + row : (g == 1 ? a.k_cache : a.v_cache) + (size_t)pos * a.M + row;
+                        float* kcb = a.rows ? a.rows[col].kc + a.kv_off : a.k_cache;
+                        float* vcb = a.rows ? a.rows[col].vc + a.kv_off : a.v_cache;
+                        float* dst = g == 0 ? a.q_out + (size_t)col * a.M + row : (g == 1 ? kcb : vcb) + (size_t)pos * a.M + row;
                         *(f4*)dst = s;
                     } else {
                         const size_t o = (size_t)col * a.ldy + row;

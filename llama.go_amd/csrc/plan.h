@@ -6,7 +6,6 @@
 namespace lh {
 
 struct SampleState;
-struct PersistState;   // resident decode kernel: uncached exchange vectors, barrier counter, layer table (plan.hip)
 
 struct LayerW {
     const float *attn_norm = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *ffn_norm = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
@@ -40,6 +39,7 @@ struct Plan {
     ModelDesc md;
     // scratch, sized for n_cap rows
     uint32_t n_cap = 0;
+    uint64_t scratch_gen = 0;                 // counts re-allocations of the scratch below (graphs captured elsewhere - lh_batch - compare it)
     float *xa = nullptr, *xb = nullptr, *h = nullptr, *qraw = nullptr, *kraw = nullptr, *vraw = nullptr, *q = nullptr, *attn = nullptr;
     float *a1 = nullptr, *a3 = nullptr, *g = nullptr, *logits = nullptr;
     float* attn_part = nullptr;               // split-T decode attention partials [H][chunks][hd + 2] (plans with ctx > 256)
@@ -69,9 +69,13 @@ struct Plan {
     uint32_t smp_topk = 0;                    // topK the sampler launches (and the captured graph) were chosen for
     uint32_t slot_counter = 0;   // round-robin over the pinned StepParams slots of eager (non-graph) steps
     bool use_graph = true;
-    // resident decode kernel (csrc/kernels_decode_persist.h); graphs_resident = what the captured decode graphs contain
-    PersistState* ps = nullptr;
-    bool graphs_resident = false;
+};
+
+// A batched Eval: n rows that belong to n DIFFERENT streams (the pods of a rank, server.go:88-101), evaluated in one pass over the weights.
+struct BatchCtx {
+    const BatchRow* rows;      // device: row -> (its stream's KV cache, its position)
+    const uint32_t* tok_dev;   // device: the rows' token ids (first stage)
+    float* attn_part;          // split-T attention partials [rows][H][chunks][hd + 2] (plans with ctx > 256), else nullptr
 };
 
 int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out);
@@ -79,7 +83,9 @@ void plan_destroy(Plan* p);
 Plan* plan_find_or_create(lh_ctx* ctx, const ModelDesc& md, int* rc);
 int plan_ensure_rows(Plan* p, uint32_t n);
 // One llama.Eval on the plan: tokens (host) or x_in (device) -> logits rows in p->logits ([n][V]) or x_out (non-last stage).
-int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only = false);
+// bc != nullptr: the rows are those of a batched Eval (tokens_host / past unused; scratch must already hold n rows; logits for every row).
+int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only = false, const BatchCtx* bc = nullptr);
+bool plan_batch_rows_ok(const Plan* p, uint32_t n);   // can n rows of different streams take one weight pass on this plan?
 // enqueue the kernels of one decode step (N = 1), parameters from p->sp_dev
 int plan_enqueue_decode(Plan* p, const float* x_in_dev, float* x_out_dev, bool with_argmax_advance, lh_kernel_time* prof, uint32_t prof_cap, uint32_t* prof_n);
 int plan_decode_step(Plan* p, uint32_t token, uint32_t past);  // graph replay of one step; logits in p->logits

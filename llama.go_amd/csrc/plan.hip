@@ -8,7 +8,6 @@
 #include "kernels_skinny.h"
 #include "kernels_attn.h"
 #include "kernels_sample.h"
-#include "kernels_decode_persist.h"
 #include "kernels_stream.h"
 #include <math.h>
 #include <algorithm>
@@ -81,45 +80,30 @@ static int set_lds_once(lh_ctx* ctx, KernT kern, size_t lds, bool* flags) {
     return 0;
 }
 
-// A/B switches (read once): LLAMAHIP_GEMV_SA=0 -> vector-addressed fp32 GEMV (k_gemv) instead of the scalar-addressed k_gemv_sa;
-// LLAMAHIP_Q8_KERNEL=0 -> first block-int8 kernel (k_gemv_q8) instead of k_gemv_q8s; LLAMAHIP_Q8_WGPCU=2 -> two int8 workgroups
-// (8 waves per SIMD) per CU.
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
-static bool gemv_sa_on() { static const int v = env_int("LLAMAHIP_GEMV_SA", 1); return v != 0; }
-static bool q8_new_on() { static const int v = env_int("LLAMAHIP_Q8_KERNEL", 1); return v != 0; }
-static int q8_wg_per_cu() { static const int v = env_int("LLAMAHIP_Q8_WGPCU", 1); return v == 2 ? 2 : 1; }
+// "This kernel is not built for the shape - take the next one": positive, so it can never be mistaken for an LH_E* code (all negative).
+// Callers fall back ONLY on ST_NA; every other non-zero value is a real failure and is returned as it is.
+static constexpr int ST_NA = 1;
 
 template <int KI, int U, int PRO, int EPI, int MAP, int THR = TH>
 static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
-    static bool flags[2][16] = {};
-    const bool sa = gemv_sa_on();
-    int rc = sa ? set_lds_once(ctx, k_gemv_sa<KI, U, THR, PRO, EPI, MAP>, FAT_LDS, flags[1]) : set_lds_once(ctx, k_gemv<KI, U, THR, PRO, EPI, MAP>, FAT_LDS, flags[0]);
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, k_gemv_sa<KI, U, THR, PRO, EPI, MAP>, FAT_LDS, flags);
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    if (sa) hipLaunchKernelGGL((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
-    else hipLaunchKernelGGL((k_gemv<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    hipLaunchKernelGGL((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
 
 template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
 static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
-    static bool flags[2][2][16] = {};
-    const bool nw = q8_new_on();
-    const int wgpcu = q8_wg_per_cu();
-    // one fat workgroup per CU (LDS request > 80 KiB), or two (64 KiB each: a third does not fit into 160 KiB)
-    const size_t lds = wgpcu == 2 ? 64 * 1024 : FAT_LDS;
-    int rc = nw ? set_lds_once(ctx, k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>, FAT_LDS, flags[1][0]) : set_lds_once(ctx, k_gemv_q8<KI, U, TPR, PRO, EPI, MAP>, FAT_LDS, flags[0][0]);
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>, FAT_LDS, flags);   // one fat workgroup per CU (LDS request > 80 KiB)
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    const dim3 grid((unsigned)(ctx->ds->num_cu * wgpcu));
-    if (nw) hipLaunchKernelGGL((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>), grid, dim3(TH), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k_gemv_q8<KI, U, TPR, PRO, EPI, MAP>), grid, dim3(TH), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -226,7 +210,7 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
     GemmArgs a = a0;
     // the DMA ring needs a few slabs to pay for its prologue and its GST-1 redundant tail slabs: short contractions (Q.K^T, K = 128)
     // stay on the register-staged kernel
-    const bool dma = gemm_dma_ok(a) && a.K >= 16 * GBK && !getenv("LLAMAHIP_GEMM_NO_DMA");
+    const bool dma = gemm_dma_ok(a) && a.K >= 16 * GBK;
     const uint32_t tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.groups;
     static bool flags[2][16] = {};
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4 * a.groups);
@@ -244,7 +228,7 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
         // partial products summed by a second pass.  Cost in slab times: rounds of the busiest CU x (slabs per item + ~8 of
         // prologue/epilogue); S must divide the slab count and leave >= 16 slabs per item.
         uint32_t splits = 1;
-        if (!a.causal && batch == 1 && tiles < ncu && a.M % 4 == 0 && a.ldy % 4 == 0 && !getenv("LLAMAHIP_GEMM_NO_SPLITK")) {
+        if (!a.causal && batch == 1 && tiles < ncu && a.M % 4 == 0 && a.ldy % 4 == 0) {
             const uint32_t nkf = a.K / GBK;
             double best = (double)((tiles + ncu - 1) / ncu) * (nkf + 8);
             for (uint32_t s2 = 2; s2 <= 32; s2 *= 2) {
@@ -258,7 +242,7 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
             if (need > ctx->splitk_floats) {
                 LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
-                ctx->splitk = nullptr; ctx->splitk_floats = 0;
+                ctx->splitk = nullptr; ctx->splitk_floats = 0; ctx->splitk_gen++;
                 LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
                 ctx->splitk_floats = need;
             }
@@ -292,7 +276,7 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
     if (K % GBK || ldx % 4 || ((uintptr_t)x & 15)) LH_FAIL(ctx, LH_ESHAPE, "gemm_q8 %s: K=%u / ldx=%u / X alignment not supported", name, K, ldx);
     {   // up to 32 rows: the streaming MFMA kernel with dequantising loader waves (kernels_stream.h)
         const int rs = gemm_stream_group(ctx, x, ldx, groups, wq, y, r, M, K, n, ldy, name, nullptr, wsc);
-        if (rs >= 0) return rs;
+        if (rs != ST_NA) return rs;
     }
     GemmArgs a = {};
     a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
@@ -304,7 +288,7 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
     const int shape = n <= 64 ? 2 : rounds(160) * 1.03 < rounds(128) ? 1 : 0;
     const uint32_t bm = shape == 1 ? 160 : 128;
     const uint32_t tiles = tn * ((M + bm - 1) / bm) * groups;
-    if (tiles < ncu && M % 4 == 0 && ldy % 4 == 0 && !getenv("LLAMAHIP_GEMM_NO_SPLITK")) {
+    if (tiles < ncu && M % 4 == 0 && ldy % 4 == 0) {
         const uint32_t nkf = K / GBK;
         double best = (double)(nkf + 8);
         for (uint32_t s2 = 2; s2 <= 32; s2 *= 2) {
@@ -317,7 +301,7 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
             if (need > ctx->splitk_floats) {
                 LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
-                ctx->splitk = nullptr; ctx->splitk_floats = 0;
+                ctx->splitk = nullptr; ctx->splitk_floats = 0; ctx->splitk_gen++;
                 LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
                 ctx->splitk_floats = need;
             }
@@ -402,7 +386,6 @@ static int attention_gemm(Plan* p, const float* q, const float* kc, const float*
 }
 
 // Single-pass causal prefill attention (kernels_attn.h): one kernel per layer, no score tensor, no V^T copy.  hd = 128 (every LLaMA size).
-static bool flash_on() { static const int v = env_int("LLAMAHIP_FLASH", 1); return v != 0; }
 static int attention_flash(Plan* p, const float* q, const float* kc, const float* vc, float* out, uint32_t n, uint32_t past, float scale) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
@@ -423,26 +406,23 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // groups (<= 3) weight matrices of equal shape multiplied with the same X in ONE launch (wq|wk|wv, w1|w3): more tiles per
 // launch = less tile-count quantisation.  Tile shape chosen per launch: work of the busiest CU = ceil(tiles / #CU) * tile area.
 // ---- short prompts, 9..64 rows: the weight-streaming MFMA kernel (kernels_stream.h) ------------------------------------------------
-static bool stream_mm_on() { static const int v = env_int("LLAMAHIP_STREAM_MM", 1); return v != 0; }
 // up to 48 rows = three column tiles (six row tiles + three column tiles, two images: 152 KB of LDS).  Four column tiles do not fit next
 // to six row tiles with 128-column chunks (with the row tiles capped at three they measured 11.4-11.9 ms at 33..64 rows, no better than
 // the tile GEMM): 49..64 rows run half-length chunks (KC = 64: 2 x (6 + 4) x 16 x 68 floats = 87 KB), fp32 weights only.
-// LLAMAHIP_STREAM_MAX_ROWS lowers the limit for A/B runs.
 static constexpr uint32_t STREAM_ROWS_BUILT = 64, STREAM_ROWS_Q8 = 48;
 static int stream_nct(uint32_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4)); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
-static uint32_t stream_max_rows() { static const int v = env_int("LLAMAHIP_STREAM_MAX_ROWS", (int)STREAM_ROWS_BUILT); return (uint32_t)std::min<int>(std::max(v, 0), (int)STREAM_ROWS_BUILT); }
+static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
 
 template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     static bool flags[3][16] = {};
-    // wave-specialised variant (loader waves + MFMA waves, two LDS images) whenever the two images fit; LLAMAHIP_STREAM_MM=1 forces the
-    // first variant (every wave loads and computes) for A/B runs.  Block-int8 weights (a.ws set) exist in the specialised variant only.
-    static const bool v1_only = env_int("LLAMAHIP_STREAM_MM", 2) == 1;
+    // wave-specialised variant (loader waves + MFMA waves, two LDS images) whenever the two images fit, else the first variant (every
+    // wave loads and computes).  Block-int8 weights (a.ws set) exist in the specialised variant only.
     const bool q8 = a.ws[0] != nullptr;
-    const bool v2 = (!v1_only || q8) && stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
-    if ((q8 || a.gamma || a.ksplit > 1 || NCT > 2) && !v2) return -1;   // block-int8, folded norm, K-split, 3 / 4 column tiles: specialised variant only
-    if (q8 && NCT > 3) return -1;
+    const bool v2 = stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
+    if ((q8 || a.gamma || a.ksplit > 1 || NCT > 2 || a.rows) && !v2) return ST_NA;   // block-int8, folded norm, K-split, 3 / 4 column tiles, batched rows: specialised variant only
+    if (q8 && NCT > 3) return ST_NA;
     const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
@@ -487,25 +467,25 @@ static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name
         default: return launch_stream_n<8>(ctx, a, name);
     }
 }
-// returns -1 when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
+// returns ST_NA when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                              uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr, const float* const* wsc = nullptr) {
-    if (!stream_mm_on() || n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return -1;
+    if (n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return ST_NA;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
     // ST_EPI_SILU_MUL deals (w1, w3) tile pairs: twice the pairs' ceiling
     const uint32_t maxt = (fused && fused->epi == ST_EPI_SILU_MUL) ? 2 * ((M / 16 + ncu - 1) / ncu) : (T + ncu - 1) / ncu;
-    if (maxt > 8) return -1;
+    if (maxt > 8) return ST_NA;
     if (fused && fused->epi != ST_EPI_STORE) {   // the fused epilogues live in the wave-specialised variant only: its two images must fit
         const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8);
-        if ((env_int("LLAMAHIP_STREAM_MM", 2) == 1 && !wsc) || env_int("LLAMAHIP_STREAM_FUSED", 1) == 0 || stream2_lds_bytes(mt, stream_nct(n), stream_kc(n)) > 160 * 1024) return -1;
-        if (fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return -1;
+        if (stream2_lds_bytes(mt, stream_nct(n), stream_kc(n)) > 160 * 1024) return ST_NA;
+        if (fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return ST_NA;
     }
     StreamArgs a = {};
     if (fused) a = *fused;
     a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) {
         a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; a.ws[g] = wsc ? wsc[g] : nullptr;
-        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || (a.ws[g] && ((uintptr_t)a.ws[g] & 3))) return -1;
+        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || (a.ws[g] && ((uintptr_t)a.ws[g] & 3))) return ST_NA;
     }
     return launch_stream_maxt(ctx, a, name, maxt);
 }
@@ -514,27 +494,25 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
 // workgroup re-reads half of X out of L2 for twice the rows, and k_stream_reduce_norm adds the two partials + the residual and
 // writes the RMSNorm * gamma rows the NEXT matmul reads - it stands where that norm's launch stood.  Standalone, 32 rows (tools/
 // stream_mm_check, profiles/r02d_stream_ksplit.txt): w2 55.6 -> 45.6 us, wo 23.9 -> 22.0 us; at 16 rows nothing (37.7 -> 37.0, 17.9 -> 21.1).
-// returns -1 when not applicable (the caller takes the one-launch path).  LLAMAHIP_STREAM_KSPLIT: bit 0 wo, bit 1 w2 (default 3).
-static int stream_ksplit_mask() { static const int v = env_int("LLAMAHIP_STREAM_KSPLIT", 3); return v; }
+// returns ST_NA when not applicable (the caller takes the one-launch path).
 static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, const float* x, uint32_t ldx, uint32_t M, uint32_t K, uint32_t n, const float* resid,
                              float* y, const float* gamma, float* h, const char* name) {
     // pairs: four-way splits measured no better, standalone (w2 at 32 / 48 rows: 45.6 / 62.2 us in pairs, 47.6 / 60.6 in fours, + a longer
-    // reduce pass) and in the model (40 / 48 tokens: 8.94 / 9.01 ms vs 9.08 / 9.24); LLAMAHIP_STREAM_KSPLIT_S overrides for A/B runs
-    static const int s_env = env_int("LLAMAHIP_STREAM_KSPLIT_S", 0);
-    const uint32_t S = s_env > 1 ? (uint32_t)s_env : 2u;
-    if (!stream_mm_on() || env_int("LLAMAHIP_STREAM_MM", 2) == 1 || n <= 16 || n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return -1;
-    if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15) || ((uintptr_t)wsc & 3)) return -1;
+    // reduce pass) and in the model (40 / 48 tokens: 8.94 / 9.01 ms vs 9.08 / 9.24)
+    const uint32_t S = 2u;
+    if (n <= 16 || n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return ST_NA;
+    if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15) || ((uintptr_t)wsc & 3)) return ST_NA;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, ngrp = ncu / S;
-    if (ngrp == 0) return -1;
+    if (ngrp == 0) return ST_NA;
     const uint32_t maxt = (M / 16 + ngrp - 1) / ngrp;
-    if (maxt > 8) return -1;
+    if (maxt > 8) return ST_NA;
     const int mt = maxt <= 4 ? (int)maxt : (maxt <= 6 ? 6 : 8);
-    if (stream2_lds_bytes(mt, stream_nct(n), stream_kc(n)) > 160 * 1024) return -1;
+    if (stream2_lds_bytes(mt, stream_nct(n), stream_kc(n)) > 160 * 1024) return ST_NA;
     const uint64_t need = (uint64_t)S * n * M;
     if (need > ctx->splitk_floats) {
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
-        ctx->splitk = nullptr; ctx->splitk_floats = 0;
+        ctx->splitk = nullptr; ctx->splitk_floats = 0; ctx->splitk_gen++;
         LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
         ctx->splitk_floats = need;
     }
@@ -552,13 +530,13 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
 }
 
 // fused != nullptr: GEMM_EPI_SILU_MUL (w = {w1, w3}, y[0] = gated output [n][M]) or GEMM_EPI_QKV_ROPE (w = {wq, wk, wv}; outputs in *fused) in
-// the epilogue of the LDS-DMA tile GEMM; returns -1 when the launch cannot take it (short prompt, split-K, register-staged kernel) and
+// the epilogue of the LDS-DMA tile GEMM; returns ST_NA when the launch cannot take it (short prompt, split-K, register-staged kernel) and
 // the caller runs the plain GEMM + the separate pass.
 int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
                     uint32_t K, uint32_t n, uint32_t ldy, const char* name, const GemmArgs* fused = nullptr) {
     if (n <= stream_max_rows() && !fused) {
         const int rs = gemm_stream_group(ctx, x, ldx, groups, w, y, r, M, K, n, ldy, name);
-        if (rs >= 0) return rs;
+        if (rs != ST_NA) return rs;
     }
     GemmArgs a = {};
     if (fused) a = *fused;
@@ -572,8 +550,8 @@ int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, 
     };
     if (fused) {
         // only where the epilogue exists: the DMA kernel, whole contraction per tile (no split-K: at least one tile per CU), long prompts
-        if (n <= 64 || env_int("LLAMAHIP_GEMM_FUSED", 1) == 0 || !gemm_dma_ok(a) || a.K < 16 * GBK || getenv("LLAMAHIP_GEMM_NO_DMA") || tn * ((a.M + 159) / 160) * a.groups < ncu) return -1;
-        if (fused->epi == GEMM_EPI_QKV_ROPE && (fused->hd % 2 || M % fused->hd)) return -1;
+        if (n <= 64 || !gemm_dma_ok(a) || a.K < 16 * GBK || tn * ((a.M + 159) / 160) * a.groups < ncu) return ST_NA;
+        if (fused->epi == GEMM_EPI_QKV_ROPE && (fused->hd % 2 || M % fused->hd)) return ST_NA;
     }
     // up to 64 rows: 64 x 128 tiles (half the matrix work of a 128-row tile whose upper half would be padding)
     if (n <= 64) return launch_gemm<2, 2, 1, 2>(ctx, a, name);
@@ -599,9 +577,9 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
     // from 9 rows on the MFMA GEMM (64-row tiles, split-K) beats two or more passes of the 8-column weight stream (7B, one Eval:
     // 8 rows 10.0 ms and 16 rows 18.4 ms on the stream; 17 rows 11.1 ms on the MFMA path)
     if (n >= MFMA_MIN_ROWS && K % GBK == 0 && ldx % 4 == 0) return gemm_mfma(ctx, w, x, y, resid, M, K, n, ldx, ldy, name);
-    if (n >= 2) {   // 2..8 rows on the general path (LLAMAHIP_SKINNY=0 or a shape k_skinny is not built for): the streaming MFMA kernel
+    if (n >= 2) {   // 2..8 rows on the general path: the streaming MFMA kernel
         const int rs = gemm_stream_group(ctx, x, ldx, 1, &w, &y, resid ? &resid : nullptr, M, K, n, ldy, name);
-        if (rs >= 0) return rs;
+        if (rs != ST_NA) return rs;
     }
     const uint32_t K4 = K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
@@ -627,17 +605,16 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
 
 // ---- short prompts (2..8 token rows, fp32 weights): one fused pass over the weights per matrix group (kernels_skinny.h) -------
 static constexpr uint32_t SKINNY_NP = 8, SKINNY_KC_MAX = 4096;
-static bool skinny_on() { static const int v = env_int("LLAMAHIP_SKINNY", 1); return v != 0; }
 // shapes the kernel is built for: every contraction length a whole number of ring groups (256 floats), RoPE pairs inside a head
 // whole-model check for the streaming MFMA kernel (the 2..8-row prompts prefer it over k_skinny: 6.0 vs 6.5 ms on 7B)
 static bool stream_shape_ok(lh_ctx* ctx, const ModelDesc& m) {
-    if (!stream_mm_on() || m.wtype != 0 || m.d % 128 || m.F % 128) return false;
+    if (m.wtype != 0 || m.d % 128 || m.F % 128) return false;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu;
     auto maxt = [&](uint32_t rows) { return (rows / 16 + ncu - 1) / ncu; };
     return maxt(3 * m.d) <= 8 && maxt(2 * m.F) <= 8;
 }
 static bool skinny_ok(const ModelDesc& m, uint32_t n) {
-    return skinny_on() && m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % SK_GRP == 0 && m.F % SK_GRP == 0 && m.hd % 2 == 0;
+    return m.wtype == 0 && n >= 2 && n <= SKINNY_NP && m.d % SK_GRP == 0 && m.F % SK_GRP == 0 && m.hd % 2 == 0;
 }
 template <int PRO, int EPI, int MAP>
 static int launch_skinny(Plan* p, SkinnyArgs a, const char* name) {
@@ -701,19 +678,20 @@ static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
 }
 
 // decode attention for long-context plans: chunks of ATT_TC keys per workgroup + combine
-static int launch_attention_split(Plan* p, const AttnArgs& a) {
+// (part: [rows][H][chunks][hd + 2] partials; rows = a.n query rows of a batched Eval, 1 otherwise)
+static int launch_attention_split(Plan* p, const AttnArgs& a, float* part) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     if (a.hd != 128) LH_FAIL(ctx, LH_EUNSUPPORTED, "split attention: head dim %u", a.hd);
-    const uint32_t nch = (m.ctx + ATT_TC - 1) / ATT_TC;
+    const uint32_t nch = (m.ctx + ATT_TC - 1) / ATT_TC, nrows = a.rows ? a.n : 1u;
     if (g_prepare_only || g_only) return 0;
     {
-        ProfScope ps(ctx->stream, "attention_split", (uint64_t)2 * m.ctx * a.d * 4);
-        hipLaunchKernelGGL(k_attention_split, dim3(m.H, nch), dim3(ATT_TH), 0, ctx->stream, a, p->attn_part);
+        ProfScope ps(ctx->stream, "attention_split", (uint64_t)2 * m.ctx * a.d * 4 * nrows);
+        hipLaunchKernelGGL(k_attention_split, dim3(m.H, nch, nrows), dim3(ATT_TH), 0, ctx->stream, a, part);
     }
     {
-        ProfScope ps(ctx->stream, "attention_combine", (uint64_t)m.H * nch * (a.hd + 2) * 4);
-        hipLaunchKernelGGL(k_attention_combine, dim3(m.H), dim3(128), 0, ctx->stream, a, (const float*)p->attn_part, nch);
+        ProfScope ps(ctx->stream, "attention_combine", (uint64_t)m.H * nch * (a.hd + 2) * 4 * nrows);
+        hipLaunchKernelGGL(k_attention_combine, dim3(m.H, nrows), dim3(128), 0, ctx->stream, a, (const float*)part, nch);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -749,6 +727,7 @@ int plan_ensure_rows(Plan* p, uint32_t n) {
     if (p->tokens_dev) LH_HIP(ctx, hipFree(p->tokens_dev));
     LH_HIP(ctx, hipMalloc((void**)&p->tokens_dev, (size_t)n * 4));
     p->n_cap = n;
+    p->scratch_gen++;
     // captured graphs hold the old scratch addresses
     drop_graphs(p, ~0u);
     return 0;
@@ -758,13 +737,6 @@ static constexpr uint32_t SP_SLOTS = 64;
 
 int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     if (md.d % md.H || md.d % 4 || md.F % 4) LH_FAIL(ctx, LH_ESHAPE, "plan: embd %u / heads %u / ff %u not supported", md.d, md.H, md.F);
-    if (!ctx->counted_for_resident) {
-        // second context with a plan on the device: from now on decode takes the per-layer kernels; a resident kernel still in flight
-        // (launched under this mutex by the first context) finishes before this context launches anything
-        std::lock_guard<std::mutex> lk(ctx->ds->resident_mu);
-        ctx->counted_for_resident = true;
-        if (++ctx->ds->live_ctx == 2) hipDeviceSynchronize();
-    }
     Plan* p = new Plan();
     p->ctx = ctx;
     p->md = md;
@@ -778,9 +750,7 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
     rc = plan_ensure_rows(p, 1);
     if (rc) { plan_destroy(p); return rc; }
-    const char* envs = getenv("LLAMAHIP_SPLIT_ATTN");  // 0 = never, 1 = always (default: contexts longer than 256)
-    const bool split = envs ? envs[0] == '1' : md.ctx > 256;
-    if (split && md.hd == 128) {
+    if (md.ctx > 256 && md.hd == 128) {   // long contexts: decode attention split over the keys (k_attention_split)
         const size_t nch = (md.ctx + ATT_TC - 1) / ATT_TC;
         e = hipMalloc((void**)&p->attn_part, (size_t)md.H * nch * (md.hd + 2) * 4);
         if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
@@ -789,14 +759,11 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     return 0;
 }
 
-static void persist_destroy(Plan* p);
-
 void plan_destroy(Plan* p) {
     if (!p) return;
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p, ~0u);
-    persist_destroy(p);
     if (p->ss_dev) hipFree(p->ss_dev);
     if (p->ring_dev) hipFree(p->ring_dev);
     float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part};
@@ -824,163 +791,6 @@ void destroy_plans(lh_ctx* ctx) {
     ctx->plans.clear();
 }
 
-// ---- resident decode kernel (csrc/kernels_decode_persist.h) ---------------------------------------------------------------------
-// One launch per token instead of 5 per layer.  OFF by default: measured on the 7B benchmark it ties with the per-layer kernels
-// (4349-4398 us vs 4353 us per token, profiles/r02b_resident_trace.txt: the five all-to-all hand-offs per layer cost what the launch
-// boundaries cost).  LLAMAHIP_RESIDENT=1 (read when a plan first decodes) selects it for whole-model fp32 plans whose shape has an
-// instantiation, while this context is the only one with a plan on the device (DeviceState::live_ctx).
-struct PersistState {
-    float *xa = nullptr, *xb = nullptr, *q = nullptr, *attn = nullptr, *g = nullptr;   // uncached exchange vectors
-    unsigned long long* count = nullptr;   // uncached
-    uint32_t* err = nullptr;               // uncached
-    float* dummy = nullptr;                // ordinary memory, zeros, >= the longest row
-    PersistLayer* layers_dev = nullptr;
-    int kd = 0, kf = 0;                    // float4 per thread of a d-long / ff-long row
-    bool failed = false;                   // a barrier timed out once: the plan stays on the ordinary kernels
-};
-
-static bool resident_env_on() { return env_int("LLAMAHIP_RESIDENT", 0) != 0; }
-static thread_local bool g_resident = false;   // decode launches of this thread take the resident kernel (set by ResidentScope)
-static thread_local int g_resident_depth = 0;
-
-static bool persist_shape_ok(const Plan* p, int* kd, int* kf) {
-    const ModelDesc& m = p->md;
-    if (!resident_env_on() || !m.first_stage() || !m.last_stage() || m.wtype != 0 || p->attn_part) return false;
-    if (m.d % 4 || m.F % 4 || m.hd % 4 || m.hd > (uint32_t)PTH || PTH % m.hd) return false;
-    const uint32_t nwg = (uint32_t)p->ctx->ds->num_cu;
-    if (m.H > nwg || nwg < 2) return false;
-    // one finishing thread per row (store / residual epilogues) or per row pair (RoPE / SiLU epilogues)
-    if (m.V / nwg + 4 > (uint32_t)PTH || m.d / nwg + 4 > (uint32_t)PTH || 3 * m.d / nwg + 4 > 2u * PTH || 2 * m.F / nwg + 4 > 2u * PTH) return false;
-    if ((2 * (size_t)((m.ctx + 63) & ~63u) + PTH) * 4 > 32 * 1024) return false;   // attention scores in LDS
-    *kd = (int)((m.d / 4 + PTH - 1) / PTH);
-    *kf = (int)((m.F / 4 + PTH - 1) / PTH);
-    return (*kd == 1 && (*kf == 1 || *kf == 2)) || (*kd == 2 && *kf == 6);
-}
-
-static bool persist_shape_ok_cached(Plan* p) {
-    if (p->ps) return !p->ps->failed;
-    int kd, kf;
-    return persist_shape_ok(p, &kd, &kf);
-}
-
-static void persist_destroy(Plan* p) {
-    PersistState* s = p->ps;
-    if (!s) return;
-    void* bufs[] = {s->xa, s->xb, s->q, s->attn, s->g, s->count, s->err, s->dummy, s->layers_dev};
-    for (void* b : bufs) if (b) hipFree(b);
-    delete s;
-    p->ps = nullptr;
-}
-
-// Allocates the resident kernel's state on first use.  Returns false (and leaves the plan on the ordinary kernels) when the shape has
-// no instantiation or the uncached allocations are not available.
-static bool persist_ready(Plan* p) {
-    if (p->ps) return !p->ps->failed;
-    int kd, kf;
-    if (!persist_shape_ok(p, &kd, &kf)) return false;
-    const ModelDesc& m = p->md;
-    PersistState* s = new PersistState();
-    s->kd = kd; s->kf = kf;
-    p->ps = s;
-    auto uc = [&](void** ptr, size_t bytes) { return hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached) == hipSuccess && hipMemset(*ptr, 0, bytes) == hipSuccess; };
-    const size_t longest = (size_t)std::max(m.d, m.F) * 4 + 4096;
-    bool ok = uc((void**)&s->xa, (size_t)m.d * 4) && uc((void**)&s->xb, (size_t)m.d * 4) && uc((void**)&s->q, (size_t)m.d * 4) && uc((void**)&s->attn, (size_t)m.d * 4) &&
-              uc((void**)&s->g, (size_t)m.F * 4) && uc((void**)&s->count, 64) && uc((void**)&s->err, 64);
-    ok = ok && hipMalloc((void**)&s->dummy, longest) == hipSuccess && hipMemset(s->dummy, 0, longest) == hipSuccess;
-    std::vector<PersistLayer> hl(m.L);
-    for (uint32_t il = 0; il < m.L; ++il) {
-        const LayerW& L = m.layers[il];
-        const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
-        hl[il] = PersistLayer{L.attn_norm, L.wq, L.wk, L.wv, L.wo, L.ffn_norm, L.w1, L.w3, L.w2, m.kc + slot, m.vc + slot};
-    }
-    ok = ok && hipMalloc((void**)&s->layers_dev, sizeof(PersistLayer) * m.L) == hipSuccess &&
-         hipMemcpy(s->layers_dev, hl.data(), sizeof(PersistLayer) * m.L, hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); s->failed = true; }
-    return ok;
-}
-
-template <int KD, int KF>
-static int launch_persist(lh_ctx* ctx, const PersistDecodeArgs& a, uint64_t bytes) {
-    static bool flags[16] = {};
-    int rc = set_lds_once(ctx, k_decode_persist<KD, KF>, P_LDS_BYTES, flags);
-    if (rc) return rc;
-    if (skip_launch("gemv_decode_resident")) return 0;
-    ProfScope ps(ctx->stream, "gemv_decode_resident", bytes);
-    hipLaunchKernelGGL((k_decode_persist<KD, KF>), dim3(ctx->ds->num_cu), dim3(PTH), P_LDS_BYTES, ctx->stream, a);
-    LH_HIP(ctx, hipGetLastError());
-    return 0;
-}
-
-// embed -> resident kernel (all layers + lm_head): the decode step between the token id and the logits
-static int enqueue_decode_resident(Plan* p, const StepParams* sp, const uint32_t* tokens_dev, uint32_t logits_row) {
-    lh_ctx* ctx = p->ctx;
-    const ModelDesc& m = p->md;
-    PersistState* s = p->ps;
-    if (!g_prepare_only && !g_only) {
-        ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
-        hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, s->xa, m.d, m.V);
-        LH_HIP(ctx, hipGetLastError());
-    }
-    PersistDecodeArgs a = {};
-    a.layers = s->layers_dev; a.n_layers = m.L; a.d = m.d; a.F = m.F; a.V = m.V; a.H = m.H; a.hd = m.hd;
-    a.xa = s->xa; a.xb = s->xb; a.q = s->q; a.attn = s->attn; a.g = s->g;
-    a.norm = m.norm; a.output = m.output; a.logits = p->logits + logits_row * (size_t)m.V;
-    a.rope = p->rope; a.sp = sp; a.scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
-    a.ctl.count = s->count; a.ctl.err = s->err; a.ctl.arrivals_per_launch = persist_decode_arrivals(m.L, (uint32_t)ctx->ds->num_cu, m.H);
-    a.ctl.timeout_ticks = 2000000;   // 20 ms per barrier
-    a.ctl.nowait = 0; a.ctl.dummy = s->dummy;
-    const uint64_t bytes = 4ull * ((uint64_t)m.L * (4ull * m.d * m.d + 3ull * m.d * m.F + 2ull * m.d) + (uint64_t)m.V * m.d + m.d);
-    if (s->kd == 1 && s->kf == 1) return launch_persist<1, 1>(ctx, a, bytes);
-    if (s->kd == 1 && s->kf == 2) return launch_persist<1, 2>(ctx, a, bytes);
-    return launch_persist<2, 6>(ctx, a, bytes);
-}
-
-// Decides, for the decode launches a thread is about to enqueue, whether they take the resident kernel, and keeps the decision valid
-// while they are enqueued: resident launches happen under DeviceState::resident_mu, the same mutex under which a second context
-// announces itself (and then drains the device).  Captured decode graphs of the other kind are dropped.  Nested scopes are no-ops.
-struct ResidentScope {
-    Plan* p;
-    std::unique_lock<std::mutex> lk;
-    bool outer;
-    explicit ResidentScope(Plan* plan) : p(plan), outer(g_resident_depth++ == 0) {
-        if (!outer) return;
-        bool want = false;
-        if (persist_shape_ok_cached(p)) {
-            lk = std::unique_lock<std::mutex>(p->ctx->ds->resident_mu);
-            want = p->ctx->ds->live_ctx == 1 && persist_ready(p);
-            if (!want) lk.unlock();
-        }
-        if (want != p->graphs_resident) {
-            hipStreamSynchronize(p->ctx->stream);
-            drop_graphs(p, ~0u);
-            p->graphs_resident = want;
-        }
-        g_resident = want;
-    }
-    ~ResidentScope() {
-        --g_resident_depth;
-        if (outer) g_resident = false;
-    }
-};
-
-// After a stream synchronisation: did a barrier of the resident kernel time out (another process holding CUs)?  The results of
-// that call are then invalid: report it, reset the counter, and keep this plan on the ordinary kernels.
-static int persist_check(Plan* p) {
-    PersistState* s = p->ps;
-    if (!s || s->failed || !p->graphs_resident) return 0;
-    lh_ctx* ctx = p->ctx;
-    uint32_t err = 0;
-    LH_HIP(ctx, hipMemcpy(&err, s->err, 4, hipMemcpyDeviceToHost));
-    if (!err) return 0;
-    s->failed = true;
-    hipMemset(s->err, 0, 4);
-    hipMemset(s->count, 0, 8);
-    drop_graphs(p, ~0u);
-    p->graphs_resident = false;
-    LH_FAIL(ctx, LH_EHIP, "resident decode kernel: a grid barrier timed out (the GPU is shared with another process?); this call's results are invalid, "
-                         "later calls use the per-layer kernels");
-}
-
 // ---- decode step (N = 1): 5 kernels per layer --------------------------------------------------------
 // advance: 0 = logits only, 1 = greedy argmax + loop bookkeeping, 2 = device sampler + loop bookkeeping
 static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, int argmax_advance, uint32_t* argmax_out,
@@ -990,10 +800,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     const double2* rope = p->rope;
     int rc;
     const float* x = p->xa;
-    const bool resident = g_resident && p->ps && !p->ps->failed && !x_in && !x_out;
-    if (resident) {
-        if ((rc = enqueue_decode_resident(p, sp, tokens_dev, logits_row))) return rc;
-    } else if (m.first_stage()) {
+    if (m.first_stage()) {
         if (!g_prepare_only && !g_only) {
             ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
             TraceScope ts_(ctx->stream, "embed1");
@@ -1006,7 +813,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     float* xa = p->xa;
     float* xb = p->xb;
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
-    for (uint32_t il = m.layer0; il < m.layer1 && !resident; ++il) {
+    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
         {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K) -> K,V appended to the cache   (llama.go:255-297)
@@ -1019,7 +826,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
             AttnArgs a = {};
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = m.d; a.hd = m.hd; a.n = 1; a.scale = scale; a.sp = sp;
-            if (p->attn_part) { if ((rc = launch_attention_split(p, a))) return rc; }
+            if (p->attn_part) { if ((rc = launch_attention_split(p, a, p->attn_part))) return rc; }
             else if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
         }
         {   // wo + residual   (llama.go:336-340)
@@ -1042,7 +849,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         x = xa;
     }
     if (m.last_stage()) {   // final RMSNorm*gamma -> lm_head   (llama.go:374-384)
-        if (!resident) {
+        {
             GemvArgs a = {};
             a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
             if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
@@ -1130,7 +937,6 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
     if (past >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: position %u outside the context window of %u", past, m.ctx);
     if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "plan_decode_step needs a whole-model plan");
     int rc;
-    ResidentScope rs(p);
     if (p->use_graph) {
         if ((rc = ensure_decode_graph(p, Plan::G_STEP))) return rc;
         if ((rc = upload_step_params(p, 0, token, past, 0))) return rc;
@@ -1143,28 +949,49 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
 
 // ---- general Eval on the plan (N >= 1) ----------------------------------------------------------------
 
-int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only) {
+// Shapes a batched Eval (rows of different streams, BatchCtx) can take in ONE weight pass: every position-dependent kernel on that route
+// reads the row table (k_stream_mm2's RoPE epilogue, k_rope_store, k_attention, k_attention_split).  Routes that do not (k_skinny, the
+// tile GEMM's RoPE epilogue above 64 rows, the flash kernel, block-int8 single-token steps) are excluded here; lh_batch then evaluates
+// the rows one after the other on their own plans.
+static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n_min) {
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu;
+    return m.wtype == 7 && n >= n_min && n <= std::min(stream_max_rows(), STREAM_ROWS_Q8) && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
+           (3 * m.d / 16 + ncu - 1) / ncu <= 8 && 2 * ((m.F / 16 + ncu - 1) / ncu) <= 8;
+}
+bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
+    const ModelDesc& m = p->md;
+    if (n < 2 || n > stream_max_rows()) return false;
+    if (m.wtype == 7) return q8_stream_ok(p->ctx, m, n, 2);
+    return m.d % GBK == 0 && m.F % GBK == 0;
+}
+
+int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only, const BatchCtx* bc) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     if (n == 0) LH_FAIL(ctx, LH_EINVAL, "Eval: empty token batch");
-    if ((uint64_t)past + n > m.ctx) LH_FAIL(ctx, LH_EINVAL, "Eval: past %u + n %u exceeds the context window of %u", past, n, m.ctx);
-    if (m.first_stage() && !tokens_host) LH_FAIL(ctx, LH_EINVAL, "Eval: first stage needs token ids");
-    if (m.first_stage())  // Go panics on tokEmbeddings.Data[id*NE[0]:] past the table (ml.go:1748); the GPU must never gather out of range
-        for (uint32_t i = 0; i < n; ++i)
-            if (tokens_host[i] >= m.V) LH_FAIL(ctx, LH_EINVAL, "Eval: token id %u at index %u outside the vocabulary of %u", tokens_host[i], i, m.V);
+    if (bc) {
+        if (!bc->rows || (m.first_stage() && !bc->tok_dev) || !plan_batch_rows_ok(p, n)) LH_FAIL(ctx, LH_EINVAL, "Eval: batched rows need a row table, token ids and a supported shape");
+        if (n > p->n_cap) LH_FAIL(ctx, LH_EINVAL, "Eval: batched rows exceed the plan's scratch (plan_ensure_rows first: a captured graph must not allocate)");
+    } else {
+        if ((uint64_t)past + n > m.ctx) LH_FAIL(ctx, LH_EINVAL, "Eval: past %u + n %u exceeds the context window of %u", past, n, m.ctx);
+        if (m.first_stage() && !tokens_host) LH_FAIL(ctx, LH_EINVAL, "Eval: first stage needs token ids");
+        if (m.first_stage())  // Go panics on tokEmbeddings.Data[id*NE[0]:] past the table (ml.go:1748); the GPU must never gather out of range
+            for (uint32_t i = 0; i < n; ++i)
+                if (tokens_host[i] >= m.V) LH_FAIL(ctx, LH_EINVAL, "Eval: token id %u at index %u outside the vocabulary of %u", tokens_host[i], i, m.V);
+    }
     if (!m.first_stage() && !x_in_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: later stage needs the residual stream");
     if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: non-final stage needs an output buffer");
     int rc;
-    if ((rc = plan_ensure_rows(p, n))) return rc;
+    if (!bc && (rc = plan_ensure_rows(p, n))) return rc;
+    const BatchRow* rows = bc ? bc->rows : nullptr;
     if (n == 1) {
         if (m.first_stage() && m.last_stage() && p->use_graph) return plan_decode_step(p, tokens_host[0], past);
-        ResidentScope rs(p);
         const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    const bool q8_stream = m.wtype == 7 && n >= 3 && n <= std::min(stream_max_rows(), STREAM_ROWS_Q8) && stream_mm_on() && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
-                           (3 * m.d / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu <= 8 && 2 * ((m.F / 16 + ctx->ds->num_cu - 1) / ctx->ds->num_cu) <= 8;
+    // block-int8: 3..48 rows on the stream kernel's dequantising loader (a batched Eval: from 2 rows)
+    const bool q8_stream = q8_stream_ok(ctx, m, n, bc ? 2 : 3);
     if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
@@ -1178,7 +1005,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         return 0;
     }
-    if (skinny_ok(m, n) && !stream_shape_ok(ctx, m)) {   // k_skinny only where the streaming MFMA kernel is not built for the shape
+    if (!bc && skinny_ok(m, n) && !stream_shape_ok(ctx, m)) {   // k_skinny only where the streaming MFMA kernel is not built for the shape
         // ---- short prompt: 4 fused weight passes per layer + the per-query attention kernel (like the decode step, n rows wide)
         const float* x = p->xa;
         if (m.first_stage()) {
@@ -1241,16 +1068,19 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         LH_HIP(ctx, hipGetLastError());
         return 0;
     }
-    // ---- prefill, N > 1 rows
+    // ---- prefill, N > 1 rows (or the rows of a batched Eval: `rows` set, every row at its own position of its own cache)
     const double2* rope = p->rope;
     const float* x = p->xa;
     if (m.first_stage()) {
-        if ((rc = ensure_staging(ctx, (uint64_t)n * 4))) return rc;
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
-        memcpy(ctx->staging, tokens_host, (size_t)n * 4);
-        LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t* tok_dev = bc ? bc->tok_dev : p->tokens_dev;
+        if (!bc) {
+            if ((rc = ensure_staging(ctx, (uint64_t)n * 4))) return rc;
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
+            memcpy(ctx->staging, tokens_host, (size_t)n * 4);
+            LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
         TraceScope ts_(ctx->stream, "embedN");
-        hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
+        hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, tok_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
         LH_HIP(ctx, hipGetLastError());
     } else {
         x = x_in_dev;
@@ -1261,46 +1091,44 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
-        const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && stream_mm_on() && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;   // grouped MFMA launches: from 9 rows (tile GEMM), from 2 rows on the streaming MFMA kernel
+        const bool mfma = (n >= MFMA_MIN_ROWS || (n >= 2 && m.wtype == 0)) && d % GBK == 0 && F % GBK == 0;   // grouped MFMA launches: from 9 rows (tile GEMM), from 2 rows on the streaming MFMA kernel
         const bool q8 = m.wtype == 7;
         bool qkv_roped = false, gated = false;
-        // 17..32 rows: wo / w2 as K-split pairs whose reduce pass also writes the next norm's rows into p->h (gemm_stream_split)
-        const int ksp = (n > 16 && n <= stream_max_rows() && (q8 ? q8_stream : mfma)) ? stream_ksplit_mask() : 0;
+        // 17..64 rows: wo / w2 as K-split pairs whose reduce pass also writes the next norm's rows into p->h (gemm_stream_split)
+        const bool ksp = n > 16 && n <= stream_max_rows() && (q8 ? q8_stream : mfma);
         bool hf_ready = false;
         const float* wqkv[3] = {L.wq, L.wk, L.wv};
         const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
         float* yqkv[3] = {p->qraw, p->kraw, p->vraw};
-        if (n <= stream_max_rows() && (q8 || mfma)) {
+        // RoPE + cache append in the GEMM's epilogue (no rope_store pass, no raw q/k/v round trip): where each row goes
+        StreamArgs fq = {};
+        fq.epi = ST_EPI_QKV_ROPE; fq.q_out = p->q; fq.k_cache = m.kc + slot; fq.v_cache = m.vc + slot; fq.rope = rope; fq.hd = m.hd; fq.past = past;
+        fq.rows = rows; fq.kv_off = slot;
+        if (n <= stream_max_rows() && n <= 16 && (q8 || mfma)) {
             // short prompts: ONE launch for RMSNorm (folded: gamma at staging, the per-token scale in the epilogue) -> wq|wk|wv -> RoPE -> cache append
-            StreamArgs fa = {};
-            fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
             // (folded up to 16 rows: -3..5 % per Eval; at 17..32 rows the extra staging work of the loader waves eats the saved launch)
-            fa.gamma = (n <= 16 && env_int("LLAMAHIP_STREAM_NORM", 1)) ? L.attn_norm : nullptr;
-            int rs = -1;
-            if (fa.gamma) rs = gemm_stream_group(ctx, x, d, 3, wqkv, nullptr, nullptr, d, d, n, d, q8 ? "stream_q8_norm_wqkv_rope" : "stream_norm_wqkv_rope", &fa, q8 ? sqkv : nullptr);
-            if (rs > 0) return rs;
+            StreamArgs fa = fq;
+            fa.gamma = L.attn_norm;
+            const int rs = gemm_stream_group(ctx, x, d, 3, wqkv, nullptr, nullptr, d, d, n, d, q8 ? "stream_q8_norm_wqkv_rope" : "stream_norm_wqkv_rope", &fa, q8 ? sqkv : nullptr);
+            if (rs < 0) return rs;
             qkv_roped = rs == 0;
         }
         if (!qkv_roped && !h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
         h_ready = false;
         if (qkv_roped) {
         } else if (q8) {
-            StreamArgs fa = {};
-            fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fa, sqkv) : -1;
-            if (rs > 0) return rs;
+            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fq, sqkv) : ST_NA;
+            if (rs < 0) return rs;
             qkv_roped = rs == 0;
             if (!qkv_roped && (rc = gemm_q8_group(ctx, p->h, d, 3, wqkv, sqkv, yqkv, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
         } else if (mfma) {
-            StreamArgs fa = {};   // short prompts: RoPE + cache append in the GEMM's epilogue (no rope_store pass, no raw q/k/v round trip)
-            fa.epi = ST_EPI_QKV_ROPE; fa.q_out = p->q; fa.k_cache = m.kc + slot; fa.v_cache = m.vc + slot; fa.rope = rope; fa.hd = m.hd; fa.past = past;
-            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fa) : -1;
-            if (rs < 0 && n > 64) {   // long prompts: the same epilogue in the tile GEMM
+            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fq) : ST_NA;
+            if (rs == ST_NA && n > 64) {   // long prompts: the same epilogue in the tile GEMM
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_QKV_ROPE; ga.q_out = p->q; ga.k_cache = m.kc + slot; ga.v_cache = m.vc + slot; ga.rope = rope; ga.hd = m.hd; ga.past = past;
                 rs = gemm_mfma_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "gemm_wqkv_rope", &ga);
             }
-            if (rs > 0) return rs;
+            if (rs < 0) return rs;
             qkv_roped = rs == 0;
             if (!qkv_roped && (rc = gemm_mfma_group(ctx, p->h, d, 3, wqkv, yqkv, nullptr, d, d, n, d, "gemm_wqkv"))) return rc;
         } else {
@@ -1309,20 +1137,25 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
         }
         if (!qkv_roped) { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
-                           m.vc + slot, rope, d, m.hd, past); }
-        if (mfma && n >= 32 && m.hd == FA_HD && flash_on()) {   // single pass, online softmax
+                           m.vc + slot, rope, d, m.hd, past, rows, (uint64_t)slot); }
+        if (rows) {   // rows of different streams: one query each, against its own cache up to its own position
+            AttnArgs a = {};
+            a.q = p->q; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.rows = rows; a.kv_off = slot;
+            if (bc->attn_part) { if ((rc = launch_attention_split(p, a, bc->attn_part))) return rc; }
+            else if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
+        } else if (mfma && n >= 32 && m.hd == FA_HD) {   // single pass, online softmax
             if ((rc = attention_flash(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
-        } else if (mfma && n >= 32 && m.hd % 32 == 0) {  // fewer queries: the per-query kernel (no score tensor) is cheaper
+        } else if (mfma && n >= 32 && m.hd % 32 == 0) {  // other head sizes: batched MFMA GEMMs over heads with a score tensor
             if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
-        } else {
+        } else {   // fewer queries: the per-query kernel (no score tensor) is cheaper
             AttnArgs a = {};
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
             if ((rc = launch_attention(ctx, a, past + n))) return rc;
         }
-        int wo_rs = -1;
-        if (ksp & 1) {
+        int wo_rs = ST_NA;
+        if (ksp) {
             wo_rs = gemm_stream_split(ctx, L.wo, q8 ? L.s_wo : nullptr, p->attn, d, d, d, n, x, p->xb, L.ffn_norm, p->h, q8 ? "stream_q8_wo_ksplit" : "stream_wo_ksplit");
-            if (wo_rs > 0) return wo_rs;
+            if (wo_rs < 0) return wo_rs;
             hf_ready = wo_rs == 0;
         }
         if (wo_rs == 0) {
@@ -1332,13 +1165,12 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const float* s13[2] = {L.s_w1, L.s_w3};
         float* y13[2] = {p->a1, p->a3};
         float* yg[2] = {p->g, nullptr};
-        if (n <= stream_max_rows() && (q8 || mfma)) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
+        if (n <= stream_max_rows() && n <= 16 && (q8 || mfma)) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
-            fa.gamma = (n <= 16 && env_int("LLAMAHIP_STREAM_NORM", 1)) ? L.ffn_norm : nullptr;
-            int rs = -1;
-            if (fa.gamma) rs = gemm_stream_group(ctx, p->xb, d, 2, w13, yg, nullptr, F, d, n, F, q8 ? "stream_q8_norm_w1w3_silu" : "stream_norm_w1w3_silu", &fa, q8 ? s13 : nullptr);
-            if (rs > 0) return rs;
+            fa.gamma = L.ffn_norm;
+            const int rs = gemm_stream_group(ctx, p->xb, d, 2, w13, yg, nullptr, F, d, n, F, q8 ? "stream_q8_norm_w1w3_silu" : "stream_norm_w1w3_silu", &fa, q8 ? s13 : nullptr);
+            if (rs < 0) return rs;
             gated = rs == 0;
         }
         if (!gated && !hf_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
@@ -1346,20 +1178,20 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (q8) {
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
-            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, s13) : -1;
-            if (rs > 0) return rs;
+            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, s13) : ST_NA;
+            if (rs < 0) return rs;
             gated = rs == 0;
             if (!gated && (rc = gemm_q8_group(ctx, p->h, d, 2, w13, s13, y13, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
         } else if (mfma) {
             StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
             fa.epi = ST_EPI_SILU_MUL;
-            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : -1;
-            if (rs < 0 && n > 64) {
+            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : ST_NA;
+            if (rs == ST_NA && n > 64) {
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_SILU_MUL;
                 rs = gemm_mfma_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "gemm_w1w3_silu", &ga);
             }
-            if (rs > 0) return rs;
+            if (rs < 0) return rs;
             gated = rs == 0;
             if (!gated && (rc = gemm_mfma_group(ctx, p->h, d, 2, w13, y13, nullptr, F, d, n, F, "gemm_w1w3"))) return rc;
         } else {
@@ -1370,11 +1202,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                            (const float*)p->a3, p->g, (uint64_t)n * F); }
         const bool last = il + 1 == m.layer1;
         float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
-        int w2_rs = -1;
-        if (ksp & 2) {
+        int w2_rs = ST_NA;
+        if (ksp) {
             const float* next_gamma = last ? nullptr : m.layers[il + 1].attn_norm;   // the next layer's first norm rides on the reduce pass
             w2_rs = gemm_stream_split(ctx, L.w2, q8 ? L.s_w2 : nullptr, p->g, F, d, F, n, p->xb, y, next_gamma, p->h, q8 ? "stream_q8_w2_ksplit" : "stream_w2_ksplit");
-            if (w2_rs > 0) return w2_rs;
+            if (w2_rs < 0) return w2_rs;
             h_ready = w2_rs == 0 && next_gamma != nullptr;
         }
         if (w2_rs == 0) {
@@ -1392,7 +1224,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if (nr >= 32) {
                 if ((rc = gemm_q8(ctx, m.output, m.s_output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_q8_lmhead"))) return rc;
             } else {
-                for (uint32_t i = 0; i < nr; ++i) {  // a few rows: the int8 weight stream of the decode path, input already normalised
+                // a few rows: one launch of the stream kernel's dequantising loader when the shape allows, else the int8 GEMV row by row
+                const float* wv = m.output; const float* sv = m.s_output; float* yv = p->logits + (size_t)r0 * m.V;
+                const int rs = nr >= 2 ? gemm_stream_group(ctx, p->h + (size_t)r0 * d, d, 1, &wv, &yv, nullptr, m.V, d, nr, m.V, "stream_q8_lmhead", nullptr, &sv) : ST_NA;
+                if (rs < 0) return rs;
+                for (uint32_t i = 0; i < nr && rs == ST_NA; ++i) {
                     GemvArgs ga = {};
                     ga.w[0] = m.output; ga.ws[0] = m.s_output; ga.M = m.V; ga.K = d; ga.x = p->h + (size_t)(r0 + i) * d; ga.y = p->logits + (size_t)(r0 + i) * m.V;
                     if ((rc = gemv<PRO_PLAIN, EPI_STORE, MAP_SINGLE>(ctx, ga, "gemv_lmhead_row", 7))) return rc;
@@ -1400,6 +1236,152 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             }
         } else if ((rc = gemm_small_n(ctx, m.output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_lmhead"))) return rc;
     }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+
+// ---- lh_batch: the pods of a rank in ONE weight pass ---------------------------------------------------------------------------
+// The reference's only parallelism is request-level: Engine() runs up to MaxPods Do() goroutines (pkg/server/server.go:84-106), each with
+// its own llama.Context over the shared Model (server.go:151).  On the GPU an N = 1 Eval streams all weights, so P pods that decode
+// independently read P x 26.4 GB per round of tokens for the bandwidth of one.  A batch binds the stages of P streams (same weights and
+// layer range, one KV cache each) and evaluates one decode step of ALL of them as a P-row pass: the stream GEMMs of the short-prompt path
+// (k_stream_mm2: every weight byte read once for all rows), RoPE / cache append / attention per row from a device table
+// {row -> its cache, its position}.  Row results do not depend on the row's index or on the other rows (every output column of the MFMA
+// tiles accumulates on its own), so a stream decodes the same ids whoever shares its tick.
+// One tick = one captured hipGraph (token ids, positions and the residual stream live at fixed device addresses; the graph itself moves the
+// positions on), so a tick costs the host one hipGraphLaunch whatever the stage's length.
+struct Batch {
+    lh_ctx* ctx = nullptr;
+    std::vector<Plan*> pods;
+    uint32_t B = 0;
+    bool batched = false;          // rows share one weight pass (else: row by row on their own plans - same results, P weight passes)
+    BatchRow* rows_dev = nullptr;  // [B]
+    uint32_t* tok_dev = nullptr;   // [B] token ids of the next tick (first stage)
+    uint32_t* ids_dev = nullptr;   // [B] ids produced by the last tick (last stage)
+    uint32_t* step_dev = nullptr;  // ticks since the last lh_batch_set: index into the rows' output lists
+    uint32_t* out_dev = nullptr;   // [B][out_cap] ids produced per row (last stage)
+    uint32_t out_cap = 0;
+    StepParams* sp_dev = nullptr;  // [B] row-by-row mode: the rows' step parameters (mirrors of rows / tok)
+    float* logits_own = nullptr;   // [B][V] row-by-row mode with B > 1 (last stage)
+    float* attn_part = nullptr;    // batched, ctx > 256: split-T attention partials for B rows
+    // sampling ticks (lh_batch_set_sampler): per-row sampler state + lastNTokens ring
+    SampleState* ss_dev = nullptr; // [B]
+    uint32_t* ring_dev = nullptr;  // [B][ring_cap]
+    uint32_t ring_cap = 0, smp_topk = 0;
+    bool sampling = false;
+    // the captured tick
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const float* cap_x_in = nullptr;
+    float* cap_x_out = nullptr;
+    uint64_t cap_splitk_gen = 0, cap_scratch_gen = 0;
+    uint64_t scratch_gen() const { uint64_t g = 0; for (const Plan* p : pods) g += p->scratch_gen; return g; }   // grows when any pod's scratch moved
+    bool cap_sampling = false;
+    bool warm = false;
+    float* logits() const { return batched || B == 1 ? pods[0]->logits : logits_own; }
+};
+
+__global__ void k_batch_sync_sp(const BatchRow* rows, const uint32_t* tok, StepParams* sp, uint32_t n) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) { sp[i].token = tok[i]; sp[i].past = rows[i].pos; }
+}
+// after the per-row sampler launches: the sampled id (already appended to the row's ring and output list) becomes the row's next token
+__global__ void k_batch_from_sp(BatchRow* rows, uint32_t* tok, uint32_t* ids, const StepParams* sp, uint32_t n) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) { tok[i] = sp[i].token; ids[i] = sp[i].token; rows[i].pos += 1; }
+}
+
+static void batch_drop_graph(Batch* b) {
+    if (b->exec) { hipGraphExecDestroy(b->exec); b->exec = nullptr; }
+    if (b->graph) { hipGraphDestroy(b->graph); b->graph = nullptr; }
+}
+
+// the kernels of one tick, in stream order
+static int batch_enqueue_tick(Batch* b, const float* x_in, float* x_out) {
+    lh_ctx* ctx = b->ctx;
+    Plan* p0 = b->pods[0];
+    const ModelDesc& m = p0->md;
+    const uint32_t B = b->B;
+    int rc;
+    if (b->batched) {
+        BatchCtx bc = {b->rows_dev, b->tok_dev, b->attn_part};
+        if ((rc = plan_eval(p0, nullptr, x_in, x_out, B, 0, false, &bc))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_batch_sync_sp, dim3(1), dim3(64), 0, ctx->stream, (const BatchRow*)b->rows_dev, (const uint32_t*)b->tok_dev, b->sp_dev, B);
+        for (uint32_t i = 0; i < B; ++i) {
+            Plan* p = b->pods[i];
+            if ((rc = enqueue_decode(p, b->sp_dev + i, x_in ? x_in + (size_t)i * m.d : nullptr, x_out ? x_out + (size_t)i * m.d : nullptr, 0, nullptr, b->tok_dev + i))) return rc;
+            if (m.last_stage() && B > 1) LH_HIP(ctx, hipMemcpyAsync(b->logits_own + (size_t)i * m.V, p->logits, (size_t)m.V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    if (m.last_stage() && b->sampling) {
+        // SampleTopPTopK per row (llama.go:455-707) on the row's own ring / draw counter; the rows' step parameters carry the output index
+        hipLaunchKernelGGL(k_batch_sync_sp, dim3(1), dim3(64), 0, ctx->stream, (const BatchRow*)b->rows_dev, (const uint32_t*)b->tok_dev, b->sp_dev, B);
+        for (uint32_t i = 0; i < B; ++i)
+            if ((rc = sample_launch(ctx, b->logits() + (size_t)i * m.V, m.V, b->ss_dev + i, b->ring_dev + (size_t)i * b->ring_cap, b->sp_dev + i, b->out_dev + (size_t)i * b->out_cap,
+                                    nullptr, nullptr, nullptr, nullptr, 1, b->smp_topk)))
+                return rc;
+        hipLaunchKernelGGL(k_batch_from_sp, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->ids_dev, (const StepParams*)b->sp_dev, B);
+        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, (BatchRow*)nullptr, B, b->step_dev);
+    } else if (m.last_stage()) {
+        hipLaunchKernelGGL(k_batch_argmax, dim3(B), dim3(1024), 0, ctx->stream, (const float*)b->logits(), m.V, b->rows_dev, b->tok_dev, b->ids_dev, b->out_dev, b->out_cap,
+                           (const uint32_t*)b->step_dev, 1);
+        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, (BatchRow*)nullptr, B, b->step_dev);
+    } else {
+        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, B, b->step_dev);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// One tick on the stream: the first one eagerly (it sets kernel attributes and makes the allocations a capture must not make), then a
+// captured graph, re-captured when an address it holds has changed.
+static int batch_tick(Batch* b, const float* x_in, float* x_out) {
+    lh_ctx* ctx = b->ctx;
+    Plan* p0 = b->pods[0];
+    int rc;
+    if (!p0->use_graph || !b->warm) {
+        b->warm = true;
+        return batch_enqueue_tick(b, x_in, x_out);
+    }
+    if (b->exec && (b->cap_x_in != x_in || b->cap_x_out != x_out || b->cap_splitk_gen != ctx->splitk_gen || b->cap_scratch_gen != b->scratch_gen() || b->cap_sampling != b->sampling))
+        batch_drop_graph(b);
+    if (!b->exec) {
+        LH_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+        rc = batch_enqueue_tick(b, x_in, x_out);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &b->graph);
+        if (rc) { if (b->graph) { hipGraphDestroy(b->graph); b->graph = nullptr; } return rc; }
+        if (e != hipSuccess) LH_FAIL(ctx, LH_EHIP, "hipStreamEndCapture (batch tick): %s", hipGetErrorString(e));
+        LH_HIP(ctx, hipGraphInstantiate(&b->exec, b->graph, nullptr, nullptr, 0));
+        b->cap_x_in = x_in; b->cap_x_out = x_out; b->cap_splitk_gen = ctx->splitk_gen; b->cap_scratch_gen = b->scratch_gen(); b->cap_sampling = b->sampling;
+    }
+    LH_HIP(ctx, hipGraphLaunch(b->exec, ctx->stream));
+    return 0;
+}
+
+static void batch_free(Batch* b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    batch_drop_graph(b);
+    void* bufs[] = {b->rows_dev, b->tok_dev, b->ids_dev, b->step_dev, b->out_dev, b->sp_dev, b->logits_own, b->attn_part, b->ss_dev, b->ring_dev};
+    for (void* q : bufs) if (q) hipFree(q);
+    delete b;
+}
+
+// positions (and, tokens != nullptr, token ids) of the next tick from host values; the tick counter restarts at step0
+static int batch_set(Batch* b, const uint32_t* tokens, const uint32_t* past, uint32_t step0 = 0) {
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    BatchSetArgs v = {};
+    for (uint32_t i = 0; i < b->B; ++i) {
+        if (past[i] >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_set: row %u at position %u outside the context window of %u", i, past[i], m.ctx);
+        if (tokens && tokens[i] >= m.V) LH_FAIL(ctx, LH_EINVAL, "lh_batch_set: token id %u of row %u outside the vocabulary of %u", tokens[i], i, m.V);
+        v.pos[i] = past[i];
+        v.tok[i] = tokens ? tokens[i] : 0;
+    }
+    hipLaunchKernelGGL(k_batch_set, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->B, tokens ? 1 : 0, v, b->sp_dev, b->step_dev, step0);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1422,7 +1404,6 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     if (ctx->splitk) hipFree(ctx->splitk);
     if (ctx->staging) hipHostFree(ctx->staging);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-    if (ctx->ds && ctx->counted_for_resident) { std::lock_guard<std::mutex> lk(ctx->ds->resident_mu); --ctx->ds->live_ctx; }
     delete ctx;
 }
 
@@ -1509,7 +1490,7 @@ int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past
     if (logits_host)
         LH_HIP(ctx, hipMemcpyAsync(logits_host, p->logits + (size_t)(n - 1) * p->md.V, (size_t)p->md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return n == 1 ? persist_check(p) : LH_OK;
+    return LH_OK;
 }
 
 int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host) {
@@ -1523,20 +1504,17 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
     if (first_token >= md.V) LH_FAIL(ctx, LH_EINVAL, "decode: token id %u outside the vocabulary of %u", first_token, md.V);
     int rc;
     if ((rc = ensure_out_tokens(p, n_steps))) return rc;
-    {
-        ResidentScope rs(p);
-        if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
-        if (p->use_graph) {
-            if ((rc = launch_resident_steps(p, n_steps, Plan::G_ADV1, Plan::G_ADVN))) return rc;
-        } else {
-            for (uint32_t s = 0; s < n_steps; ++s)
-                if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
-        }
+    if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
+    if (p->use_graph) {
+        if ((rc = launch_resident_steps(p, n_steps, Plan::G_ADV1, Plan::G_ADVN))) return rc;
+    } else {
+        for (uint32_t s = 0; s < n_steps; ++s)
+            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
     }
     if (out_tokens) LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, p->logits, (size_t)md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return persist_check(p);
+    return LH_OK;
 }
 
 int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t ring_size, const lh_sample_params* sp,
@@ -1584,18 +1562,15 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
     if ((rc = upload_step_params(p, 0, 0, n_prompt - 1, 0))) return rc;
     const float* last_row = n_prompt == 1 ? p->logits : p->logits + (size_t)(n_prompt - 1) * md.V;
     if ((rc = sample_launch(ctx, last_row, md.V, p->ss_dev, p->ring_dev, p->sp_dev, p->out_tokens_dev, nullptr, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
-    {
-        ResidentScope rs(p);
-        if (p->use_graph) {
-            if (n_predict > 1 && (rc = launch_resident_steps(p, n_predict - 1, Plan::G_SMP1, Plan::G_SMPN))) return rc;
-        } else {
-            for (uint32_t s = 1; s < n_predict; ++s)
-                if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
-        }
+    if (p->use_graph) {
+        if (n_predict > 1 && (rc = launch_resident_steps(p, n_predict - 1, Plan::G_SMP1, Plan::G_SMPN))) return rc;
+    } else {
+        for (uint32_t s = 1; s < n_predict; ++s)
+            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
     }
     LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_predict * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return persist_check(p);
+    return LH_OK;
 }
 
 int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_dev, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past,
@@ -1612,7 +1587,6 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
         const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
         if (md.first_stage() && !tokens && !tokens_dev) LH_FAIL(ctx, LH_EINVAL, "stage: first stage needs a token id (host or device)");
         if (md.first_stage() && tokens && tokens[0] >= md.V) LH_FAIL(ctx, LH_EINVAL, "stage: token id %u outside the vocabulary of %u", tokens[0], md.V);
-        ResidentScope rs(p);
         if ((rc = upload_step_params(p, slot, tokens ? tokens[0] : 0, past, 0))) return rc;
         if ((rc = enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, md.last_stage() ? argmax_dev : nullptr, tokens ? nullptr : tokens_dev))) return rc;
     } else {
@@ -1629,6 +1603,201 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
     return LH_OK;
 }
 
+// ---- lh_batch ---------------------------------------------------------------------------------------------------------------------
+struct lh_batch { lh::Batch* b; };
+
+int lh_batch_create(lh_ctx* ctx, lh_llama* const* pods, uint32_t n_pods, lh_batch** out) {
+    if (!ctx || !pods || !out) LH_FAIL(ctx, LH_EINVAL, "lh_batch_create: NULL argument");
+    *out = nullptr;
+    if (n_pods == 0 || n_pods > 64) LH_FAIL(ctx, LH_EINVAL, "lh_batch_create: %u rows outside 1..64", n_pods);
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    Batch* b = new Batch();
+    b->ctx = ctx;
+    b->B = n_pods;
+    for (uint32_t i = 0; i < n_pods; ++i) {
+        if (!pods[i] || pods[i]->ctx != ctx) { delete b; LH_FAIL(ctx, LH_EINVAL, "lh_batch_create: pod %u lives on another context (one stream orders the tick)", i); }
+        Plan* p = pods[i]->plan;
+        if (i > 0) {
+            // same weights, same layer range, same shape; only the KV cache differs (a llama.Context per pod over one Model, server.go:151)
+            ModelDesc a = p->md, c = b->pods[0]->md;
+            a.kc = c.kc; a.vc = c.vc;
+            if (!a.same(c)) { delete b; LH_FAIL(ctx, LH_EINVAL, "lh_batch_create: pod %u is not a stage of the same model as pod 0", i); }
+            for (uint32_t j = 0; j < i; ++j)
+                if (b->pods[j]->md.kc == p->md.kc || b->pods[j]->md.vc == p->md.vc) { delete b; LH_FAIL(ctx, LH_EINVAL, "lh_batch_create: pods %u and %u share a KV cache", j, i); }
+        }
+        b->pods.push_back(p);
+    }
+    Plan* p0 = b->pods[0];
+    const ModelDesc& m = p0->md;
+    b->batched = plan_batch_rows_ok(p0, n_pods);
+    int rc = 0;
+    if (b->batched) rc = plan_ensure_rows(p0, n_pods);
+    else for (uint32_t i = 0; i < n_pods && !rc; ++i) rc = plan_ensure_rows(b->pods[i], 1);
+    if (rc) { batch_free(b); return rc; }
+    b->out_cap = m.ctx + 1;
+    auto al = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, bytes) == hipSuccess && hipMemsetAsync(*ptr, 0, bytes, ctx->stream) == hipSuccess; };
+    bool ok = al((void**)&b->rows_dev, sizeof(BatchRow) * n_pods) && al((void**)&b->tok_dev, 4 * (size_t)n_pods) && al((void**)&b->ids_dev, 4 * (size_t)n_pods) &&
+              al((void**)&b->step_dev, 4) && al((void**)&b->sp_dev, sizeof(StepParams) * n_pods);
+    if (ok && m.last_stage()) ok = al((void**)&b->out_dev, 4 * (size_t)n_pods * b->out_cap);
+    if (ok && m.last_stage() && !b->batched && n_pods > 1) ok = al((void**)&b->logits_own, 4 * (size_t)n_pods * m.V);
+    if (ok && b->batched && p0->attn_part) ok = al((void**)&b->attn_part, 4 * (size_t)n_pods * m.H * ((m.ctx + ATT_TC - 1) / ATT_TC) * (m.hd + 2));
+    if (ok) {
+        std::vector<BatchRow> hr(n_pods);
+        for (uint32_t i = 0; i < n_pods; ++i) hr[i] = BatchRow{b->pods[i]->md.kc, b->pods[i]->md.vc, 0u, 0u};
+        ok = hipMemcpy(b->rows_dev, hr.data(), sizeof(BatchRow) * n_pods, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); batch_free(b); LH_FAIL(ctx, LH_ENOMEM, "lh_batch_create: device allocation failed"); }
+    lh_batch* h = new lh_batch();
+    h->b = b;
+    *out = h;
+    return LH_OK;
+}
+
+void lh_batch_destroy(lh_batch* h) {
+    if (!h) return;
+    batch_free(h->b);
+    delete h;
+}
+
+uint32_t lh_batch_rows(const lh_batch* h) { return h ? h->b->B : 0; }
+int lh_batch_batched(const lh_batch* h) { return h && h->b->batched ? 1 : 0; }
+uint32_t* lh_batch_tokens_dev(lh_batch* h) { return h ? h->b->tok_dev : nullptr; }
+uint32_t* lh_batch_ids_dev(lh_batch* h) { return h ? h->b->ids_dev : nullptr; }
+
+int lh_batch_read_ids(lh_batch* h, uint32_t* ids_host) {
+    if (!h || !ids_host) return LH_EINVAL;
+    lh_ctx* ctx = h->b->ctx;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipMemcpyAsync(ids_host, h->b->ids_dev, (size_t)h->b->B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LH_OK;
+}
+
+int lh_batch_set(lh_batch* h, const uint32_t* tokens, const uint32_t* past) {
+    if (!h || !past) return LH_EINVAL;
+    LH_HIP(h->b->ctx, hipSetDevice(h->b->ctx->device));
+    return batch_set(h->b, tokens, past);
+}
+
+int lh_batch_set_sampler(lh_batch* h, const lh_sample_params* sp, uint32_t ring_size, const uint32_t* const* ring_init, const uint32_t* n_init) {
+    if (!h) return LH_EINVAL;
+    Batch* b = h->b;
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!sp) { b->sampling = false; return LH_OK; }   // back to greedy ticks
+    if (!m.last_stage()) { b->sampling = false; return LH_OK; }   // only the last stage samples; the other stages' ticks are the same either way
+    int rc;
+    if ((rc = sample_check(ctx, sp, m.V))) return rc;
+    if (ring_size == 0) LH_FAIL(ctx, LH_EINVAL, "lh_batch_set_sampler: the lastNTokens ring needs at least one slot (the reference uses CtxSize, server.go:127)");
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!b->ss_dev) LH_HIP(ctx, hipMalloc((void**)&b->ss_dev, sizeof(SampleState) * b->B));
+    if (ring_size > b->ring_cap) {
+        if (b->ring_dev) LH_HIP(ctx, hipFree(b->ring_dev));
+        b->ring_dev = nullptr; b->ring_cap = 0;
+        LH_HIP(ctx, hipMalloc((void**)&b->ring_dev, (size_t)b->B * ring_size * 4));
+        b->ring_cap = ring_size;
+        batch_drop_graph(b);
+    }
+    if ((sp->top_k <= 64) != (b->smp_topk <= 64)) batch_drop_graph(b);   // the captured tick holds the kernel variant
+    b->smp_topk = sp->top_k;
+    // ring: ring_size zeros, then the ids seen so far (appendToken, server.go:129-138, 193-197)
+    std::vector<uint32_t> ring((size_t)b->B * b->ring_cap, 0u);
+    std::vector<SampleState> st(b->B);
+    for (uint32_t i = 0; i < b->B; ++i) {
+        const uint32_t ni = (ring_init && n_init) ? n_init[i] : 0;
+        for (uint32_t j = 0; j < ni; ++j) ring[(size_t)i * b->ring_cap + j % ring_size] = ring_init[i][j];
+        st[i] = SampleState{sp->top_k, sp->top_p, sp->temp, sp->repeat_penalty, sp->seed, 0, ring_size, ni};   // every row = a solo run with this seed
+    }
+    LH_HIP(ctx, hipMemcpy(b->ring_dev, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
+    LH_HIP(ctx, hipMemcpy(b->ss_dev, st.data(), sizeof(SampleState) * b->B, hipMemcpyHostToDevice));
+    LH_HIP(ctx, hipMemset(b->sp_dev, 0, sizeof(StepParams) * b->B));   // .step = index into the rows' output lists
+    b->sampling = true;
+    return LH_OK;
+}
+
+int lh_batch_prompt(lh_batch* h, const uint32_t* const* prompts, const uint32_t* n_prompt, const float* x_in_dev, float* x_out_dev) {
+    if (!h || !n_prompt) return LH_EINVAL;
+    Batch* b = h->b;
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (m.first_stage() && !prompts) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: the first stage needs the prompts");
+    if (!m.first_stage() && !x_in_dev) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: later stage needs the residual stream");
+    if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: non-final stage needs an output buffer");
+    uint32_t past[64];
+    for (uint32_t i = 0; i < b->B; ++i) {   // everything is checked before anything runs
+        if (!n_prompt[i] || n_prompt[i] >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: row %u: prompt of %u tokens outside 1..%u", i, n_prompt[i], m.ctx - 1);
+        if (m.first_stage()) {
+            if (!prompts[i]) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: row %u has no prompt", i);
+            for (uint32_t j = 0; j < n_prompt[i]; ++j)
+                if (prompts[i][j] >= m.V) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: row %u: token id %u outside the vocabulary of %u", i, prompts[i][j], m.V);
+        }
+        past[i] = n_prompt[i];
+    }
+    int rc;
+    LH_HIP(ctx, hipMemsetAsync(b->sp_dev, 0, sizeof(StepParams) * b->B, ctx->stream));   // sampling: the prompt's id is entry 0 of the row's output list
+    size_t off = 0;   // rows of the pods, one after the other, in the residual stream buffers
+    for (uint32_t i = 0; i < b->B; ++i) {
+        Plan* p = b->pods[i];
+        const uint32_t n = n_prompt[i];
+        // the prompt as ONE Eval on the row's own plan (server.go:185-192).  (Plan 0 also holds the batch's scratch: it only ever grows, and
+        // the captured tick is re-captured when it did - Plan::scratch_gen.)
+        if ((rc = plan_eval(p, m.first_stage() ? prompts[i] : nullptr, x_in_dev ? x_in_dev + off * m.d : nullptr, x_out_dev ? x_out_dev + off * m.d : nullptr, n, 0, true))) return rc;
+        if (m.last_stage()) {
+            const float* last_row = n == 1 ? p->logits : p->logits + (size_t)(n - 1) * m.V;
+            if (b->sampling) {
+                if ((rc = sample_launch(ctx, last_row, m.V, b->ss_dev + i, b->ring_dev + (size_t)i * b->ring_cap, b->sp_dev + i, b->out_dev + (size_t)i * b->out_cap, b->ids_dev + i,
+                                        nullptr, nullptr, nullptr, 1, b->smp_topk)))
+                    return rc;
+            } else {
+                hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, last_row, m.V, (StepParams*)nullptr, b->out_dev + (size_t)i * b->out_cap, b->ids_dev + i, 0);
+                LH_HIP(ctx, hipMemcpyAsync(b->out_dev + (size_t)i * b->out_cap, b->ids_dev + i, 4, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        off += n;
+    }
+    if ((rc = batch_set(b, nullptr, past, 1))) return rc;   // every row now stands behind its prompt; out[row][0] holds the id the prompt produced
+    if (m.first_stage() && m.last_stage()) LH_HIP(ctx, hipMemcpyAsync(b->tok_dev, b->ids_dev, (size_t)b->B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    LH_HIP(ctx, hipGetLastError());
+    return LH_OK;
+}
+
+int lh_batch_stage(lh_batch* h, const float* x_in_dev, float* x_out_dev, float* logits_dev, uint32_t* ids_dev) {
+    if (!h) return LH_EINVAL;
+    Batch* b = h->b;
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m.first_stage() && !x_in_dev) LH_FAIL(ctx, LH_EINVAL, "lh_batch_stage: later stage needs the residual stream");
+    if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "lh_batch_stage: non-final stage needs an output buffer");
+    int rc;
+    if ((rc = batch_tick(b, x_in_dev, x_out_dev))) return rc;
+    if (m.last_stage() && logits_dev) LH_HIP(ctx, hipMemcpyAsync(logits_dev, b->logits(), (size_t)b->B * m.V * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (m.last_stage() && ids_dev) LH_HIP(ctx, hipMemcpyAsync(ids_dev, b->ids_dev, (size_t)b->B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return LH_OK;
+}
+
+int lh_batch_decode(lh_batch* h, const uint32_t* first_tokens, const uint32_t* past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host) {
+    if (!h || !first_tokens || !past || !n_steps) return LH_EINVAL;
+    Batch* b = h->b;
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_batch_decode needs whole-model pods; use lh_batch_stage on a layer shard");
+    for (uint32_t i = 0; i < b->B; ++i)
+        if ((uint64_t)past[i] + n_steps > m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_decode: row %u: past %u + %u steps exceed the context window of %u", i, past[i], n_steps, m.ctx);
+    int rc;
+    if ((rc = batch_set(b, first_tokens, past))) return rc;
+    for (uint32_t s = 0; s < n_steps; ++s)
+        if ((rc = batch_tick(b, nullptr, nullptr))) return rc;
+    if (out_tokens)
+        LH_HIP(ctx, hipMemcpy2DAsync(out_tokens, (size_t)n_steps * 4, b->out_dev, (size_t)b->out_cap * 4, (size_t)n_steps * 4, b->B, hipMemcpyDeviceToHost, ctx->stream));
+    if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, b->logits(), (size_t)b->B * m.V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LH_OK;
+}
+
 int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t repeats, lh_kernel_time* out, uint32_t cap) {
     if (!m || !out || !repeats) return LH_EINVAL;
     lh_ctx* ctx = m->ctx;
@@ -1636,7 +1805,6 @@ int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t
     LH_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = ensure_out_tokens(p, 1))) return rc;
-    ResidentScope rs(p);
     const float* pin = p->md.first_stage() ? nullptr : p->h;   // stage models: scratch stands in for the received residual
     float* pout = p->md.last_stage() ? nullptr : p->attn;
     ProfSink sink;

@@ -18,6 +18,7 @@
 #include <unordered_set>
 #include "../../include/llamago.h"
 #include "../../include/llamahip.h"
+#include "../../include/llamago_ext.h"
 
 #define MAX_NODES 4096  // ml.go:20
 
@@ -900,6 +901,76 @@ int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_d
         return halt_rc(lh_last_error(c->mlctx->hip));
     return 0;
 }
+// ---- the pods of one GPU in ONE weight pass (lh_batch): contexts of the same model, one KV cache each --------------------------
+// All contexts must have been created on the same ml.Context stream: llama_NewContext makes one lh_ctx per context, so a batch is built
+// over contexts that SHARE one - llamago_NewBatchContexts creates them.
+struct llama_batch {
+    ml_context* mlctx = nullptr;
+    llama_model* model = nullptr;
+    std::vector<ml_tensor*> K, V;
+    std::vector<lh_llama*> pods;
+    lh_batch* b = nullptr;
+    uint32_t ctxSize = 0;
+};
+void llamago_FreeBatch(llama_batch* p) {
+    if (!p) return;
+    if (p->b) lh_batch_destroy(p->b);
+    for (lh_llama* m : p->pods) lh_llama_destroy(m);
+    if (p->mlctx) lh_ctx_sync(p->mlctx->hip);
+    for (ml_tensor* t : p->K) free_tensor(t);
+    for (ml_tensor* t : p->V) free_tensor(t);
+    ml_ReleaseContext(p->mlctx);
+    if (p->model) model_release(p->model);
+    delete p;
+}
+// `pods` llama.Contexts (llama.go:91-103: one KV cache each) over one Model on one stream, bound into an lh_batch
+llama_batch* llamago_NewBatch(llama_model* m, uint32_t ctxSize, uint32_t pods) {
+    g_err.clear();
+    if (!m || !pods) return (llama_batch*)halt("llamago_NewBatch: bad arguments");
+    if (m->layer0 != 0 || m->layer1 != m->hp.layersCount) return (llama_batch*)halt("llamago_NewBatch: layer-sharded model, use llamago_NewPipeline");
+    const uint64_t size = (uint64_t)m->hp.embdSize * m->hp.layersCount * ctxSize;
+    if (size > 0xFFFFFFFFull) return (llama_batch*)halt("[HALT] KV cache exceeds uint32 element count (ml.Tensor.NE is uint32)");
+    llama_batch* p = new llama_batch();
+    p->ctxSize = ctxSize;
+    p->mlctx = ml_NewContext(1, 0, 0);
+    if (!p->mlctx) { delete p; return nullptr; }
+    p->model = m;
+    model_acquire(m);
+    lh_ctx* hip = p->mlctx->hip;
+    for (uint32_t i = 0; i < pods; i++) {
+        ml_tensor* k = new_weight(1, (uint32_t)size, 1);
+        ml_tensor* v = new_weight(1, (uint32_t)size, 1);
+        if (k) p->K.push_back(k);
+        if (v) p->V.push_back(v);
+        if (!k || !v) { llamago_FreeBatch(p); return nullptr; }
+        lh_llama* st = make_stage(m, hip, k->buf, v->buf, ctxSize);
+        if (!st) { llamago_FreeBatch(p); return nullptr; }
+        p->pods.push_back(st);
+    }
+    if (lh_batch_create(hip, p->pods.data(), pods, &p->b)) { g_err = lh_last_error(hip); llamago_FreeBatch(p); return nullptr; }
+    return p;
+}
+int llamago_BatchBatched(llama_batch* p) { return p ? lh_batch_batched(p->b) : 0; }
+// prompts -> for every pod its prompt Eval (server.go:185-192) and then n_predict - 1 decode steps of ALL pods per weight pass, greedy:
+// out[i * n_predict + s] = s-th id of pod i (what llama_GreedyDecode returns for that prompt alone).  logits (optional): [pods][vocab]
+// of the last tick.
+int llamago_BatchGreedyDecode(llama_batch* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t n_predict, uint32_t* out, float* logits) {
+    if (!p || !n_predict) return halt_rc("llamago_BatchGreedyDecode: bad arguments");
+    lh_ctx* hip = p->mlctx->hip;
+    const uint32_t B = (uint32_t)p->pods.size();
+    if (lh_batch_set_sampler(p->b, nullptr, 0, nullptr, nullptr)) return halt_rc(lh_last_error(hip));
+    if (lh_batch_prompt(p->b, prompts, n_prompt, nullptr, nullptr)) return halt_rc(lh_last_error(hip));
+    std::vector<uint32_t> first(B);
+    if (lh_batch_read_ids(p->b, first.data())) return halt_rc(lh_last_error(hip));
+    for (uint32_t i = 0; i < B; i++) out[(size_t)i * n_predict] = first[i];
+    if (n_predict == 1) return 0;
+    std::vector<uint32_t> rest((size_t)B * (n_predict - 1));
+    if (lh_batch_decode(p->b, first.data(), n_prompt, n_predict - 1, rest.data(), logits)) return halt_rc(lh_last_error(hip));
+    for (uint32_t i = 0; i < B; i++)
+        for (uint32_t s2 = 0; s2 + 1 < n_predict; s2++) out[(size_t)i * n_predict + 1 + s2] = rest[(size_t)i * (n_predict - 1) + s2];
+    return 0;
+}
+
 // ---- pods as pipeline streams over a layer-sharded model (server.go:84-106, 151) ----------------------
 // One ml.Context (= one HIP stream) per rank carries every pod's stage and the RCCL p2p; each pod owns its KV cache like a
 // llama.Context does (llama.go:91-98).  All scheduling happens below the C-ABI (lh_pipeline_run).
@@ -932,7 +1003,8 @@ void llamago_FreePipeline(llama_pipeline* p) {
 }
 // id: the 128-byte RCCL unique id from rank 0 (llamago_CommUniqueId), or NULL with hooks (host-staged transport), or both NULL
 // for an unsharded model (world must be 1).
-llama_pipeline* llamago_NewPipeline(llama_model* m, uint32_t ctxSize, uint32_t pods, int rank, int world, const uint8_t* id, const lh_comm_hooks* hooks) {
+// maxRows: rows (streams) one tick evaluates together in one pass over the weights (lh_pipeline_create_grouped); 0 = as many as fit.
+llama_pipeline* llamago_NewPipelineGrouped(llama_model* m, uint32_t ctxSize, uint32_t pods, int rank, int world, const uint8_t* id, const lh_comm_hooks* hooks, uint32_t maxRows) {
     g_err.clear();
     if (!m || !pods || world < 1 || rank < 0 || rank >= world) return (llama_pipeline*)halt("llamago_NewPipeline: bad arguments");
     const uint64_t nlayers = m->layer1 - m->layer0, size = (uint64_t)m->hp.embdSize * nlayers * ctxSize;
@@ -959,8 +1031,19 @@ llama_pipeline* llamago_NewPipeline(llama_model* m, uint32_t ctxSize, uint32_t p
         if (!st) { llamago_FreePipeline(p); return nullptr; }
         p->pods.push_back(st);
     }
-    if (lh_pipeline_create(hip, p->comm, p->pods.data(), pods, &p->pl)) { g_err = lh_last_error(hip); llamago_FreePipeline(p); return nullptr; }
+    if (lh_pipeline_create_grouped(hip, p->comm, p->pods.data(), pods, maxRows, &p->pl)) { g_err = lh_last_error(hip); llamago_FreePipeline(p); return nullptr; }
     return p;
+}
+llama_pipeline* llamago_NewPipeline(llama_model* m, uint32_t ctxSize, uint32_t pods, int rank, int world, const uint8_t* id, const lh_comm_hooks* hooks) {
+    return llamago_NewPipelineGrouped(m, ctxSize, pods, rank, world, id, hooks, 0);
+}
+uint32_t llamago_PipelineGroups(llama_pipeline* p) { return p ? lh_pipeline_groups(p->pl) : 0; }
+// server.Do's loop with SampleTopPTopK after every Eval (server.go:201-204) for every stream of the pipeline; prompts on every rank
+int llamago_PipelineRunSample(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, uint32_t topK, float topP, float temp,
+                              float repeatPenalty, uint64_t seed, uint32_t ringSize) {
+    const lh_sample_params sp = {topK, topP, temp, repeatPenalty, seed};
+    if (lh_pipeline_run_sample(p->pl, prompts, n_prompt, steps, &sp, ringSize)) return halt_rc(lh_last_error(p->mlctx->hip));
+    return 0;
 }
 int llamago_PipelineRun(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps) {
     if (lh_pipeline_run(p->pl, prompts, n_prompt, steps)) return halt_rc(lh_last_error(p->mlctx->hip));

@@ -356,6 +356,20 @@ def _bind_extensions(ml):
     L.llamago_CommUniqueId.argtypes = [C.POINTER(C.c_uint8)]
     L.llamago_NewPipeline.restype = VP
     L.llamago_NewPipeline.argtypes = [VP, c_u32, c_u32, C.c_int, C.c_int, C.POINTER(C.c_uint8), VP]
+    L.llamago_NewPipelineGrouped.restype = VP
+    L.llamago_NewPipelineGrouped.argtypes = [VP, c_u32, c_u32, C.c_int, C.c_int, C.POINTER(C.c_uint8), VP, c_u32]
+    L.llamago_PipelineGroups.restype = c_u32
+    L.llamago_PipelineGroups.argtypes = [VP]
+    L.llamago_PipelineRunSample.restype = C.c_int
+    L.llamago_PipelineRunSample.argtypes = [VP, C.POINTER(c_u32p), c_u32p, c_u32, c_u32, C.c_float, C.c_float, C.c_float, c_u64, c_u32]
+    L.llamago_NewBatch.restype = VP
+    L.llamago_NewBatch.argtypes = [VP, c_u32, c_u32]
+    L.llamago_FreeBatch.restype = None
+    L.llamago_FreeBatch.argtypes = [VP]
+    L.llamago_BatchBatched.restype = C.c_int
+    L.llamago_BatchBatched.argtypes = [VP]
+    L.llamago_BatchGreedyDecode.restype = C.c_int
+    L.llamago_BatchGreedyDecode.argtypes = [VP, C.POINTER(c_u32p), c_u32p, c_u32, c_u32p, c_f32p]
     L.llamago_FreePipeline.restype = None
     L.llamago_FreePipeline.argtypes = [VP]
     L.llamago_PipelineRun.restype = C.c_int
@@ -386,12 +400,33 @@ class Pipeline:
     comm_id: bytes from comm_unique_id (RCCL), or None with `hooks` (an lh_comm_hooks ctypes struct: host-staged
     transport), or both None for world == 1."""
 
-    def __init__(self, model, ctxSize, pods, rank=0, world=1, comm_id=None, hooks=None):
-        self.model, self.ml, self.pods, self.rank, self.world = model, model.ml, pods, rank, world
+    def __init__(self, model, ctxSize, pods, rank=0, world=1, comm_id=None, hooks=None, max_rows=0):
+        """max_rows: streams one tick evaluates together in ONE pass over the rank's weights (0 = as many as fit, 1 = every stream
+        on its own: one weight pass per stream and tick)."""
+        self.model, self.ml, self.pods, self.rank, self.world, self.ctxSize = model, model.ml, pods, rank, world, ctxSize
         idbuf = (C.c_uint8 * COMM_ID_BYTES)(*comm_id) if comm_id is not None else None
         self._hooks = hooks  # keep the callbacks alive
-        h = self.ml.lib.llamago_NewPipeline(model.h, ctxSize, pods, rank, world, idbuf, C.byref(hooks) if hooks is not None else None)
+        h = self.ml.lib.llamago_NewPipelineGrouped(model.h, ctxSize, pods, rank, world, idbuf, C.byref(hooks) if hooks is not None else None, max_rows)
         self.h = self.ml._chk(h, "llamago_NewPipeline")
+        self.groups = int(self.ml.lib.llamago_PipelineGroups(self.h))
+
+    def _prompt_args(self, prompts):
+        assert len(prompts) == self.pods
+        arrs = [(c_u32 * len(p))(*[int(t) for t in p]) for p in prompts]
+        pp = (c_u32p * self.pods)(*[C.cast(a, c_u32p) for a in arrs])
+        nn = (c_u32 * self.pods)(*[len(p) for p in prompts])
+        return arrs, pp, nn
+
+    def run_sample(self, prompts=None, steps=0, topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=0, ringSize=0):
+        """Like run(), with SampleTopPTopK on the last rank after every Eval (server.go:201-204); prompts on EVERY rank."""
+        ring = ringSize or self.ctxSize
+        if prompts is not None:
+            keep, pp, nn = self._prompt_args(prompts)
+            rc = self.ml.lib.llamago_PipelineRunSample(self.h, pp, nn, steps, topK, topP, temp, repeatPenalty, seed, ring)
+        else:
+            rc = self.ml.lib.llamago_PipelineRunSample(self.h, None, None, steps, topK, topP, temp, repeatPenalty, seed, ring)
+        if rc:
+            raise MLError(f"llamago_PipelineRunSample: {self.ml.last_error()}")
 
     def run(self, prompts=None, steps=0):
         """prompts: list of per-stream token lists (every rank passes them: the lengths shape the messages) or None to continue."""
@@ -424,6 +459,34 @@ class Pipeline:
     def free(self):
         if self.h:
             self.ml.lib.llamago_FreePipeline(self.h)
+            self.h = None
+
+
+class Batch:
+    """`pods` llama.Contexts over one Model on ONE GPU whose decode steps share one pass over the weights (lh_batch; the reference
+    runs its pods as independent goroutines, server.go:88-101)."""
+
+    def __init__(self, model, ctxSize, pods):
+        self.model, self.ml, self.pods = model, model.ml, pods
+        self.h = self.ml._chk(self.ml.lib.llamago_NewBatch(model.h, ctxSize, pods), "llamago_NewBatch")
+        self.batched = bool(self.ml.lib.llamago_BatchBatched(self.h))
+
+    def GreedyDecode(self, prompts, n_predict, want_logits=False):
+        """Every pod: its prompt as one Eval, then greedy steps; returns per pod the ids llama_GreedyDecode gives for its prompt alone."""
+        assert len(prompts) == self.pods
+        arrs = [(c_u32 * len(p))(*[int(t) for t in p]) for p in prompts]
+        pp = (c_u32p * self.pods)(*[C.cast(a, c_u32p) for a in arrs])
+        nn = (c_u32 * self.pods)(*[len(p) for p in prompts])
+        out = (c_u32 * (self.pods * n_predict))()
+        lg = np.empty((self.pods, self.model.hp.vocabSize), dtype=np.float32) if want_logits else None
+        if self.ml.lib.llamago_BatchGreedyDecode(self.h, pp, nn, n_predict, out, lg.ctypes.data_as(c_f32p) if want_logits else None):
+            raise MLError(f"llamago_BatchGreedyDecode: {self.ml.last_error()}")
+        ids = [list(out[i * n_predict:(i + 1) * n_predict]) for i in range(self.pods)]
+        return (ids, lg) if want_logits else ids
+
+    def free(self):
+        if self.h:
+            self.ml.lib.llamago_FreeBatch(self.h)
             self.h = None
 
 

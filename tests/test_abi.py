@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:lh|ml|llama)_[A-Za-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:lh|ml|llama|llamago)_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_libllamahip_exports_every_declared_symbol(built):
@@ -23,6 +23,35 @@ def test_libllamahip_exports_every_declared_symbol(built):
     assert not missing, f"libllamahip.so lacks {missing}"
     lib.lh_abi_version.restype = C.c_int
     assert lib.lh_abi_version() == 1
+
+
+def exported(path, prefix_re):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in ("T", "W")]
+    return sorted(n for n in names if re.match(prefix_re, n))
+
+
+def test_headers_and_exports_agree_in_both_directions(built):
+    """Every C symbol the libraries export is declared in a header under include/ and vice versa: the hand-written ctypes / cgo
+    bindings are written against the headers, so an export without a declaration (or a stale declaration) is a drift nobody sees."""
+    import llama_go_amd as pkg
+    hip_decl = set(declared_functions("llamahip.h"))
+    hip_exp = set(exported(pkg.LIBLLAMAHIP, r"lh_"))
+    assert hip_exp == hip_decl, (sorted(hip_exp - hip_decl), sorted(hip_decl - hip_exp))
+    go_decl = set(declared_functions("llamago.h")) | set(n for n in declared_functions("llamago_ext.h") if n.startswith("llamago_"))
+    go_exp = set(exported(pkg.LIBLLAMAGO, r"(ml|llama|llamago)_"))
+    assert go_exp == go_decl, (sorted(go_exp - go_decl), sorted(go_decl - go_exp))
+    # the checker exports the mirror API and the [both] part of the extensions; nothing of it is undeclared
+    orc_exp = set(exported(os.path.join(ROOT, "oracle", "liboracle.so"), r"(ml|llama|llamago)_"))
+    assert orc_exp <= go_decl, sorted(orc_exp - go_decl)
+    src = open(os.path.join(ROOT, "include", "llamago_ext.h")).read()
+    both = set(re.findall(r"\b(llamago_[A-Za-z0-9_]+)\s*\(", src.split("[product] device plumbing")[0].split("#define LLAMAGO_EXT_H")[1]))
+    assert both and both <= orc_exp, sorted(both - orc_exp)
+    # mlapi.py binds only declared names
+    py = open(os.path.join(ROOT, "llama.go_amd", "mlapi.py")).read()
+    bound = set(re.findall(r"(?:lib|L)\.((?:ml|llama|llamago)_[A-Za-z0-9_]+)\b", py)) | set(re.findall(r"sig\(\"((?:ml|llama|llamago)_[A-Za-z0-9_]+)\"", py))
+    assert bound <= go_decl, sorted(bound - go_decl)
 
 
 def test_host_library_and_oracle_export_the_mirror_api(built):

@@ -1,0 +1,218 @@
+"""-m gpu: the pods of one GPU in ONE weight pass (lh_batch), against the oracle.
+
+The reference runs its pods as independent goroutines, each with its own llama.Context over the shared Model
+(pkg/server/server.go:88-101, 151); whatever shares a tick here, every stream must decode exactly what it decodes alone:
+ - token ids of every pod == the checker's greedy ids for that pod's prompt alone (prompts of different lengths, so the rows
+   of a tick stand at different positions of different KV caches), logits of the last tick within 1e-4;
+ - a row's result does not depend on its index in the tick or on its neighbours (bit-identical logits for the same prompt in two
+   rows of one batch);
+ - fp32 and block-int8 weights; row counts on both sides of every kernel boundary (2..16 folded norm, 17..32 / 33..48 / 49..64
+   column tiles with K-split wo / w2); contexts beyond 256 (split-T attention per row); shapes the P-row kernels are not built
+   for fall back to row-by-row evaluation with the same results;
+ - the same through the pipeline scheduler on one rank (groups of streams per tick vs every stream on its own), greedy and with
+   the reference's sampler (server.go:201-204) against the solo device loop and the checker's sampler.
+"""
+import numpy as np
+import pytest
+
+from llama_go_amd.mlapi import SHAPES, Batch, Pipeline, make_hparams
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / np.abs(b).max())
+
+
+def make_prompts(rng, vocab, lengths):
+    return [[int(t) for t in rng.integers(0, vocab, n)] for n in lengths]
+
+
+def oracle_streams(oracle, hp, seed, prompts, n_predict, ctx, int8=False):
+    om = oracle.NewSyntheticModel(hp, seed)
+    if int8:
+        om.QuantizeQ8()
+    ids, last = [], []
+    for pr in prompts:
+        oc = om.NewContext(ctx, 16, False)
+        t, lg = oc.GreedyDecode(pr, n_predict)
+        oc.free()
+        ids.append(list(t))
+        last.append(lg[-1])
+    om.free()
+    return ids, np.stack(last)
+
+
+def margins_ok(lg):
+    s = np.sort(lg, axis=-1)
+    return float(((s[..., -1] - s[..., -2]) / np.abs(lg).max(axis=-1)).min()) > 10 * TOL
+
+
+@pytest.mark.parametrize("shape,layers,int8,lengths", [
+    ("tiny", None, False, [4, 1, 11, 2, 7]),
+    ("tiny", None, True, [4, 1, 11, 2, 7]),
+    ("small", None, False, [3, 9]),                               # two rows: the smallest batch
+    ("small", None, True, [3, 9, 1]),
+    ("small", None, False, list(range(1, 18))),                   # 17 rows: two column tiles, K-split wo / w2
+    ("small", None, True, list(range(1, 18))),
+    ("7B", 2, False, [8, 3, 1, 5, 2, 9, 4, 6]),                   # the 7B launches (8 rows, folded norm)
+    ("7B", 2, True, [8, 3, 1, 5, 2, 9, 4, 6]),
+    ("7B", 2, False, [1 + (i % 5) for i in range(24)]),           # 24 rows
+    ("7B", 2, False, [1 + (i % 7) for i in range(40)]),           # 40 rows: three column tiles
+    ("7B", 2, True, [1 + (i % 7) for i in range(40)]),
+    ("7B", 2, False, [1 + (i % 3) for i in range(64)]),           # 64 rows: four column tiles, half-length chunks
+])
+def test_batched_decode_equals_every_stream_alone(product, oracle, shape, layers, int8, lengths):
+    kw = dict(SHAPES[shape])
+    if layers:
+        kw["layers"] = layers
+    n_predict, ctx = 5, 32
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(len(lengths) * 131 + int(int8))
+    prompts = make_prompts(rng, kw["vocab"], lengths)
+    m = product.NewSyntheticModel(hp, 4321)
+    if int8:
+        m.QuantizeQ8()
+    b = Batch(m, ctx, len(prompts))
+    assert b.batched, "these shapes must take the one-pass route"
+    ids, lg = b.GreedyDecode(prompts, n_predict, want_logits=True)
+    ids2 = b.GreedyDecode(prompts[::-1], n_predict)     # the same batch object again, rows permuted: state fully reset, captured tick reused
+    b.free()
+    m.free()
+    want, wlg = oracle_streams(oracle, hp, 4321, prompts, n_predict, ctx, int8)
+    assert rel(lg, wlg) <= TOL
+    if margins_ok(wlg):
+        assert ids == want
+        assert ids2 == want[::-1]
+
+
+def test_row_results_do_not_depend_on_the_neighbours(product):
+    """The same prompt in rows 1 and 4 of one batch, among different neighbours at different positions: bit-identical logits and ids."""
+    hp = make_hparams(**SHAPES["small"], ctx=48)
+    rng = np.random.default_rng(5)
+    same = [int(t) for t in rng.integers(0, hp.vocabSize, 6)]
+    others = make_prompts(rng, hp.vocabSize, [2, 9, 13, 1])
+    prompts = [others[0], same, others[1], others[2], same, others[3]]
+    m = product.NewSyntheticModel(hp, 99)
+    b = Batch(m, 48, len(prompts))
+    ids, lg = b.GreedyDecode(prompts, 6, want_logits=True)
+    b.free()
+    # ... and in a batch of another size, next to other streams: still the same ids
+    b2 = Batch(m, 48, 3)
+    ids_b2 = b2.GreedyDecode([same, others[2], others[0]], 6)
+    b2.free()
+    m.free()
+    assert ids[1] == ids[4] and np.array_equal(lg[1], lg[4])
+    assert ids_b2[0] == ids[1]
+
+
+def test_batched_decode_long_context_split_attention(product, oracle):
+    """Context > 256: the rows' attention runs split over the keys (k_attention_split per row), rows on both sides of a chunk boundary."""
+    kw = dict(vocab=515, embd=640, mult=32, heads=5, layers=2)   # 5 heads of 128
+    ctx = 320
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(11)
+    prompts = make_prompts(rng, kw["vocab"], [260, 3, 127, 130])
+    m = product.NewSyntheticModel(hp, 8)
+    b = Batch(m, ctx, len(prompts))
+    ids, lg = b.GreedyDecode(prompts, 4, want_logits=True)
+    assert b.batched
+    b.free()
+    m.free()
+    want, wlg = oracle_streams(oracle, hp, 8, prompts, 4, ctx)
+    assert rel(lg, wlg) <= TOL
+    if margins_ok(wlg):
+        assert ids == want
+
+
+@pytest.mark.parametrize("kw", [
+    dict(vocab=300, embd=384, mult=32, heads=6, layers=2),      # head dim 64, ff = 1024: one pass, stream kernels
+    dict(vocab=300, embd=160, mult=32, heads=5, layers=2),      # embd not a multiple of 128: one pass through the tile GEMM + the separate RoPE / append kernel
+    dict(vocab=1000, embd=200, mult=8, heads=25, layers=2),     # embd not a multiple of 32: row by row on the decode kernels
+])
+def test_batched_decode_odd_shapes(product, oracle, kw):
+    ctx = 40
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(kw["embd"])
+    prompts = make_prompts(rng, kw["vocab"], [5, 1, 8])
+    m = product.NewSyntheticModel(hp, 3)
+    b = Batch(m, ctx, len(prompts))
+    ids, lg = b.GreedyDecode(prompts, 5, want_logits=True)
+    b.free()
+    m.free()
+    want, wlg = oracle_streams(oracle, hp, 3, prompts, 5, ctx)
+    assert rel(lg, wlg) <= TOL
+    if margins_ok(wlg):
+        assert ids == want
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_pipeline_groups_streams_into_one_weight_pass(product, oracle, int8):
+    """The scheduler on one rank: 6 streams as ONE group (one weight pass per tick) and as six groups of one (max_rows = 1): the same ids
+    as every stream alone, across two run() calls (state carried over)."""
+    hp = make_hparams(**SHAPES["small"], ctx=40)
+    rng = np.random.default_rng(21)
+    prompts = make_prompts(rng, hp.vocabSize, [5, 1, 8, 2, 12, 3])
+    m = product.NewSyntheticModel(hp, 17)
+    if int8:
+        m.QuantizeQ8()
+    got = {}
+    for mr in (0, 1, 4):
+        pl = Pipeline(m, 40, len(prompts), 0, 1, max_rows=mr)
+        assert pl.groups == {0: 1, 1: 6, 4: 2}[mr]
+        pl.run(prompts, 2)
+        pl.run(None, 3)
+        got[mr] = [pl.tokens(i) for i in range(len(prompts))]
+        pl.free()
+    m.free()
+    want, wlg = oracle_streams(oracle, hp, 17, prompts, 6, 40, int8)
+    if margins_ok(wlg):
+        for mr in got:
+            assert got[mr] == want, mr
+    assert got[0] == got[4]
+
+
+def test_pipeline_samples_like_the_solo_loop(product, oracle):
+    """lh_pipeline_run_sample: SampleTopPTopK after every Eval (server.go:201-204) for every stream of a tick == the solo device loop
+    (llama_SampleDecode) and the checker's sampler with the same seed."""
+    hp = make_hparams(**SHAPES["small"], ctx=40)
+    rng = np.random.default_rng(33)
+    prompts = make_prompts(rng, hp.vocabSize, [5, 2, 9, 1])
+    smp = dict(topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=777)
+    m = product.NewSyntheticModel(hp, 17)
+    pl = Pipeline(m, 40, len(prompts), 0, 1)
+    pl.run_sample(prompts, 3, **smp)
+    pl.run_sample(None, 2, **smp)
+    got = [pl.tokens(i) for i in range(len(prompts))]
+    pl.free()
+    solo = []
+    for pr in prompts:
+        c = m.NewContext(40, 1)
+        solo.append(c.SampleDecode(pr, 6, **smp))
+        c.free()
+    m.free()
+    assert got == solo
+    om = oracle.NewSyntheticModel(hp, 17)
+    for i, pr in enumerate(prompts):
+        oc = om.NewContext(40, 16, False)
+        want = oc.SampleDecode(pr, 6, **smp)
+        oc.free()
+        assert got[i] == want, i
+    om.free()
+
+
+def test_batch_argument_errors(product):
+    from llama_go_amd.mlapi import MLError
+    hp = make_hparams(**SHAPES["tiny"], ctx=16)
+    m = product.NewSyntheticModel(hp, 5)
+    with pytest.raises(MLError):
+        Batch(m, 16, 65)                       # more rows than one pass takes
+    b = Batch(m, 16, 2)
+    with pytest.raises(MLError):
+        b.GreedyDecode([[1, 2], [9999]], 2)    # token id outside the vocabulary: nothing runs
+    with pytest.raises(MLError):
+        b.GreedyDecode([[1, 2], [3]], 30)      # leaves the context window
+    assert b.GreedyDecode([[1, 2], [3]], 3) == b.GreedyDecode([[1, 2], [3]], 3)
+    b.free()
+    m.free()

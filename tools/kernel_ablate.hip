@@ -2,6 +2,7 @@
 // + row mapping vs + RMSNorm prologue vs + fused epilogue.  Not product code.  Cycles through a 6 GiB weight pool.
 #include "../llama.go_amd/csrc/kernels_llama.h"
 #include "../llama.go_amd/csrc/kernels_q8.h"
+#include "legacy_kernels.h"   // k_gemv, k_gemv_q8: the round-1 kernels the ablations compare against
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -1,3 +1,5 @@
+// MOVED OUT OF THE PRODUCT in round 3 (was csrc/): the resident-kernel experiment measured a tie with the per-layer kernels and produced one
+// unexplained wrong token (profiles/r02b_resident_trace.txt, r02c_resident_trace_again.txt); kept only for tools/persist_probe.hip / resident_probe.hip.
 // csrc/kernels_decode_persist.h — one decode step (llama.Eval with N = 1, pkg/llama/llama.go:246-384) as ONE resident kernel:
 // a workgroup per CU walks  qkv_rope | attention | wo_resid | w1w3_silu | w2_resid  for every layer and the lm_head, with a grid
 // barrier between the phases (csrc/kernels_persist.h).  Against the five-launches-per-layer plan it removes

@@ -1,3 +1,5 @@
+// MOVED OUT OF THE PRODUCT in round 3 (was csrc/): the resident-kernel experiment measured a tie with the per-layer kernels and produced one
+// unexplained wrong token (profiles/r02b_resident_trace.txt, r02c_resident_trace_again.txt); kept only for tools/persist_probe.hip / resident_probe.hip.
 // csrc/kernels_persist.h — building blocks of the PERSISTENT decode kernel (gfx950): one workgroup per CU stays resident for a
 // whole token and walks the GEMV phases of llama.Eval (pkg/llama/llama.go:246-384) with a grid barrier between them instead of a
 // kernel boundary.
@@ -17,7 +19,7 @@
 //   XM_SCOPED every exchanged word is read / written with agent-scope (sc1) accesses, no cache maintenance
 //   XM_PLAIN  plain accesses, no cache maintenance: for exchange buffers in uncached (MTYPE_UC) or fine-grained memory
 #pragma once
-#include "kernels_llama.h"
+#include "../llama.go_amd/csrc/kernels_llama.h"
 
 namespace lh {
 

@@ -5,7 +5,7 @@
 //   baseline B: k_gemv_sa with the persistent kernel's own shapes (512 threads) -> results must match the persistent kernel BIT FOR BIT
 //   persistent: coherence mode (fences / uncached buffers / scoped accesses) x poll path (vector / scalar) x parked bytes
 // Every spin is time-bounded: a variant that cannot synchronise reports "TIMEOUT", it cannot hang the GPU.
-#include "../llama.go_amd/csrc/kernels_persist.h"
+#include "kernels_persist.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

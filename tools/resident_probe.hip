@@ -4,7 +4,7 @@
 #ifndef PERSIST_TRACE
 #define PERSIST_TRACE
 #endif
-#include "../llama.go_amd/csrc/kernels_decode_persist.h"
+#include "kernels_decode_persist.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
