@@ -260,6 +260,9 @@ int lh_pipeline_create(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32
 int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, uint32_t max_rows_per_tick, lh_pipeline** out);
 void lh_pipeline_destroy(lh_pipeline* pl);
 uint32_t lh_pipeline_groups(const lh_pipeline* pl);
+/* The pure function behind the grouping (no GPU): groups for `pods` streams on `world` ranks with at most max_rows_per_tick (0 = 64)
+ * streams per group; stream p belongs to group p * groups / pods. */
+uint32_t lh_pipeline_group_count(uint32_t pods, uint32_t world, uint32_t max_rows_per_tick);
 /* server.Do for every stream at once, greedy: if n_prompt != NULL, unit 0 evaluates prompts[i][0..n_prompt[i]) at
  * position 0 (prompts is read on rank 0 only; n_prompt on every rank); then `steps` decode units follow, each feeding
  * the argmax of the previous unit.  State (position, next token) persists across calls, so run(prompts, n, W) followed

@@ -270,6 +270,11 @@ static uint32_t group_count(uint32_t pods, uint32_t world, uint32_t max_rows) {
     return G;
 }
 
+uint32_t lh_pipeline_group_count(uint32_t pods, uint32_t world, uint32_t max_rows_per_tick) {
+    if (!pods || !world) return 0;
+    return group_count(pods, world, max_rows_per_tick ? max_rows_per_tick : 64u);
+}
+
 int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, uint32_t max_rows, lh_pipeline** out) {
     if (!ctx || !pods || !n_pods || !out) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: NULL argument");
     *out = nullptr;

@@ -72,22 +72,14 @@ __host__ __device__ inline size_t stream_lds_bytes(int maxt, int nct, int kc) { 
 
 typedef float f4m __attribute__((ext_vector_type(4)));
 
-// STREAM_BUFFER_LOADS=1 (build flag, 0 in the shipped library): the fp32 loader waves of k_stream_mm2 fetch through buffer_load with a
-// uniform resource per register (base = first row of its 16-row tile), a constant lane offset and the chunk offset in an SGPR, so no
-// vector ALU instruction stands in front of a load.  Why: profiles/r02d_stream_traffic_probe.txt - from 17 rows on the launch is not
-// memory-bound; the loads' 64-bit vector address adds wait while the MFMA wave of the same SIMD issues back to back, loading and
-// computing alternate.  An inline-asm probe of the same addressing measured 114.1 -> 103.5 us on w1|w3 at 48 rows.  Written at the end of
-// round 2 with no GPU time left: NOT yet run on hardware - build the checker and the library with -DSTREAM_BUFFER_LOADS=1, run
-// tools/stream_mm_check and the GPU suite, then make it the default.
-#ifndef STREAM_BUFFER_LOADS
-#define STREAM_BUFFER_LOADS 0
-#endif
-#ifndef STREAM_MFMA_PACE
-#define STREAM_MFMA_PACE -1     // >= 0: s_nop <value> behind every MFMA of k_stream_mm2's compute waves (experiment, see there); -1 = none (shipped)
-#endif
-#ifndef STREAM_LOADER_SLEEP
-#define STREAM_LOADER_SLEEP 0   // s_sleep argument (units of 64 clocks) of the loader waves behind every chunk barrier; 0 = none (shipped)
-#endif
+// The fp32 loader waves of k_stream_mm2 fetch through buffer_load from two column tiles on (n > 16): a uniform resource per register
+// (base = first row of its 16-row tile), a constant lane offset and the chunk offset in an SGPR, so no vector ALU instruction stands in
+// front of a load.  Why: profiles/r02d_stream_traffic_probe.txt - from 17 rows on the launch is not memory-bound; the loads' 64-bit vector
+// address adds wait while the MFMA wave of the same SIMD issues back to back, loading and computing alternate.  Measured round 3
+// (profiles/r03_stream_buffer_loads.txt, w1|w3 / wq|wk|wv of 7B): 32 rows 88.6 -> 79.2 / 47.6 -> 43.8 us, 48 rows 121.3 -> 105.0 / 64.0 -> 58.8,
+// 64 rows 143.3 -> 130.2 / 79.5 -> 73.7; with ONE column tile (<= 16 rows, HBM-bound) it measured 2-3 % slower and stays on global loads.
+// Tried with it and dropped (same file): pacing the MFMA waves with s_nop (only slower from 32 rows on; +3 % at 16 rows on w1|w3, nothing
+// on wq|wk|wv) and letting the loader waves sleep behind the chunk barrier (no consistent gain).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const void* base) {
     // raw buffer (stride 0), no range limit in practice, 32-bit data format (gfx9 resource word 3)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -488,9 +480,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             const uint64_t base = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
             wp[i] = (const float*)base + (size_t)row * a.K + kbase + seg * 4;
         }
-        // STREAM_BUFFER_LOADS: all lanes of register i sit in ONE tile (a pass of the loader covers RPP <= 16 rows and 16 is a multiple
+        // buffer loads: all lanes of register i sit in ONE tile (a pass of the loader covers RPP <= 16 rows and 16 is a multiple
         // of RPP), so the tile's first row is a uniform base; the lane keeps (row in tile) * K + its 16-byte segment as a byte offset
-        constexpr bool BUF = STREAM_BUFFER_LOADS != 0;
+        constexpr bool BUF = NCT >= 2;
         __amdgpu_buffer_rsrc_t wres[NW], xres = stream_rsrc(a.x + kbase), gres = stream_rsrc((a.gamma ? a.gamma : a.x) + kbase);
         uint32_t wvo[NW], xvo[NX];
         if constexpr (BUF) {
@@ -603,13 +595,6 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 issue(ws[q], xs[q], gs[q], ch + q + NS);
                 ST_STAMP(2);
                 __syncthreads();         // barrier `ch + q`: the image holds the chunk; the compute waves are done with what it held before
-#if STREAM_LOADER_SLEEP > 0
-                // experiment (next round, with STREAM_BUFFER_LOADS): right behind a barrier the MFMA waves' 18 operand reads and the
-                // loaders' 19 image writes per wave land in the CU's LDS queue together (the probe trace shows ~1200 clocks from the
-                // barrier to the 4th MFMA); a loader that has slack (it waits ~3300 clocks at the barrier once its loads issue freely)
-                // can let the reads go first
-                __builtin_amdgcn_s_sleep(STREAM_LOADER_SLEEP);
-#endif
                 ST_STAMP(3);
             }
         }
@@ -662,18 +647,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                         for (int t = 0; t < MAXT; ++t)
 #pragma unroll
                             for (int c = 0; c < NCT; ++c)
-                            {
                                 acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
-#if STREAM_MFMA_PACE >= 0
-                                // experiment (next round): the MFMA wave idles in s_nop instead of presenting its next MFMA to the issue
-                                // arbiter while the pipe is still busy - next to a wave that always has an MFMA ready the loader wave of the
-                                // SIMD gets one instruction issued per 100-190 clocks, next to a paced one it issues at full speed
-                                // (tools/valu_mfma_probe, profiles/r02d_valu_mfma_probe.txt; s_nop 15 was too long: tune 8..11)
-                                __builtin_amdgcn_sched_barrier(0);
-                                asm volatile("s_nop %0" : : "n"(STREAM_MFMA_PACE));
-                                __builtin_amdgcn_sched_barrier(0);
-#endif
-                            }
             }
         };
 #ifdef STREAM_TRACE

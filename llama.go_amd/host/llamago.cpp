@@ -750,7 +750,7 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
         rc = 0;
     } while (0);
     ml_FreeGraph(graph);
-    if (rc) gc_free_down_to(gc_mark);  // a halted build leaves constructor-made tensors that never reached the graph
+    gc_free_down_to(gc_mark);  // whatever this Eval constructed and the graph did not reach (a halted build, an unused temporary) goes with it: nothing accumulates between the runtime.GC() points of llama.go:423
     g_gc_enabled = save;
     return rc;
 }

@@ -48,6 +48,27 @@ def test_schedule_is_consistent_across_ranks(built):
                 assert act == list(range(act[0], act[-1] + 1))
 
 
+def test_streams_are_dealt_into_groups_that_fill_the_ranks(built):
+    """lh_pipeline_group_count: min(pods, world) groups (every rank busy every tick, one weight pass per group), more when a group
+    would exceed the rows one pass takes; pods = 4 world -> world groups of 4; max_rows = 1 -> every stream on its own."""
+    import ctypes as C
+    import llama_go_amd as pkg
+    lib = C.CDLL(pkg.LIBLLAMAHIP)
+    f = lib.lh_pipeline_group_count
+    f.restype, f.argtypes = C.c_uint32, [C.c_uint32] * 3
+    for world in (1, 2, 4, 8):
+        assert f(4 * world, world, 0) == world
+        assert f(1, world, 0) == 1
+        assert f(3, world, 1) == 3
+    assert f(100, 1, 0) == 2 and f(100, 1, 48) == 3 and f(64, 1, 0) == 1
+    assert f(6, 1, 4) == 2 and f(7, 8, 0) == 7
+    assert f(0, 1, 0) == 0
+    for pods, world, mr in ((32, 8, 0), (100, 1, 48), (6, 1, 4), (7, 3, 2)):
+        G = f(pods, world, mr)
+        sizes = [sum(1 for p in range(pods) if p * G // pods == g) for g in range(G)]
+        assert sum(sizes) == pods and min(sizes) >= 1 and max(sizes) <= (mr or 64) and max(sizes) - min(sizes) <= 1
+
+
 def test_layer_ranges_partition_the_model():
     for L in (32, 40, 80):
         for world in (1, 2, 4, 8):
