@@ -119,6 +119,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    ncpu_early = usable_cores()   # BEFORE an OpenMP runtime pins this thread (OMP_PROC_BIND below): the affinity mask then shows one core
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before any OpenMP runtime loads (CPU baseline threads)
     os.environ.setdefault("OMP_PROC_BIND", "close")      # pinned threads: the CPU figure swung 4.9 -> 8.6 tok/s box to box with migrating ones
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -235,29 +236,18 @@ def main():
                 traffic, traffic_src = pmc["bytes_per_launch"].get(dom["name"]), pmc["source"]
         except Exception:
             pass
-        # what this box's HBM actually moves: a 2 GiB device-to-device copy (read + write bytes / time), measured live - the nominal 8 TB/s
-        # is not reachable by any access pattern (MI355X_MICROARCH.md: ~6.3 TB/s copy ceiling); SURVEY 8d asks for both yardsticks
+        # what this box's HBM delivers to a kernel that only reads (lh_hbm_read_probe: the weight stream's access pattern, no arithmetic),
+        # measured live: the nominal 8 TB/s is not reachable by any access pattern; SURVEY 8d asks for both yardsticks
         meas = None
         try:
-            src_t = torch.empty(1 << 29, dtype=torch.float32, device="cuda")
-            dst_t = torch.empty_like(src_t)
-            dst_t.copy_(src_t)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                dst_t.copy_(src_t)
-            e1.record()
-            torch.cuda.synchronize()
-            meas = 5 * 2 * src_t.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del src_t, dst_t
-            torch.cuda.empty_cache()
+            from llama_go_amd.mlapi import hbm_read_probe
+            meas = hbm_read_probe(prod)
         except Exception:
             pass
         result["roofline"] = {
             "bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "measured_copy_GBps": round(meas, 1) if meas else None,
-            "frac_of_measured_copy": round(dom["gbps"] / meas, 4) if meas else None, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "measured_read_stream_GBps": round(meas, 1) if meas else None,
+            "frac_of_measured_stream": round(dom["gbps"] / meas, 4) if meas else None, "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": dom["bytes_per_launch"], "avg_us": round(dom["avg_us"], 2), "avg_us_with_event_pair_per_launch": round(per_pair_us, 2),
             "note": "algorithmic bytes = rows*cols*4 of the weights one launch streams (SURVEY 8d); avg_us = HIP events around the kernel's 32 launches "
                     "of a step, back to back, all weights distinct (agrees with the rocprofv3 kernel trace in profiles/); traffic (PMC) in profiles/",
@@ -265,8 +255,7 @@ def main():
         # ---- CPU baseline + parity on the same inputs (oracle = test infrastructure; only used here as the checker / baseline)
         if not args.no_cpu_baseline:
             orc = MLLib(os.path.join(ROOT, "oracle", "liboracle.so"))
-            ncpu = usable_cores()
-            os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+            ncpu = ncpu_early
             t_gen = time.perf_counter()
             om = orc.NewSyntheticModel(hp, SEED)
             if args.int8:
@@ -457,7 +446,7 @@ def main():
                     orc_q = MLLib(os.path.join(ROOT, "oracle", "liboracle.so"))
                     omq = orc_q.NewSyntheticModel(hp, SEED)
                     omq.QuantizeQ8()
-                    ocq = omq.NewContext(ctx_size, usable_cores(), False)
+                    ocq = omq.NewContext(ctx_size, ncpu_early, False)
                     oq_ids, oq_lg = ocq.GreedyDecode(PROMPT, K + 1)
                     ocq.free()
                     omq.free()

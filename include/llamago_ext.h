@@ -33,6 +33,7 @@ int llamago_QuantizeModelQ8(llama_model* m);
 
 /* ---- [product] device plumbing ---------------------------------------------------------------------------------------- */
 int llamago_DeviceCount(void);                       /* lh_device_count */
+int llamago_HbmReadProbe(uint64_t bytes, uint32_t repeats, float* gbps);   /* lh_hbm_read_probe on the model context's device */
 void llamago_SetStream(void* hip_stream);            /* HIP stream for contexts created from now on (NULL: a private one each) */
 int llamago_Sync(llama_context* c);                  /* waits for the context's stream */
 int llamago_LastGraphFused(ml_context* ctx);         /* 1 if the last ml_GraphCompute ran as the fused LLaMA plan */

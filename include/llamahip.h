@@ -44,6 +44,10 @@ int lh_ctx_create(int device, void* stream, lh_ctx** out);
 void lh_ctx_destroy(lh_ctx* ctx);
 const char* lh_last_error(lh_ctx* ctx);         /* ctx may be NULL: last error of the calling thread */
 int lh_ctx_sync(lh_ctx* ctx);                   /* wait for everything enqueued on the context's stream */
+/* Measurement aid: GB/s of a read-only stream over `bytes` of HBM (16-byte non-temporal loads, eight per lane in flight, one workgroup
+ * per CU: the decode weight stream's access pattern with no arithmetic behind it) = what this box's memory delivers to a kernel that
+ * does nothing else; the yardstick bench.py reports next to the nominal 8 TB/s (SURVEY 8d "vs measured achievable"). */
+int lh_hbm_read_probe(lh_ctx* ctx, uint64_t bytes, uint32_t repeats, float* gbps);
 void* lh_ctx_stream(lh_ctx* ctx);
 
 /* ---- persistent tensors: weights resident after LoadModel (llama.go:975), KV cache of NewContext

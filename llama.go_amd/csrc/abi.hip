@@ -118,7 +118,56 @@ __global__ __launch_bounds__(256) void k_fill_synth(float* __restrict__ dst, uin
 
 using namespace lh;
 
+// Read-only HBM stream (lh_hbm_read_probe): every workgroup walks its own contiguous share with 16-byte non-temporal loads, eight
+// independent loads per lane in flight - the access pattern of the decode weight stream without any arithmetic behind it: what this
+// box's memory system delivers to a kernel that does nothing else (the yardstick next to the nominal 8 TB/s; SURVEY 8d "vs measured").
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void k_read_probe(const probe_f4* __restrict__ src, uint64_t n16, float* __restrict__ sink) {
+    const uint64_t per = (n16 + gridDim.x - 1) / gridDim.x, b0 = (uint64_t)blockIdx.x * per, b1 = b0 + per < n16 ? b0 + per : n16;
+    float acc = 0.f;
+    constexpr int U = 8;
+    for (uint64_t i = b0 + threadIdx.x; i < b1; i += (uint64_t)1024 * U) {
+        probe_f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t j = i + (uint64_t)u * 1024;
+            v[u] = __builtin_nontemporal_load(src + (j < b1 ? j : b0));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u].x + v[u].w;
+    }
+    if (acc == 12345.678f) sink[blockIdx.x] = acc;   // keeps the loads alive; practically never true
+}
+
 extern "C" {
+
+int lh_hbm_read_probe(lh_ctx* ctx, uint64_t bytes, uint32_t repeats, float* gbps) {
+    if (!ctx || !gbps || !repeats || bytes < (1u << 20)) return LH_EINVAL;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    float* buf = nullptr;
+    float* sink = nullptr;
+    LH_HIP(ctx, hipMalloc((void**)&buf, bytes));
+    if (hipMalloc((void**)&sink, 4096 * 4) != hipSuccess) { hipFree(buf); LH_FAIL(ctx, LH_ENOMEM, "lh_hbm_read_probe: allocation failed"); }
+    hipMemsetAsync(buf, 0, bytes, ctx->stream);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const uint32_t grid = (uint32_t)ctx->ds->num_cu;
+    hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(1024), 0, ctx->stream, (const probe_f4*)buf, bytes / 16, sink);
+    hipEventRecord(e0, ctx->stream);
+    for (uint32_t r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(1024), 0, ctx->stream, (const probe_f4*)buf, bytes / 16, sink);
+    hipEventRecord(e1, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(buf);
+    hipFree(sink);
+    if (e != hipSuccess || ms <= 0.f) LH_FAIL(ctx, LH_EHIP, "lh_hbm_read_probe: %s", hipGetErrorString(e));
+    *gbps = (float)((double)(bytes / 16 * 16) * repeats / (ms * 1e-3) / 1e9);
+    return LH_OK;
+}
 
 int lh_abi_version(void) { return LH_ABI_VERSION; }
 

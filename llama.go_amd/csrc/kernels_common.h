@@ -24,7 +24,7 @@ struct BatchRow {
     float* kc;       // this pod's K cache [layers of the stage][ctx][d]
     float* vc;
     uint32_t pos;    // position of the row's token (= keys already cached for its stream)
-    uint32_t pad;
+    uint32_t step;   // ticks since the row was last set: index into the row's output list
 };
 
 // Weights are read exactly once per token and shared by no other CU: stream them with the

@@ -729,21 +729,26 @@ __global__ __launch_bounds__(256) void k_rope_store(const float* __restrict__ qr
 }
 
 // ---- batched decode (lh_batch): bookkeeping of the row table ---------------------------------------------------------------------
-// One thread per row: position and (first stage) token of the next tick, from kernel arguments (<= 64 rows: 2 x 256 B of arguments).
+// The table rows[] and the per-row StepParams sp[] (what the N = 1 decode kernels read when a batch runs row by row) move in lockstep:
+// every kernel that advances one advances the other, so a tick needs no separate synchronisation launch.
+// One thread per row: position, output index and (first stage) token of the next tick, from kernel arguments (<= 64 rows).
 struct BatchSetArgs { uint32_t pos[64]; uint32_t tok[64]; };
-__global__ void k_batch_set(BatchRow* rows, uint32_t* tok, uint32_t n, int set_tok, const BatchSetArgs v, StepParams* sp, uint32_t* step, uint32_t step0) {
+__global__ void k_batch_set(BatchRow* rows, uint32_t* tok, uint32_t n, int set_tok, const BatchSetArgs v, StepParams* sp, uint32_t step0) {
     const uint32_t i = threadIdx.x;
-    if (i == 0) *step = step0;
     if (i >= n) return;
     rows[i].pos = v.pos[i];
+    rows[i].step = step0;
+    if (set_tok) tok[i] = v.tok[i];
+    sp[i].token = set_tok ? v.tok[i] : tok[i];
+    sp[i].past = v.pos[i];
     sp[i].step = step0;
-    if (set_tok && tok) tok[i] = v.tok[i];
+    sp[i].pad = 0;
 }
 // Greedy argmax of every row's logits (strict >, lowest index on ties: SURVEY §8c) -> ids_out[row]; `advance`: the id becomes the row's
-// next token, is appended to the row's output list out[row * out_cap + *step] and the row's position moves on (the resident loop).
-// grid = rows, 1024 threads.  *step is only read here; k_batch_advance (the next launch) moves it on.
+// next token, is appended to the row's output list out[row * out_cap + step] and the row moves on by one position (the resident loop).
+// grid = rows, 1024 threads; a row is touched by its own workgroup only.
 __global__ __launch_bounds__(1024) void k_batch_argmax(const float* __restrict__ logits, uint32_t V, BatchRow* rows, uint32_t* tok, uint32_t* __restrict__ ids_out,
-                                                       uint32_t* __restrict__ out, uint32_t out_cap, const uint32_t* __restrict__ step, int advance) {
+                                                       uint32_t* __restrict__ out, uint32_t out_cap, StepParams* sp, int advance) {
     __shared__ float sv[16];
     __shared__ uint32_t si[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -768,17 +773,31 @@ __global__ __launch_bounds__(1024) void k_batch_argmax(const float* __restrict__
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
         if (ids_out) ids_out[row] = bi;
         if (advance) {
-            if (out && *step < out_cap) out[(size_t)row * out_cap + *step] = bi;
+            const uint32_t st = rows[row].step;
+            if (out && st < out_cap) out[(size_t)row * out_cap + st] = bi;
             tok[row] = bi;
             rows[row].pos += 1;
+            rows[row].step = st + 1;
+            sp[row].token = bi;
+            sp[row].past += 1;
+            sp[row].step = st + 1;
         }
     }
 }
-// every row's position moves on by one (ranks that do not sample: the last rank's argmax does it there); *step += 1 when given
-__global__ void k_batch_advance(BatchRow* rows, uint32_t n, uint32_t* step) {
+// every row moves on by one position (stages that do not produce ids: the last stage's argmax / sampler does it there)
+__global__ void k_batch_advance(BatchRow* rows, StepParams* sp, uint32_t n) {
     const uint32_t i = threadIdx.x;
-    if (i < n && rows) rows[i].pos += 1;
-    if (i == 0 && step) *step += 1;
+    if (i >= n) return;
+    rows[i].pos += 1;
+    rows[i].step += 1;
+    sp[i].past += 1;
+    sp[i].step += 1;
+}
+// after the per-row sampler launches (each advanced its row's StepParams: token, past + 1, step + 1, and appended the id to the row's
+// ring and output list): the row table follows
+__global__ void k_batch_from_sp(BatchRow* rows, uint32_t* tok, uint32_t* ids, const StepParams* sp, uint32_t n) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) { tok[i] = sp[i].token; ids[i] = sp[i].token; rows[i].pos += 1; rows[i].step += 1; }
 }
 
 // silu(a) * b elementwise (prefill FFN gate).

@@ -204,6 +204,25 @@ static bool gemm_dma_ok(const GemmArgs& a) {
     return true;
 }
 
+// Split-K for launches whose tiles do not fill the CUs evenly (prompts of <= 128 tokens are ONE row of tiles): S ranges of the contraction
+// per tile, partial products summed by a second pass.  Cost model in microseconds: rounds of the busiest CU x (slabs per item + ~8 of
+// prologue / epilogue) x the time of one 32-deep slab of a bn x bm tile at the CU's fp32 matrix peak (157.3 TFLOP/s / 256), plus the
+// reduce pass ((S + 1) x output floats through HBM at ~4 TB/s + a launch).  S must divide the slab count and leave >= 16 slabs per item;
+// a split has to win 5 %.  Not only for tiles < #CU: 344 tiles of w1|w3 at 128 rows are two rounds at 67 % occupancy, 688 half-tiles three
+// rounds at 90 %.
+static uint32_t pick_splitk(uint32_t tiles, uint32_t ncu, uint32_t nkf, uint32_t bn, uint32_t bm, uint64_t out_floats, double* cost_us) {
+    const double slab_us = 2.0 * bn * bm * GBK / (157.3e6 / 256.0);
+    double best = (double)((tiles + ncu - 1) / ncu) * (nkf + 8) * slab_us;
+    uint32_t splits = 1;
+    for (uint32_t s2 = 2; s2 <= 32; s2 *= 2) {
+        if (nkf % s2 || nkf / s2 < 16) break;
+        const double c = (double)(((uint64_t)tiles * s2 + ncu - 1) / ncu) * (nkf / s2 + 8) * slab_us + (double)(s2 + 1) * out_floats * 4.0 / 4e6 + 5.0;
+        if (c < best * 0.95) { best = c; splits = s2; }
+    }
+    if (cost_us) *cost_us = best;
+    return splits;
+}
+
 template <int WN, int WM, int TN, int TM>
 static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32_t batch = 1) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
@@ -224,19 +243,9 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
         if (g_prepare_only) return 0;
         a.batch = batch;
         const uint32_t ncu = (uint32_t)ctx->ds->num_cu;
-        // Split-K for launches with few tiles (prompts of <= 128 tokens are ONE row of tiles): S ranges of the contraction per tile,
-        // partial products summed by a second pass.  Cost in slab times: rounds of the busiest CU x (slabs per item + ~8 of
-        // prologue/epilogue); S must divide the slab count and leave >= 16 slabs per item.
         uint32_t splits = 1;
-        if (!a.causal && batch == 1 && tiles < ncu && a.M % 4 == 0 && a.ldy % 4 == 0) {
-            const uint32_t nkf = a.K / GBK;
-            double best = (double)((tiles + ncu - 1) / ncu) * (nkf + 8);
-            for (uint32_t s2 = 2; s2 <= 32; s2 *= 2) {
-                if (nkf % s2 || nkf / s2 < 16) break;
-                const double c = (double)(((uint64_t)tiles * s2 + ncu - 1) / ncu) * (nkf / s2 + 8);
-                if (c < best * 0.95) { best = c; splits = s2; }
-            }
-        }
+        if (!a.causal && batch == 1 && a.epi == GEMM_EPI_STORE && a.M % 4 == 0 && a.ldy % 4 == 0)
+            splits = pick_splitk(tiles, ncu, a.K / GBK, BN, BM, (uint64_t)a.groups * a.N * a.M, nullptr);
         if (splits > 1) {
             const uint64_t need = (uint64_t)a.groups * splits * a.N * a.M;
             if (need > ctx->splitk_floats) {
@@ -409,8 +418,10 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // up to 48 rows = three column tiles (six row tiles + three column tiles, two images: 152 KB of LDS).  Four column tiles do not fit next
 // to six row tiles with 128-column chunks (with the row tiles capped at three they measured 11.4-11.9 ms at 33..64 rows, no better than
 // the tile GEMM): 49..64 rows run half-length chunks (KC = 64: 2 x (6 + 4) x 16 x 68 floats = 87 KB), fp32 weights only.
-static constexpr uint32_t STREAM_ROWS_BUILT = 64, STREAM_ROWS_Q8 = 48;
-static int stream_nct(uint32_t n) { return n <= 16 ? 1 : (n <= 32 ? 2 : (n <= 48 ? 3 : 4)); }
+// 65..96 rows (round 3): five / six column tiles on the same half-length chunks (2 x (6 + 6) x 16 x 68 floats = 104 KB; 6 x 6 accumulator tiles =
+// 144 registers of the MFMA waves).  The tile GEMM's single row of 128-row tiles cost 17.6 ms at 65 rows against 10.2 ms at 64.
+static constexpr uint32_t STREAM_ROWS_BUILT = 96, STREAM_ROWS_Q8 = 48, BATCH_ROWS_MAX = 64;
+static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
 
@@ -444,7 +455,7 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
 // runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02c_stream_mm_check.txt.
 template <int MAXT, int NCT>
 static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    if constexpr (NCT == 4) return launch_stream<MAXT, NCT, 64>(ctx, a, name);
+    if constexpr (NCT >= 4) return launch_stream<MAXT, NCT, 64>(ctx, a, name);
     else {
         if (MAXT == 1 && a.K > 4096 && a.K % 256 == 0) return launch_stream<MAXT, NCT, (MAXT == 1 ? 256 : 128)>(ctx, a, name);
         return launch_stream<MAXT, NCT, 128>(ctx, a, name);
@@ -455,7 +466,12 @@ static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (a.n <= 16) return launch_stream_kc<MAXT, 1>(ctx, a, name);
     if (a.n <= 32) return launch_stream_kc<MAXT, 2>(ctx, a, name);
     if (a.n <= 48) return launch_stream_kc<MAXT, 3>(ctx, a, name);
-    return launch_stream_kc<MAXT, 4>(ctx, a, name);
+    if (a.n <= 64) return launch_stream_kc<MAXT, 4>(ctx, a, name);
+    if constexpr (MAXT <= 6) {   // (8 x 5 / 8 x 6 accumulator tiles do not fit the registers: those launches take the tile GEMM)
+        if (a.n <= 80) return launch_stream_kc<MAXT, 5>(ctx, a, name);
+        return launch_stream_kc<MAXT, 6>(ctx, a, name);
+    }
+    return ST_NA;
 }
 static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name, uint32_t maxt) {
     switch (maxt) {
@@ -544,9 +560,13 @@ int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, 
     for (uint32_t g = 0; g < groups; ++g) { a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; }
     if (fused && fused->epi == GEMM_EPI_SILU_MUL) { a.groups = 1; a.M = 2 * M; }   // one matrix of 2 M virtual rows (w1, w3 interleaved)
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, tn = (n + 127) / 128;
+    // tile width and split-K chosen together: slab times of the busiest CU (pick_splitk) x tile width x the narrow tiles' lower matrix-pipe yield
+    const bool may_split = !fused && a.K >= 16 * GBK && gemm_dma_ok(a) && a.M % 4 == 0 && ldy % 4 == 0;
     auto cost = [&](uint32_t bm, double penalty) {
         const uint32_t tiles = tn * ((a.M + bm - 1) / bm) * a.groups;
-        return (double)((tiles + ncu - 1) / ncu) * bm * penalty;
+        double c = (double)((tiles + ncu - 1) / ncu) * (a.K / GBK + 8) * bm;
+        if (may_split) pick_splitk(tiles, ncu, a.K / GBK, 128, bm, (uint64_t)a.groups * n * a.M, &c);
+        return c * penalty;
     };
     if (fused) {
         // only where the epilogue exists: the DMA kernel, whole contraction per tile (no split-K: at least one tile per CU), long prompts
@@ -960,7 +980,7 @@ static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n
 }
 bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     const ModelDesc& m = p->md;
-    if (n < 2 || n > stream_max_rows()) return false;
+    if (n < 2 || n > BATCH_ROWS_MAX) return false;
     if (m.wtype == 7) return q8_stream_ok(p->ctx, m, n, 2);
     return m.d % GBK == 0 && m.F % GBK == 0;
 }
@@ -1259,10 +1279,9 @@ struct Batch {
     BatchRow* rows_dev = nullptr;  // [B]
     uint32_t* tok_dev = nullptr;   // [B] token ids of the next tick (first stage)
     uint32_t* ids_dev = nullptr;   // [B] ids produced by the last tick (last stage)
-    uint32_t* step_dev = nullptr;  // ticks since the last lh_batch_set: index into the rows' output lists
     uint32_t* out_dev = nullptr;   // [B][out_cap] ids produced per row (last stage)
     uint32_t out_cap = 0;
-    StepParams* sp_dev = nullptr;  // [B] row-by-row mode: the rows' step parameters (mirrors of rows / tok)
+    StepParams* sp_dev = nullptr;  // [B] the rows' step parameters, in lockstep with rows_dev (what the N = 1 kernels and the sampler read)
     float* logits_own = nullptr;   // [B][V] row-by-row mode with B > 1 (last stage)
     float* attn_part = nullptr;    // batched, ctx > 256: split-T attention partials for B rows
     // sampling ticks (lh_batch_set_sampler): per-row sampler state + lastNTokens ring
@@ -1282,16 +1301,6 @@ struct Batch {
     float* logits() const { return batched || B == 1 ? pods[0]->logits : logits_own; }
 };
 
-__global__ void k_batch_sync_sp(const BatchRow* rows, const uint32_t* tok, StepParams* sp, uint32_t n) {
-    const uint32_t i = threadIdx.x;
-    if (i < n) { sp[i].token = tok[i]; sp[i].past = rows[i].pos; }
-}
-// after the per-row sampler launches: the sampled id (already appended to the row's ring and output list) becomes the row's next token
-__global__ void k_batch_from_sp(BatchRow* rows, uint32_t* tok, uint32_t* ids, const StepParams* sp, uint32_t n) {
-    const uint32_t i = threadIdx.x;
-    if (i < n) { tok[i] = sp[i].token; ids[i] = sp[i].token; rows[i].pos += 1; }
-}
-
 static void batch_drop_graph(Batch* b) {
     if (b->exec) { hipGraphExecDestroy(b->exec); b->exec = nullptr; }
     if (b->graph) { hipGraphDestroy(b->graph); b->graph = nullptr; }
@@ -1308,7 +1317,6 @@ static int batch_enqueue_tick(Batch* b, const float* x_in, float* x_out) {
         BatchCtx bc = {b->rows_dev, b->tok_dev, b->attn_part};
         if ((rc = plan_eval(p0, nullptr, x_in, x_out, B, 0, false, &bc))) return rc;
     } else {
-        hipLaunchKernelGGL(k_batch_sync_sp, dim3(1), dim3(64), 0, ctx->stream, (const BatchRow*)b->rows_dev, (const uint32_t*)b->tok_dev, b->sp_dev, B);
         for (uint32_t i = 0; i < B; ++i) {
             Plan* p = b->pods[i];
             if ((rc = enqueue_decode(p, b->sp_dev + i, x_in ? x_in + (size_t)i * m.d : nullptr, x_out ? x_out + (size_t)i * m.d : nullptr, 0, nullptr, b->tok_dev + i))) return rc;
@@ -1317,19 +1325,16 @@ static int batch_enqueue_tick(Batch* b, const float* x_in, float* x_out) {
     }
     if (m.last_stage() && b->sampling) {
         // SampleTopPTopK per row (llama.go:455-707) on the row's own ring / draw counter; the rows' step parameters carry the output index
-        hipLaunchKernelGGL(k_batch_sync_sp, dim3(1), dim3(64), 0, ctx->stream, (const BatchRow*)b->rows_dev, (const uint32_t*)b->tok_dev, b->sp_dev, B);
         for (uint32_t i = 0; i < B; ++i)
             if ((rc = sample_launch(ctx, b->logits() + (size_t)i * m.V, m.V, b->ss_dev + i, b->ring_dev + (size_t)i * b->ring_cap, b->sp_dev + i, b->out_dev + (size_t)i * b->out_cap,
                                     nullptr, nullptr, nullptr, nullptr, 1, b->smp_topk)))
                 return rc;
         hipLaunchKernelGGL(k_batch_from_sp, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->ids_dev, (const StepParams*)b->sp_dev, B);
-        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, (BatchRow*)nullptr, B, b->step_dev);
     } else if (m.last_stage()) {
         hipLaunchKernelGGL(k_batch_argmax, dim3(B), dim3(1024), 0, ctx->stream, (const float*)b->logits(), m.V, b->rows_dev, b->tok_dev, b->ids_dev, b->out_dev, b->out_cap,
-                           (const uint32_t*)b->step_dev, 1);
-        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, (BatchRow*)nullptr, B, b->step_dev);
+                           b->sp_dev, 1);
     } else {
-        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, B, b->step_dev);
+        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, B);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -1365,7 +1370,7 @@ static void batch_free(Batch* b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     batch_drop_graph(b);
-    void* bufs[] = {b->rows_dev, b->tok_dev, b->ids_dev, b->step_dev, b->out_dev, b->sp_dev, b->logits_own, b->attn_part, b->ss_dev, b->ring_dev};
+    void* bufs[] = {b->rows_dev, b->tok_dev, b->ids_dev, b->out_dev, b->sp_dev, b->logits_own, b->attn_part, b->ss_dev, b->ring_dev};
     for (void* q : bufs) if (q) hipFree(q);
     delete b;
 }
@@ -1381,7 +1386,7 @@ static int batch_set(Batch* b, const uint32_t* tokens, const uint32_t* past, uin
         v.pos[i] = past[i];
         v.tok[i] = tokens ? tokens[i] : 0;
     }
-    hipLaunchKernelGGL(k_batch_set, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->B, tokens ? 1 : 0, v, b->sp_dev, b->step_dev, step0);
+    hipLaunchKernelGGL(k_batch_set, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->B, tokens ? 1 : 0, v, b->sp_dev, step0);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1637,7 +1642,7 @@ int lh_batch_create(lh_ctx* ctx, lh_llama* const* pods, uint32_t n_pods, lh_batc
     b->out_cap = m.ctx + 1;
     auto al = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, bytes) == hipSuccess && hipMemsetAsync(*ptr, 0, bytes, ctx->stream) == hipSuccess; };
     bool ok = al((void**)&b->rows_dev, sizeof(BatchRow) * n_pods) && al((void**)&b->tok_dev, 4 * (size_t)n_pods) && al((void**)&b->ids_dev, 4 * (size_t)n_pods) &&
-              al((void**)&b->step_dev, 4) && al((void**)&b->sp_dev, sizeof(StepParams) * n_pods);
+              al((void**)&b->sp_dev, sizeof(StepParams) * n_pods);
     if (ok && m.last_stage()) ok = al((void**)&b->out_dev, 4 * (size_t)n_pods * b->out_cap);
     if (ok && m.last_stage() && !b->batched && n_pods > 1) ok = al((void**)&b->logits_own, 4 * (size_t)n_pods * m.V);
     if (ok && b->batched && p0->attn_part) ok = al((void**)&b->attn_part, 4 * (size_t)n_pods * m.H * ((m.ctx + ATT_TC - 1) / ATT_TC) * (m.hd + 2));
@@ -1757,8 +1762,8 @@ int lh_batch_prompt(lh_batch* h, const uint32_t* const* prompts, const uint32_t*
         }
         off += n;
     }
-    if ((rc = batch_set(b, nullptr, past, 1))) return rc;   // every row now stands behind its prompt; out[row][0] holds the id the prompt produced
     if (m.first_stage() && m.last_stage()) LH_HIP(ctx, hipMemcpyAsync(b->tok_dev, b->ids_dev, (size_t)b->B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = batch_set(b, nullptr, past, 1))) return rc;   // every row now stands behind its prompt; out[row][0] holds the id the prompt produced
     LH_HIP(ctx, hipGetLastError());
     return LH_OK;
 }

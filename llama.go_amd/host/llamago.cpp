@@ -339,6 +339,12 @@ int llamago_GraphComputeNoFusion(ml_context* ctx, ml_graph* g) { return graph_co
 int llamago_LastGraphFused(ml_context* ctx) { return ctx && ctx->hip ? lh_last_graph_fused(ctx->hip) : 0; }
 void llamago_SetStream(void* hip_stream) { g_stream_for_new_contexts = hip_stream; }
 int llamago_DeviceCount(void) { return lh_device_count(); }
+int llamago_HbmReadProbe(uint64_t bytes, uint32_t repeats, float* gbps) {
+    lh_ctx* h = model_ctx();
+    if (!h) return 1;
+    if (lh_hbm_read_probe(h, bytes, repeats, gbps)) return halt_rc(lh_last_error(h));
+    return 0;
+}
 
 }  // extern "C"
 

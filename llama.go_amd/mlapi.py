@@ -348,6 +348,8 @@ def _bind_extensions(ml):
     L.llamago_SetStream.restype = None
     L.llamago_SetStream.argtypes = [VP]
     L.llamago_DeviceCount.restype = C.c_int
+    L.llamago_HbmReadProbe.restype = C.c_int
+    L.llamago_HbmReadProbe.argtypes = [c_u64, c_u32, c_f32p]
     L.llamago_LastGraphFused.restype = C.c_int
     L.llamago_LastGraphFused.argtypes = [VP]
     L.llamago_GraphComputeNoFusion.restype = C.c_int
@@ -488,6 +490,14 @@ class Batch:
         if self.h:
             self.ml.lib.llamago_FreeBatch(self.h)
             self.h = None
+
+
+def hbm_read_probe(ml, nbytes=4 << 30, repeats=4):
+    """GB/s of a bare read-only HBM stream on this box (lh_hbm_read_probe)."""
+    g = C.c_float(0)
+    if ml.lib.llamago_HbmReadProbe(nbytes, repeats, C.byref(g)):
+        raise MLError(f"llamago_HbmReadProbe: {ml.last_error()}")
+    return float(g.value)
 
 
 def decode_greedy_resident(ctx, first_token, past, n_steps, want_logits=False):

@@ -238,7 +238,7 @@ def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     assert greedy_margin(lg_o) > 10 * TOL, "test seed has a near-tie; pick another"
 
 
-@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64, 65, 100])
+@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64, 65, 66, 80, 81, 96, 97, 100, 127, 128, 129])
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
     """One Eval of N tokens: 2..64 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
     append / SiLU fused into its epilogues; one to four 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
@@ -446,14 +446,15 @@ def test_7b_shape_slice_matches_oracle(product, oracle, layers):
     assert toks_h == toks_o
 
 
-@pytest.mark.parametrize("n_prompt", [12, 24, 40, 56])
+@pytest.mark.parametrize("n_prompt", [12, 24, 40, 56, 72, 90])
 def test_7b_shape_slice_short_prompts_match_oracle(product, oracle, n_prompt):
     """The 7B layer shape at the prompt lengths where the stream kernel changes its launch shape: 12 rows (RMSNorm folded into the
     GEMMs), 24 rows (two column tiles; wo / w2 as K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles),
-    56 rows (four column tiles on half-length K-chunks) - 2 layers, then 2 decode steps on the cache the prompt wrote."""
+    56 rows (four column tiles on half-length K-chunks), 72 / 90 rows (five / six column tiles) - 2 layers, then 2 decode steps on the cache
+    the prompt wrote."""
     rng = np.random.default_rng(100 + n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["7B"]["vocab"], n_prompt)]
-    out = decode_both(product, oracle, "7B", 64, prompt, 3, layers=2, threads=64)
+    out = decode_both(product, oracle, "7B", 64 if n_prompt <= 56 else 128, prompt, 3, layers=2, threads=64)
     toks_h, lg_h = out["hip"]
     toks_o, lg_o = out["orc"]
     assert out["fused"] == 1
