@@ -121,7 +121,9 @@ def main():
 
     ncpu_early = usable_cores()   # BEFORE an OpenMP runtime pins this thread (OMP_PROC_BIND below): the affinity mask then shows one core
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before any OpenMP runtime loads (CPU baseline threads)
-    os.environ.setdefault("OMP_PROC_BIND", "close")      # pinned threads: the CPU figure swung 4.9 -> 8.6 tok/s box to box with migrating ones
+    # pinned threads (the CPU figure swung 4.9 -> 8.6 tok/s box to box with migrating ones), SPREAD over the sockets' cores: 16 neighbouring
+    # cores share a few memory channels and gave 3.3 tok/s, stable but not what unpinned goroutines on an otherwise idle host get
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
     import numpy as np
     import torch  # first: the process then uses ONE HIP runtime (torch's), libllamahip binds to it by SONAME

@@ -43,19 +43,8 @@ struct FlashArgs {
 constexpr int FA_BQ = 64, FA_TH = 256, FA_HD = 128;
 constexpr size_t FA_LDS_BYTES = (size_t)4 * 32 * FA_HD * 4;   // K tiles of the two pairs + V tiles of the two pairs = 64 KiB
 
-// ATTN_MFMA_PACE >= 0 (build flag, -1 in the shipped library): s_nop <value> behind every MFMA.  Two workgroups share a CU so that one's
-// softmax (vector ALU: scale, mask, max, exp, sum, rescale) runs under the other's MFMAs - but next to a wave that always has its next
-// MFMA ready, the other wave of a SIMD gets one vector instruction issued per ~140 clocks (tools/valu_mfma_probe, profiles/
-// r02d_valu_mfma_probe.txt), which is why the matrix pipe sits at 43 % here; a paced MFMA wave lets it issue at full speed.  A 32x32x2
-// MFMA occupies the pipe for 64 clocks: the s_nop length to find is the longest that still keeps them back to back.  NOT yet run.
-#ifndef ATTN_MFMA_PACE
-#define ATTN_MFMA_PACE -1
-#endif
-#if ATTN_MFMA_PACE >= 0
-#define FA_PACE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop %0" : : "n"(ATTN_MFMA_PACE)); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define FA_PACE() do { } while (0)
-#endif
+// (Tried and dropped, round 3: s_nop 2 / 8 / 16 behind every MFMA so that the other workgroup's softmax issues next to them - 0.792 / 0.792 /
+// 0.791 of the fp32 peak on 13B N = 1024 against 0.793 unpaced, profiles/r03_attn_pace.txt.)
 __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_attn_flash(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fa_smem[];
     float* Ksm = fa_smem;                     // [2][32][128], granule g of row r stored at slot g ^ r
@@ -125,10 +114,10 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const f4 kf = *(const f4*)(Kt + (((2 * g + lh2) ^ lj) << 2));
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g].x, s, 0, 0, 0); FA_PACE();
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g].y, s, 0, 0, 0); FA_PACE();
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g].z, s, 0, 0, 0); FA_PACE();
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g].w, s, 0, 0, 0); FA_PACE();
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[g].x, s, 0, 0, 0); 
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[g].y, s, 0, 0, 0); 
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[g].z, s, 0, 0, 0); 
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[g].w, s, 0, 0, 0); 
                 }
             }
             // ---- online softmax on this lane's 16 keys of the tile: key of accumulator entry e = 32 kt + 8 (e / 4) + 4 h + e % 4
@@ -174,10 +163,10 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 for (int e = 0; e < 16; ++e) {
                     const int rr = 8 * (e >> 2) + 4 * lh2 + (e & 3);   // tile row of the key this half-wave supplies in step e
                     const f4 vf = *(const f4*)(Vt + rr * FA_HD);
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, p[e], o[0], 0, 0, 0); FA_PACE();
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, p[e], o[1], 0, 0, 0); FA_PACE();
-                    o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, p[e], o[2], 0, 0, 0); FA_PACE();
-                    o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, p[e], o[3], 0, 0, 0); FA_PACE();
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, p[e], o[0], 0, 0, 0); 
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, p[e], o[1], 0, 0, 0); 
+                    o[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, p[e], o[2], 0, 0, 0); 
+                    o[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, p[e], o[3], 0, 0, 0); 
                 }
             }
             __builtin_amdgcn_s_barrier();                       // every wave is done reading V(st)

@@ -240,12 +240,13 @@ def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
 
 @pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64, 65, 66, 80, 81, 96, 97, 100, 127, 128, 129])
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
-    """One Eval of N tokens: 2..64 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
-    append / SiLU fused into its epilogues; one to four 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
-    (v_mfma_f32_32x32x2_f32) + blocked attention; the next decode steps read the KV cache that prefill wrote."""
+    """One Eval of N tokens: 2..96 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
+    append / SiLU fused into its epilogues; one to six 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
+    (v_mfma_f32_32x32x2_f32, tile width and split-K picked by the cost model) + blocked attention; the next decode steps read the KV
+    cache that prefill wrote."""
     rng = np.random.default_rng(n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n_prompt)]
-    out = decode_both(product, oracle, "small", 128, prompt, 4)
+    out = decode_both(product, oracle, "small", 128 if n_prompt <= 120 else 192, prompt, 4)
     toks_h, lg_h = out["hip"]
     toks_o, lg_o = out["orc"]
     assert out["fused"] == 1

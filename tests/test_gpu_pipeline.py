@@ -78,6 +78,37 @@ def test_single_stream_and_self_spawned_ranks(product):
     assert q2["tokens_stream0"][:5] == q1["tokens_stream0"][:5]
 
 
+@pytest.mark.parametrize("sample", [0, 1])
+def test_pipeline_two_ranks_share_one_gpu_greedy_and_sampled(product, sample):
+    """Two ranks (two layers each) on ONE GPU, five streams as two groups: greedy ids == llama_GreedyDecode of every prompt alone, and with
+    lh_pipeline_run_sample (the sampler on the LAST rank, its ring seeded from the prompts given there) == llama_SampleDecode alone."""
+    import numpy as np
+    from llama_go_amd.mlapi import make_hparams, SHAPES
+    rng = np.random.default_rng(8)
+    prompts = [[int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n)] for n in (5, 1, 9, 3, 2)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "pipeline_worker.py"), "small", "40", "3", str(sample), json.dumps(prompts)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = last_json(r.stdout)
+    assert got["groups"] == 2
+    hp = make_hparams(**SHAPES["small"], ctx=40)
+    m = product.NewSyntheticModel(hp, 17)
+    for i, pr in enumerate(prompts):
+        c = m.NewContext(40, 1)
+        want = c.SampleDecode(pr, 6, topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=777) if sample else c.GreedyDecode(pr, 6, want_logits=False)[0]
+        c.free()
+        assert got["ids"][i] == list(want), (i, got["ids"][i], want)
+    m.free()
+
+
 def test_rccl_transport_world_of_one(product, oracle):
     """lh_comm_unique_id / lh_comm_init / lh_comm_exchange on real RCCL with the one GPU of the box: a world of one rank sends the
     produced token id to itself (grouped ncclSend + ncclRecv on the context's stream).  Streams must equal the checker's greedy ids."""
