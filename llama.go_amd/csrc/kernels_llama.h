@@ -37,41 +37,7 @@ struct GemvArgs {
     uint32_t hd;            // head dim (= rope dims)
     uint32_t d;             // embd
     const StepParams* sp;   // past
-    // Cross-kernel prefetch (k_gemv_sa): the head of what THIS workgroup's successor - workgroup blockIdx.x of the next weight-stream launch,
-    // which the dispatcher places on the same XCD (same grid size, same round-robin) - will read first: pf_bytes (<= 64 KB, 0 = none) from
-    // the first row of its row range of the NEXT launch's matrices (pf_w / pf_M / pf_K / pf_rpm / pf_map as w / M / K / rows_per_mat / MAP
-    // there).  One dword per 128-byte line, temporal, into the XCD's L2 (and its address translations into the TLBs): the next launch's
-    // first requests, which nothing overlaps, then hit on chip.  pf_mode 1: issued at kernel start, 2: behind the last row's requests.
-    const float* pf_w[3];
-    uint32_t pf_M, pf_K, pf_rpm, pf_map, pf_bytes, pf_mode;
 };
-
-// the prefetch requests of one thread (see GemvArgs::pf_*): returns the loaded dwords so that the caller keeps them live to the kernel's end
-template <int TH>
-__device__ __forceinline__ void gemv_prefetch_next(const GemvArgs& a, float (&pf)[2]) {
-    pf[0] = pf[1] = 0.f;
-    const uint32_t np = a.pf_M >> 1;
-    const uint32_t q0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * np) / gridDim.x);
-    const uint64_t rb = (uint64_t)a.pf_K * 4;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t off = ((uint32_t)threadIdx.x + (uint32_t)i * TH) * 128u;
-        if (off < a.pf_bytes) {
-            // byte `off` of the successor's first rows: virtual row q0 + off / row bytes (clamped into the matrix), MAP of the next launch
-            uint32_t v = q0 + (uint32_t)(off / rb);
-            v = v < a.pf_M ? v : a.pf_M - 1;
-            const uint32_t ro = (uint32_t)(off % rb);
-            const char* base;
-            if (a.pf_map == 1) { const uint32_t m = (v >= a.pf_rpm ? 1u : 0u) + (v >= 2u * a.pf_rpm ? 1u : 0u); base = (const char*)a.pf_w[m] + (uint64_t)(v - m * a.pf_rpm) * rb; }
-            else if (a.pf_map == 2) base = (const char*)a.pf_w[v & 1u] + (uint64_t)(v >> 1) * rb;
-            else base = (const char*)a.pf_w[0] + (uint64_t)v * rb;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pf[i]) : "v"(base + ro) : "memory");
-        }
-    }
-}
-// keeps the prefetched dwords' registers reserved until here (the loads are invisible to the compiler's own wait bookkeeping; the
-// hardware waits for every outstanding load before the wave ends, so no explicit wait is needed - and none is wanted)
-__device__ __forceinline__ void gemv_prefetch_keep(const float (&pf)[2]) { asm volatile("" : : "v"(pf[0]), "v"(pf[1]) : "memory"); }
 
 template <int KI, int TH>
 __device__ __forceinline__ void rmsnorm_prologue(f4 (&xr)[KI], const bool (&act)[KI], const f4 (&gr)[KI], uint32_t K, double* sred) {
@@ -229,8 +195,6 @@ __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
 #pragma unroll
         for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((const f4*)(p + loff[j]));
     }
-    float pf[2] = {0.f, 0.f};
-    if (a.pf_bytes && a.pf_mode == 1) gemv_prefetch_next<TH>(a, pf);   // behind this kernel's own first requests
     if (PRO == PRO_RMSNORM) rmsnorm_prologue<KI, TH>(xr, act, gr, a.K, sred);
     // inactive lanes (K not a multiple of 4*TH) multiply whatever they loaded by x = 0
     for (uint32_t r = r0; r < r1; r += U) {
@@ -258,11 +222,9 @@ __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
             for (int u = 0; u < U; ++u)
                 if (r + u < r1) red[(r - r0 + u) * NW + wave] = acc[u];
         }
-        if (a.pf_bytes && a.pf_mode == 2 && r + 2 * U >= r1 && r + U < r1) gemv_prefetch_next<TH>(a, pf);   // last-but-one pass: behind the last rows' requests
     }
     __syncthreads();
     gemv_finish<EPI, NW>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
-    gemv_prefetch_keep(pf);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -833,13 +833,6 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     float* xa = p->xa;
     float* xb = p->xb;
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
-    // cross-kernel prefetch (GemvArgs::pf_*, fp32 weights): every weight-stream launch requests the head of its successor's rows
-    static const int pf_mode = [] { const char* e = getenv("LLAMAHIP_PF"); return e ? atoi(e) : 0; }();
-    static const uint32_t pf_bytes = [] { const char* e = getenv("LLAMAHIP_PF_BYTES"); return e ? (uint32_t)atoi(e) : 32768u; }();
-    auto pf_set = [&](GemvArgs& a, const float* w0, const float* w1, const float* w2, uint32_t M, uint32_t K, uint32_t rpm, uint32_t map) {
-        if (!pf_mode || m.wtype != 0 || !w0) return;
-        a.pf_w[0] = w0; a.pf_w[1] = w1; a.pf_w[2] = w2; a.pf_M = M; a.pf_K = K; a.pf_rpm = rpm; a.pf_map = map; a.pf_bytes = std::min(pf_bytes, 65536u); a.pf_mode = (uint32_t)pf_mode;
-    };
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
@@ -848,7 +841,6 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
             a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.ws[0] = L.s_wq; a.ws[1] = L.s_wk; a.ws[2] = L.s_wv; a.rows_per_mat = m.d; a.M = 3 * m.d; a.K = m.d;
             a.x = x; a.gamma = L.attn_norm; a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot;
             a.rope = rope; a.hd = m.hd; a.d = m.d; a.sp = sp;
-            pf_set(a, L.wo, nullptr, nullptr, m.d, m.d, 0, MAP_SINGLE);   // (the attention launch in between reads no weights)
             if ((rc = gemv<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "gemv_qkv_rope", m.wtype))) return rc;
         }
         {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
@@ -860,13 +852,11 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         {   // wo + residual   (llama.go:336-340)
             GemvArgs a = {};
             a.w[0] = L.wo; a.ws[0] = L.s_wo; a.M = m.d; a.K = m.d; a.x = p->attn; a.resid = x; a.y = xb;
-            pf_set(a, L.w1, L.w3, nullptr, 2 * m.F, m.d, 0, MAP_PAIR);
             if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_wo_resid", m.wtype))) return rc;
         }
         {   // RMSNorm*gamma -> w1|w3 -> silu(w1 h) * (w3 h)   (llama.go:346-361)
             GemvArgs a = {};
             a.w[0] = L.w1; a.w[1] = L.w3; a.ws[0] = L.s_w1; a.ws[1] = L.s_w3; a.M = 2 * m.F; a.K = m.d; a.x = xb; a.gamma = L.ffn_norm; a.y = p->g;
-            pf_set(a, L.w2, nullptr, nullptr, m.d, m.F, 0, MAP_SINGLE);
             if ((rc = gemv<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "gemv_w1w3_silu", m.wtype))) return rc;
         }
         {   // w2 + residual   (llama.go:363-366)
@@ -874,8 +864,6 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
             GemvArgs a = {};
             a.w[0] = L.w2; a.ws[0] = L.s_w2; a.M = m.d; a.K = m.F; a.x = p->g; a.resid = xb;
             a.y = (last && !m.last_stage()) ? x_out : xa;
-            if (!last) { const LayerW& N = m.layers[il + 1]; pf_set(a, N.wq, N.wk, N.wv, 3 * m.d, m.d, m.d, MAP_BLOCK); }
-            else if (m.last_stage()) pf_set(a, m.output, nullptr, nullptr, m.V, m.d, 0, MAP_SINGLE);
             if ((rc = gemv<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "gemv_w2_resid", m.wtype))) return rc;
         }
         x = xa;
@@ -884,7 +872,6 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         {
             GemvArgs a = {};
             a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = m.d; a.x = x; a.gamma = m.norm; a.y = p->logits + logits_row * (size_t)m.V;
-            if (m.first_stage()) { const LayerW& N = m.layers[m.layer0]; pf_set(a, N.wq, N.wk, N.wv, 3 * m.d, m.d, m.d, MAP_BLOCK); }   // the next token starts there
             if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
         }
         if (g_only) {
