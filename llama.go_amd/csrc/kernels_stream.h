@@ -347,7 +347,13 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             c = c < a.n ? c : a.n - 1;
             xp[i] = a.x + (size_t)c * a.ldx + kbase + seg * 4;
         }
-        constexpr int NS = 2;            // register sets = chunks in flight (four measured no better than two for single-tile workgroups)
+#ifndef STREAM_NS
+#define STREAM_NS 2
+#endif
+        // register sets = chunks in flight.  Two everywhere except the single-tile fp32 launches of <= 16 rows (wo, w2: one 16-row tile per CU,
+        // 8 / 16 KB per chunk - too few bytes in flight with two): four there (profiles/r03_stream_sets_in_flight.txt: wo 18.6 -> 17.8 us, w2
+        // 42.8 -> 38.4; with more tiles three are flat and four much slower: 144+ registers of rows in flight).  -DSTREAM_NS=n overrides for probes.
+        constexpr int NS = (STREAM_NS == 2 && !Q8 && MAXT == 1 && NCT == 1) ? 4 : STREAM_NS;
         // gamma chunk: fetched with every set (from x itself when the launch has no norm: the count of loads per set stays a constant)
         const float* gp = (a.gamma ? a.gamma : a.x) + kbase + seg * 4;
         const bool norm = a.gamma != nullptr;
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
                 stash_x(xr, gq, im);
             };
             constexpr int PER_SET = 2 * NQ + NX + 1;
-            static_assert(PER_SET * (NS - 1) < 64, "vmcnt range");
+            static_assert(PER_SET * (NS - 1) < 64 || STREAM_NS != 2, "vmcnt range");   // (experiment builds with more sets in flight only launch the shapes that fit)
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 issue(qs[q], ds[q], xs[q], gs[q], (uint32_t)q);
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             for (; ch + NS <= nch; ch += NS) {
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
-                    wait_vm<PER_SET * (NS - 1)>();
+                    wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
                     ST_STAMP(0);
                     stash(qs[q], ds[q], xs[q], gs[q], (q & 1) ? img + IMG : img);
                     ST_STAMP(1);
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
 #endif
             if (ch < nch) {              // one chunk left (NS = 2), already requested into set 0
-                wait_vm<PER_SET * (NS - 1)>();
+                wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
                 stash(qs[0], ds[0], xs[0], gs[0], img);
                 __syncthreads();
             }
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
             stash_x(xr, gq, im);
         };
         constexpr int PER_SET = NW + NX + 1;
-        static_assert(PER_SET * (NS - 1) < 64, "vmcnt range");
+        static_assert(PER_SET * (NS - 1) < 64 || STREAM_NS != 2, "vmcnt range");   // (experiment builds with more sets in flight only launch the shapes that fit)
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             issue(ws[q], xs[q], gs[q], (uint32_t)q);
@@ -588,9 +594,9 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         for (; ch + NS <= nch; ch += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                wait_vm<PER_SET * (NS - 1)>();
+                wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
                 ST_STAMP(0);
-                stash(ws[q], xs[q], gs[q], (q & 1) ? img + IMG : img);   // chunk ch + q; NS is even, so its image is q & 1
+                stash(ws[q], xs[q], gs[q], ((ch + q) & 1) ? img + IMG : img);   // chunk ch + q lives in image (ch + q) & 1
                 ST_STAMP(1);
                 issue(ws[q], xs[q], gs[q], ch + q + NS);
                 ST_STAMP(2);
@@ -605,10 +611,10 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
 #pragma unroll
         for (int q = 0; q < NS - 1; ++q) {
             if ((uint32_t)q < rem) {
-                if (q == 0) wait_vm<PER_SET * (NS - 1)>();
-                else if (q == 1) wait_vm<PER_SET * (NS > 2 ? NS - 2 : 0)>();
-                else wait_vm<PER_SET * (NS > 3 ? NS - 3 : 0)>();
-                stash(ws[q], xs[q], gs[q], (q & 1) ? img + IMG : img);
+                if (q == 0) wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
+                else if (q == 1) wait_vm<(PER_SET * (NS > 2 ? NS - 2 : 0) < 64 ? PER_SET * (NS > 2 ? NS - 2 : 0) : 63)>();
+                else wait_vm<(PER_SET * (NS > 3 ? NS - 3 : 0) < 64 ? PER_SET * (NS > 3 ? NS - 3 : 0) : 63)>();
+                stash(ws[q], xs[q], gs[q], ((ch + q) & 1) ? img + IMG : img);
                 __syncthreads();
             }
         }

@@ -981,7 +981,9 @@ static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n
 bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     const ModelDesc& m = p->md;
     if (n < 2 || n > BATCH_ROWS_MAX) return false;
-    if (m.wtype == 7) return q8_stream_ok(p->ctx, m, n, 2);
+    // block-int8: from 3 rows (one pass of the dequantising stream kernel costs 4.9 ms on 7B whatever the row count <= 16, a single-row
+    // int8 GEMV step 2.04 ms: two rows are faster one after the other - profiles/r03_pods_one_gpu.jsonl)
+    if (m.wtype == 7) return q8_stream_ok(p->ctx, m, n, 3);
     return m.d % GBK == 0 && m.F % GBK == 0;
 }
 
@@ -1010,8 +1012,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    // block-int8: 3..48 rows on the stream kernel's dequantising loader (a batched Eval: from 2 rows)
-    const bool q8_stream = q8_stream_ok(ctx, m, n, bc ? 2 : 3);
+    // block-int8: 3..48 rows on the stream kernel's dequantising loader
+    const bool q8_stream = q8_stream_ok(ctx, m, n, 3);
     if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
