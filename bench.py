@@ -552,6 +552,8 @@ def main():
         else:
             par["reason"] = "golden ids exist for the full fp32 7B model only"
         result["parity"] = par
+        result["weak_scaling_reference"] = ("`value` counts 4N streams that share a pass over each rank's weights four at a time; the matching ONE-GPU point is "
+                                            "pods_batched['4'] of the N = 1 line (four streams, one 4-row pass per tick), not its single-stream `value`")
         produced = allt[1:]          # ids produced by the decode steps at positions P0.. (the first W of them by the warm-up)
         timed_pos0 = P0 + W
         parallelism = (f"layer-shard pp{R} ({l1 - l0} layers on this rank), {pods} independent greedy stream{'s' if pods > 1 else ''} in flight as {groups} "
