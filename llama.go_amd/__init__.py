@@ -7,7 +7,8 @@ Layout:
   go/          the cgo shim a llama.go maintainer drops into pkg/ml (cannot be compiled here: no Go toolchain)
   mlapi.py     ctypes binding of include/llamago.h (drives the product library; any other library exporting the
                same API can be wrapped by the same class)
-  pipeline.py  layer-shard pipeline schedule over torch.distributed (RCCL send/recv of the residual stream)
+  pipeline.py  ctypes view of the C pipeline scheduler (lh_pipeline_schedule / run_hooks) + a gloo transport hook for CPU and shared-GPU tests;
+               the schedule, the stages and the RCCL send/recv all live below the C-ABI (csrc/comm.hip)
 
 The product path has no CPU fallback: loading fails loudly if the HIP library is missing.
 """

@@ -333,6 +333,17 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
     typedef const f4 __attribute__((address_space(1))) gf4;
     constexpr int KB = KC / 64;
     constexpr int KA0 = (MAXT * NCT >= 4) ? 1 : (MAXT * NCT >= 2 ? 2 : 4), KA = KA0 < KB ? KA0 : KB;
+    // PIPE (round 3; the half-length chunks of four / five column tiles): the MFMA waves run ONE chunk behind the images - while chunk c
+    // multiplies out of registers they read the operands of chunk c + 1 (its image was completed a barrier ago), so no operand read stands
+    // between a barrier and the first MFMA behind it.  The images and the loader waves are unchanged: chunk k is stashed before barrier k;
+    // chunk k's operands are read between barriers k and k + 1 and multiplied between k + 1 and k + 2, which is also when the loader
+    // overwrites its image with chunk k + 2.  Two more barriers per launch.  Measured (profiles/r03_stream_operand_pipeline.txt): with
+    // 64-column chunks (a barrier every 96-120 MFMAs) +2..5 % (w2 pairs at 64 rows 75.4 -> 71.2 us, wq|wk|wv 73.7 -> 71.0, w1|w3 129.5 ->
+    // 127.4); with 128-column chunks -2.7..+1.5 %, i.e. nothing: the reads behind a barrier are NOT what keeps the matrix pipe at 73 %.
+#ifndef STREAM_PIPE
+#define STREAM_PIPE 1                // -DSTREAM_PIPE=0: the round-2 schedule (operands read behind each barrier), for A/B builds of the checker
+#endif
+    constexpr bool PIPE = STREAM_PIPE != 0 && KC == 64 && NCT >= 2 && NCT <= 5;
     f4m acc[KA][MAXT][NCT];
     const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
     if (wave < 4) {
@@ -621,6 +632,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
         wait_vm<0>();                    // the clamped tail loads
         publish_scales();
         }
+        if constexpr (PIPE) { __syncthreads(); __syncthreads(); }   // the MFMA waves' last two periods (operands of the last chunk, its MFMAs)
     } else {
         // ---- compute waves
         const int cw = wave - 4;
@@ -659,11 +671,61 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
 #ifdef STREAM_TRACE
         unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
 #endif
+        if constexpr (PIPE) {
+            constexpr int NO = MAXT + NCT;
+            f4 ops[2][KB][NO];           // [buffer][k-block][A tiles, then B tiles]
+            auto read_ops = [&](f4 (&o)[KB][NO], const float* im) {
+                const float* Wt = im;
+                const float* Xt = im + (size_t)MAXT * 16 * ST_PITCH;
+#pragma unroll
+                for (int h = 0; h < KB; ++h) {
+                    const uint32_t koff = (uint32_t)(KB * cw + h) * 16 + slot * 4;
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) o[h][MAXT + c] = *(const f4*)(Xt + (size_t)(c * 16 + r16) * ST_PITCH + koff);
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) o[h][t] = *(const f4*)(Wt + (size_t)(t * 16 + r16) * ST_PITCH + koff);
+                }
+            };
+            auto mfmas = [&](const f4 (&o)[KB][NO]) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int h = 0; h < KB; ++h)
+#pragma unroll
+                        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                            for (int c = 0; c < NCT; ++c)
+                                acc[h % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[h][t][s], o[h][MAXT + c][s], acc[h % KA][t][c], 0, 0, 0);
+            };
+            __syncthreads();             // barrier 0: image 0 holds chunk 0
+            read_ops(ops[0], img);
+            __syncthreads();             // barrier 1: image 1 holds chunk 1, image 0 may be overwritten
+            for (uint32_t ch = 0; ch < nch; ch += 2) {   // two chunks per trip: the operand buffers swap by name
+                // scheduling fences: the reads are ISSUED in front of the MFMAs they hide behind, and no MFMA drifts across the workgroup
+                // barrier (pure register work: the compiler otherwise moves the barrier up behind the block's first MFMA, and the wait for the
+                // LDS reads that belongs to it with it)
+                if (ch + 1 < nch) read_ops(ops[1], img + IMG);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(ops[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();         // barrier ch + 2
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + 1 < nch) {
+                    if (ch + 2 < nch) read_ops(ops[0], img);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(ops[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();     // barrier ch + 3
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
         for (uint32_t ch = 0; ch < nch; ++ch) {
             __syncthreads();             // barrier `ch`
             ST_STAMP(0);
             compute((ch & 1) ? img + IMG : img);
             ST_STAMP(1);
+        }
         }
 #ifdef STREAM_TRACE
         if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
