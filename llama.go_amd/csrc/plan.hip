@@ -176,7 +176,8 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
         case 3: return launch_gemv<3, 1, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 4: return launch_gemv<4, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 5: return launch_gemv<5, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
-        case 6: return launch_gemv<6, 2, PRO, EPI, MAP>(ctx, a, name, bytes);
+        // (six float4 of x, gamma and two rows each do not fit the 128 registers of a 1024-thread workgroup next to the norm: 20 B of scratch)
+        case 6: return launch_gemv<6, (PRO == PRO_RMSNORM ? 1 : 2), PRO, EPI, MAP>(ctx, a, name, bytes);
         default: LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: K=%u exceeds the supported 24576 columns", name, a.K);
     }
 }
@@ -603,7 +604,8 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
     }
     const uint32_t K4 = K / 4;
     const int ki = (int)((K4 + TH - 1) / TH);
-    const uint32_t NCmax = ki <= 2 ? 8 : 4;
+    // activation columns per pass: what fits the 128 registers of a 1024-thread workgroup without scratch (ISA-checked per instantiation)
+    const uint32_t NCmax = ki <= 2 ? 8 : (ki <= 4 ? 4 : 2);
     for (uint32_t c0 = 0; c0 < n; c0 += NCmax) {
         GemmColsArgs a;
         a.w = w; a.x = x + (size_t)c0 * ldx; a.y = y + (size_t)c0 * ldy; a.resid = resid ? resid + (size_t)c0 * ldy : nullptr;
@@ -613,9 +615,9 @@ int gemm_small_n(lh_ctx* ctx, const float* w, const float* x, float* y, const fl
             case 1: rc = launch_cols<1, 2, 8>(ctx, a, name); break;
             case 2: rc = launch_cols<2, 2, 8>(ctx, a, name); break;
             case 3: rc = launch_cols<3, 2, 4>(ctx, a, name); break;
-            case 4: rc = launch_cols<4, 2, 4>(ctx, a, name); break;
-            case 5: rc = launch_cols<5, 1, 4>(ctx, a, name); break;
-            case 6: rc = launch_cols<6, 1, 4>(ctx, a, name); break;
+            case 4: rc = launch_cols<4, 1, 4>(ctx, a, name); break;
+            case 5: rc = launch_cols<5, 1, 2>(ctx, a, name); break;
+            case 6: rc = launch_cols<6, 1, 2>(ctx, a, name); break;
             default: LH_FAIL(ctx, LH_EUNSUPPORTED, "gemm %s: K=%u exceeds the supported 24576 columns", name, K);
         }
         if (rc) return rc;
@@ -1256,6 +1258,10 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                     if ((rc = gemv<PRO_PLAIN, EPI_STORE, MAP_SINGLE>(ctx, ga, "gemv_lmhead_row", 7))) return rc;
                 }
             }
+        } else if (nr == 1) {   // the one row llama.Eval reads: the decode weight stream (76 us on 7B; the column kernel took 122)
+            GemvArgs ga = {};
+            ga.w[0] = m.output; ga.M = m.V; ga.K = d; ga.x = p->h + (size_t)r0 * d; ga.y = p->logits + (size_t)r0 * m.V;
+            if ((rc = gemv<PRO_PLAIN, EPI_STORE, MAP_SINGLE>(ctx, ga, "gemv_lmhead_row", 0))) return rc;
         } else if ((rc = gemm_small_n(ctx, m.output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_lmhead"))) return rc;
     }
     LH_HIP(ctx, hipGetLastError());
