@@ -593,4 +593,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:   # whatever a rank dies of, it says so on one JSON line and exits non-zero: nobody waits for it
+        import traceback
+        traceback.print_exc()
+        print(json.dumps({"error": f"rank {os.environ.get('RANK', '0')}: {e!r}", "n_gpus": int(os.environ.get("WORLD_SIZE", "1"))}), flush=True)
+        sys.stdout.flush()
+        os._exit(1)

@@ -1,0 +1,162 @@
+// csrc/kernels_rows.h — the decode weight stream for 2..4 activation rows at once (round 3).
+//
+// Why: the pods of a rank advance together in one pass over the weights (lh_batch; the reference runs them as independent goroutines,
+// pkg/server/server.go:88-101), and prompts of 2..4 tokens are one Eval (server.go:185-192).  The 2..16-row launches of k_stream_mm2
+// (kernels_stream.h) stream at 5.2-5.5 TB/s: their K-chunked LDS image makes a load instruction touch 512-byte segments of many rows.
+// With two to four rows the arithmetic still fits the vector ALU next to the stream (4 x rows FMAs per 16-byte load: 13 of a CU's 64
+// lanes per clock at four rows), so this kernel keeps k_gemv_sa's structure (kernels_llama.h) - one fat workgroup per CU, contiguous
+// row blocks, whole weight rows streamed with scalar-addressed non-temporal loads, activations in registers, ONE barrier - and carries
+// NC activation rows through it: NC accumulators per weight row, NC wave reductions, and the same fused prologue / epilogues per
+// activation row (RMSNorm, RoPE + cache append at the row's own position of its own cache, silu * mul, + residual).
+// Per activation row the arithmetic and the summation order are those of k_gemv_sa: a pod decodes bit-identical logits whether it
+// runs alone (k_gemv_sa) or in a tick of two to four (this kernel).
+#pragma once
+#include "kernels_llama.h"
+
+namespace lh {
+
+struct GemvRowsArgs {
+    const float* w[3];      // matrix bases (MAP_BLOCK: [wq, wk, wv]; MAP_PAIR: [w1, w3])
+    uint32_t rows_per_mat;  // MAP_BLOCK
+    uint32_t M, K;          // virtual weight rows, columns
+    const float* x;         // activation rows [n][ldx]
+    const float* gamma;     // PRO_RMSNORM: norm weight [K]
+    float* y;               // EPI_STORE / EPI_RESID / EPI_SILU_MUL: [n][ldy]
+    const float* resid;     // EPI_RESID: [n][ldy]
+    float* q_out;           // EPI_QKV_ROPE: roped Q [n][d]
+    float* k_cache;         //   prompt rows (rows == nullptr): this layer's slot [ctx][d], activation row r at position past + r
+    float* v_cache;
+    const double2* rope;    // [pos][hd / 2] (cos, sin)
+    const BatchRow* rows;   //   rows of different streams: row r at position rows[r].pos of the cache rows[r].kc / .vc + kv_off
+    uint64_t kv_off;
+    uint32_t ldx, ldy, hd, d, past, n;   // n <= NC activation rows
+};
+
+template <int KI, int U, int TH, int NC, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = TH / 64;
+    double* sred = (double*)smem_raw;                       // [NC][NW]
+    float* red = (float*)(smem_raw + NC * NW * 8);          // [weight rows of this workgroup][NC][NW] per-wave partial dot products
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t K4 = a.K >> 2;
+    const uint32_t nwg = gridDim.x;
+    const uint32_t npairs = a.M >> 1;
+    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
+    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    const char *w0 = (const char*)a.w[0], *w1 = (const char*)a.w[1], *w2 = (const char*)a.w[2];
+    const char* xdummy = (const char*)a.x;                  // K floats = exactly one row's extent: any lane offset stays inside it
+    const uint32_t rpm = a.rows_per_mat;
+    const uint64_t row_bytes = (uint64_t)a.K * 4;
+
+    f4 xr[NC][KI];
+    f4 gr[KI];
+    bool act[KI];
+    uint32_t loff[KI];
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+        act[j] = (uint32_t)(tid + j * TH) < K4;
+        loff[j] = act[j] ? (uint32_t)(tid + j * TH) * 16u : 0u;
+        if (PRO == PRO_RMSNORM) gr[j] = act[j] ? ((const f4*)a.gamma)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float* xc = a.x + (size_t)((uint32_t)c < a.n ? c : 0) * a.ldx;   // rows past n: a duplicate of row 0, results never stored
+#pragma unroll
+        for (int j = 0; j < KI; ++j) xr[c][j] = act[j] ? ((const f4*)xc)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    f4 w[U][KI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const char* p = (r0 + u < r1) ? gemv_row_base<MAP>(w0, w1, w2, rpm, r0 + u, row_bytes) : xdummy;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((const f4*)(p + loff[j]));
+    }
+    if (PRO == PRO_RMSNORM) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) rmsnorm_prologue<KI, TH>(xr[c], act, gr, a.K, sred + c * NW);   // k_gemv_sa's norm, row by row (own scratch each)
+    }
+    for (uint32_t r = r0; r < r1; r += U) {
+        float acc[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t nr = r + U + u;
+            const char* p = nr < r1 ? gemv_row_base<MAP>(w0, w1, w2, rpm, nr, row_bytes) : xdummy;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[u][c] = 0.f;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                const f4 q = w[u][j];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {      // per activation row the chain of k_gemv_sa: x, y, z, w of one float4 after the other
+                    float s = acc[u][c];
+                    s = fmaf(q.x, xr[c][j].x, s);
+                    s = fmaf(q.y, xr[c][j].y, s);
+                    s = fmaf(q.z, xr[c][j].z, s);
+                    s = fmaf(q.w, xr[c][j].w, s);
+                    acc[u][c] = s;
+                }
+                w[u][j] = ld_nt((const f4*)(p + loff[j]));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[u][c] = wave_sum(acc[u][c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (r + u < r1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) red[((size_t)(r - r0 + u) * NC + c) * NW + wave] = acc[u][c];
+                }
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: thread `fin` finishes weight row r0 + fin (or the pair r0 + fin, r0 + fin + 1) for every activation row, cross-wave sums
+    // in wave order (bit-reproducible, the order of gemv_finish)
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    if (r0 + fin >= r1) return;
+    const uint32_t v = r0 + fin;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if ((uint32_t)c >= a.n) break;
+        const float* p0 = red + ((size_t)fin * NC + c) * NW;
+        float s0 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) s0 += p0[k];
+        if (EPI == EPI_STORE) {
+            a.y[(size_t)c * a.ldy + v] = s0;
+        } else if (EPI == EPI_RESID) {
+            a.y[(size_t)c * a.ldy + v] = __fadd_rn(s0, a.resid[(size_t)c * a.ldy + v]);   // Add(cur, inp) ml.go:2515-2584
+        } else {
+            const float* p1 = p0 + (size_t)NC * NW;      // the pair's second weight row
+            float s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) s1 += p1[k];
+            if (EPI == EPI_SILU_MUL) {
+                a.y[(size_t)c * a.ldy + (v >> 1)] = __fmul_rn(silu_ref(s0), s1);   // ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+            } else {   // EPI_QKV_ROPE: Rope mode 0 on Q / mode 1 on the new K row (ml.go:2253-2328), K, V appended to the row's cache (llama.go:274-278)
+                const uint32_t d = a.d;
+                const uint32_t pos = a.rows ? a.rows[c].pos : a.past + (uint32_t)c;
+                float* kcb = a.rows ? a.rows[c].kc + a.kv_off : a.k_cache;
+                float* vcb = a.rows ? a.rows[c].vc + a.kv_off : a.v_cache;
+                if (v < 2 * d) {
+                    const uint32_t e = v < d ? v : v - d;
+                    const double2 cs = a.rope[(size_t)pos * (a.hd >> 1) + ((e % a.hd) >> 1)];
+                    float o0, o1;
+                    rope_rotate(s0, s1, cs, &o0, &o1);
+                    float* dst = v < d ? a.q_out + (size_t)c * d + e : kcb + (size_t)pos * d + e;
+                    dst[0] = o0;
+                    dst[1] = o1;
+                } else {
+                    float* dst = vcb + (size_t)pos * d + (v - 2 * d);
+                    dst[0] = s0;
+                    dst[1] = s1;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace lh

@@ -9,6 +9,7 @@
 #include "kernels_attn.h"
 #include "kernels_sample.h"
 #include "kernels_stream.h"
+#include "kernels_rows.h"
 #include <math.h>
 #include <algorithm>
 
@@ -181,6 +182,51 @@ static int gemv_f32(lh_ctx* ctx, const GemvArgs& a, const char* name) {
         default: LH_FAIL(ctx, LH_EUNSUPPORTED, "gemv %s: K=%u exceeds the supported 24576 columns", name, a.K);
     }
 }
+
+// ---- 2..4 activation rows on the decode weight stream (kernels_rows.h): the same workgroup size and float4-per-thread count as the
+// single-row launch of the shape (gemv_f32), so every row's sums are bit-identical to its solo decode step
+template <int KI, int U, int THR, int NC, int PRO, int EPI, int MAP>
+static int launch_gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, uint64_t bytes) {
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, k_gemv_rows<KI, U, THR, NC, PRO, EPI, MAP>, FAT_LDS, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, name, bytes);
+    hipLaunchKernelGGL((k_gemv_rows<KI, U, THR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+static bool gemv_rows_shape_ok(lh_ctx* ctx, uint32_t M, uint32_t K) {
+    const uint32_t K4 = K / 4, rows_wg = M / (uint32_t)ctx->ds->num_cu + 4;
+    return K % 4 == 0 && M % 2 == 0 && ((K4 <= 4 * 256 && rows_wg <= 256) || (K4 <= 6 * 512 && rows_wg <= 512));
+}
+template <int NC, int PRO, int EPI, int MAP>
+static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
+    if (!gemv_rows_shape_ok(ctx, a.M, a.K)) LH_FAIL(ctx, LH_ESHAPE, "gemv_rows %s: %u x %u has no instantiation", name, a.M, a.K);
+    const uint32_t K4 = a.K / 4, rows_wg = a.M / (uint32_t)ctx->ds->num_cu + 4;
+    const uint64_t bytes = (uint64_t)a.M * a.K * 4;
+    if (K4 <= 4 * 256 && rows_wg <= 256) {
+        switch ((K4 + 255) / 256) {
+            case 1: return launch_gemv_rows<1, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+            case 2: return launch_gemv_rows<2, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+            case 3: return launch_gemv_rows<3, 2, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+            default: return launch_gemv_rows<4, 2, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+        }
+    }
+    switch ((K4 + 511) / 512) {
+        case 1: return launch_gemv_rows<1, 2, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 2: return launch_gemv_rows<2, 2, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 3: return launch_gemv_rows<3, 2, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 4: return launch_gemv_rows<4, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+        case 5: return launch_gemv_rows<5, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+        default: return launch_gemv_rows<6, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+    }
+}
+template <int PRO, int EPI, int MAP>
+static int gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
+    return a.n <= 2 ? gemv_rows_nc<2, PRO, EPI, MAP>(ctx, a, name) : gemv_rows_nc<4, PRO, EPI, MAP>(ctx, a, name);
+}
+static constexpr uint32_t GEMV_ROWS_MAX = 4;
 
 template <int KI, int U, int NC>
 static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
@@ -1027,6 +1073,81 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                                      nullptr, nullptr, i)))
                 return rc;
         }
+        return 0;
+    }
+    if (m.wtype == 0 && n <= GEMV_ROWS_MAX && m.hd % 2 == 0 && gemv_rows_shape_ok(ctx, 3 * m.d, m.d) && gemv_rows_shape_ok(ctx, m.d, m.d) &&
+        gemv_rows_shape_ok(ctx, 2 * m.F, m.d) && gemv_rows_shape_ok(ctx, m.d, m.F) && (!m.last_stage() || gemv_rows_shape_ok(ctx, m.V, m.d))) {
+        // ---- 2..4 rows (a prompt of that many tokens, or a tick of that many pods): the decode launches with NC activation rows each
+        // (kernels_rows.h): 5 launches per layer like the decode step, every row bit-identical to its solo step
+        const float* x = p->xa;
+        if (m.first_stage()) {
+            const uint32_t* tok_dev = bc ? bc->tok_dev : p->tokens_dev;
+            if (!bc) {
+                if ((rc = ensure_staging(ctx, (uint64_t)n * 4))) return rc;
+                LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
+                memcpy(ctx->staging, tokens_host, (size_t)n * 4);
+                LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+            }
+            if (!g_prepare_only) hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, tok_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
+            LH_HIP(ctx, hipGetLastError());
+        } else {
+            x = x_in_dev;
+        }
+        const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
+        const uint32_t d = m.d, F = m.F;
+        for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+            const LayerW& L = m.layers[il];
+            const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
+            {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K rows) -> K, V appended   (llama.go:255-297)
+                GemvRowsArgs a = {};
+                a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.rows_per_mat = d; a.M = 3 * d; a.K = d; a.x = x; a.ldx = d; a.n = n; a.gamma = L.attn_norm;
+                a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.rope = p->rope; a.hd = m.hd; a.d = d; a.past = past; a.rows = rows; a.kv_off = slot;
+                if ((rc = gemv_rows<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "rows_qkv_rope"))) return rc;
+            }
+            {   // scores, scale, mask, softmax, PV, head merge per row   (llama.go:300-333)
+                AttnArgs a = {};
+                a.q = p->q; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale;
+                if (rows) {
+                    a.rows = rows; a.kv_off = slot;
+                    if (bc->attn_part) { if ((rc = launch_attention_split(p, a, bc->attn_part))) return rc; }
+                    else if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
+                } else {
+                    a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.sp = nullptr; a.past_host = past;
+                    if ((rc = launch_attention(ctx, a, past + n))) return rc;
+                }
+            }
+            {   // wo + residual   (llama.go:336-340)
+                GemvRowsArgs a = {};
+                a.w[0] = L.wo; a.M = d; a.K = d; a.x = p->attn; a.ldx = d; a.n = n; a.y = p->xb; a.resid = x; a.ldy = d;
+                if ((rc = gemv_rows<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "rows_wo_resid"))) return rc;
+            }
+            {   // RMSNorm*gamma -> w1|w3 -> silu(w1 h) * (w3 h)   (llama.go:346-361)
+                GemvRowsArgs a = {};
+                a.w[0] = L.w1; a.w[1] = L.w3; a.M = 2 * F; a.K = d; a.x = p->xb; a.ldx = d; a.n = n; a.gamma = L.ffn_norm; a.y = p->g; a.ldy = F;
+                if ((rc = gemv_rows<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "rows_w1w3_silu"))) return rc;
+            }
+            {   // w2 + residual   (llama.go:363-366)
+                const bool last = il + 1 == m.layer1;
+                GemvRowsArgs a = {};
+                a.w[0] = L.w2; a.M = d; a.K = F; a.x = p->g; a.ldx = F; a.n = n; a.resid = p->xb; a.ldy = d;
+                a.y = (last && !m.last_stage()) ? x_out_dev : p->xa;
+                if ((rc = gemv_rows<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "rows_w2_resid"))) return rc;
+            }
+            x = p->xa;
+        }
+        if (m.last_stage()) {   // final RMSNorm*gamma -> lm_head: the rows the caller reads (llama.go:372-384, 394-401)
+            const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
+            if (nr == 1) {
+                GemvArgs a = {};
+                a.w[0] = m.output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V;
+                if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", 0))) return rc;
+            } else {
+                GemvRowsArgs a = {};
+                a.w[0] = m.output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.ldx = d; a.n = nr; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V; a.ldy = m.V;
+                if ((rc = gemv_rows<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "rows_lmhead"))) return rc;
+            }
+        }
+        LH_HIP(ctx, hipGetLastError());
         return 0;
     }
     if (!bc && skinny_ok(m, n) && !stream_shape_ok(ctx, m)) {   // k_skinny only where the streaming MFMA kernel is not built for the shape

@@ -115,3 +115,29 @@ def test_host_mirror_builds_reference_graph_shapes(built):
     ml.BuildForwardExpand(g, ml.SoftMax(None, ml.Scale(None, mm, ml.NewFP32(None, 0.5))))
     assert ml.graph_ops(g) == ["MUL_MAT", "SCALE", "SOFT_MAX"]
     ml.FreeGraph(g)
+
+
+def test_bench_ranks_fail_fast_without_a_gpu(built):
+    """`bench.py --gpus 2` where no rank can work (no GPU here): every rank says {"error": ...} and exits non-zero, the self-spawning
+    parent takes the siblings down and returns - within seconds, not after a rendezvous timeout (a crashed rank must not
+    hold the others)."""
+    import json
+    import subprocess
+    import sys
+    import time
+    C.CDLL(os.path.join(ROOT, "llama.go_amd", "lib", "libllamahip.so"), mode=C.RTLD_GLOBAL).lh_device_count.restype = C.c_int
+    import llama_go_amd as pkg
+    lib = C.CDLL(pkg.LIBLLAMAHIP)
+    lib.lh_device_count.restype = C.c_int
+    if lib.lh_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    env = dict(os.environ, BENCH_CONTROL_TIMEOUT_S="30")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shape", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert time.time() - t0 < 200
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines and "error" in json.loads(lines[-1]), r.stdout[-500:]
