@@ -12,11 +12,13 @@
 // runs alone (k_gemv_sa) or in a tick of two to four (this kernel).
 #pragma once
 #include "kernels_llama.h"
+#include "kernels_q8.h"
 
 namespace lh {
 
 struct GemvRowsArgs {
-    const float* w[3];      // matrix bases (MAP_BLOCK: [wq, wk, wv]; MAP_PAIR: [w1, w3])
+    const float* w[3];      // matrix bases (MAP_BLOCK: [wq, wk, wv]; MAP_PAIR: [w1, w3]); block-int8: the int8 planes
+    const float* ws[3];     // block-int8 only (k_gemv_q8_rows): per-32-column scales [rows][K / 32]
     uint32_t rows_per_mat;  // MAP_BLOCK
     uint32_t M, K;          // virtual weight rows, columns
     const float* x;         // activation rows [n][ldx]
@@ -153,6 +155,194 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
                     float* dst = vcb + (size_t)pos * d + (v - 2 * d);
                     dst[0] = s0;
                     dst[1] = s1;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same for block-int8 weights: k_gemv_q8s (kernels_q8.h) with NC activation rows.  A 16-byte load = 16 quants is converted ONCE
+// (16 v_cvt) and multiplied into every row's pair of packed accumulators (8 v_pk_fma per row), the block scale is applied per row as in
+// the single-row kernel; per activation row the arithmetic and its order are those of k_gemv_q8s (dot16_q8, then fmaf with the scale,
+// DPP wave sum, cross-wave sum in wave order): a pod's int8 logits are bit-identical alone and in a tick of two to four.
+// One 16-quant chunk per thread (KI = 1: K <= 4096 with 256 threads per row, 8192 < K <= 16384 with 1024): the 16 x NC activation
+// floats a thread keeps leave no room for more inside the 128 registers of a 1024-thread workgroup.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int U, int TPR, int NC, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(1024) void k_gemv_q8_rows(const GemvRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TH = 1024, G = TH / TPR, NWR = TPR / 64;
+    static_assert(TPR % 64 == 0, "a row group must be a whole number of waves");
+    double* sred = (double*)smem_raw;                        // [NC][16]
+    float* red = (float*)(smem_raw + NC * 16 * 8);           // [weight rows of this workgroup][NC][NWR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tr = tid % TPR, wr = wave % NWR;
+    const uint32_t grp = (uint32_t)__builtin_amdgcn_readfirstlane(tid / TPR);   // uniform within a wave
+    const uint32_t K = a.K, K16 = K >> 4;
+    const uint32_t nwg = gridDim.x;
+    const uint32_t npairs = a.M >> 1;
+    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
+    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    // matrix bases as scalar integers + distances (see k_gemv_q8s)
+    const uint64_t q0 = (uint64_t)sgpr_ptr(a.w[0]), s0 = (uint64_t)sgpr_ptr(a.ws[0]);
+    const uint64_t dq1 = MAP == MAP_SINGLE ? 0 : (uint64_t)sgpr_ptr(a.w[1]) - q0, ds1 = MAP == MAP_SINGLE ? 0 : (uint64_t)sgpr_ptr(a.ws[1]) - s0;
+    const uint64_t dq2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.w[2]) - q0 - dq1 : 0, ds2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.ws[2]) - s0 - ds1 : 0;
+    const uint64_t xdummy = (uint64_t)sgpr_ptr(a.x);         // 4K bytes: covers a quant row (K bytes) and a scale row (K / 8 bytes)
+    const uint32_t rpm = a.rows_per_mat;
+    const bool act = (uint32_t)tr < K16;
+    const uint32_t qoff = act ? (uint32_t)tr * 16u : 0u, soff = act ? ((uint32_t)tr >> 1) * 4u : 0u;
+    f4 xr[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float* xc = a.x + (size_t)((uint32_t)c < a.n ? c : 0) * a.ldx;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xr[c][k] = act ? ((const f4*)xc)[tr * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto fetch = [&](u4 (&wd)[U], float (&sd)[U], uint32_t row_base) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t row = row_base + G * u;
+            uint64_t qb = xdummy, sb = xdummy;
+            if (row < r1) {   // scalar condition
+                uint32_t m = 0, r = row;
+                if (MAP == MAP_BLOCK) { m = (row >= rpm ? 1u : 0u) + (row >= 2u * rpm ? 1u : 0u); r = row - m * rpm; }
+                if (MAP == MAP_PAIR) { m = row & 1u; r = row >> 1; }
+                qb = q0 + (m >= 1u ? dq1 : 0) + (m == 2u ? dq2 : 0) + (uint64_t)r * K;
+                sb = s0 + (m >= 1u ? ds1 : 0) + (m == 2u ? ds2 : 0) + (uint64_t)r * (K >> 5) * 4u;
+            }
+            typedef const u4 __attribute__((address_space(1))) gu4;
+            typedef const float __attribute__((address_space(1))) gf32;
+            wd[u] = __builtin_nontemporal_load((gu4*)(qb + qoff));
+            sd[u] = *(gf32*)(sb + soff);
+        }
+    };
+    u4 wA[U], wB[U];
+    float scA[U], scB[U];
+    fetch(wA, scA, r0 + grp);
+
+    if (PRO == PRO_RMSNORM) {
+        f4 gr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gr[k] = act ? ((const f4*)a.gamma)[tr * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (act) {
+                    s += (double)__fmul_rn(xr[c][k].x, xr[c][k].x);
+                    s += (double)__fmul_rn(xr[c][k].y, xr[c][k].y);
+                    s += (double)__fmul_rn(xr[c][k].z, xr[c][k].z);
+                    s += (double)__fmul_rn(xr[c][k].w, xr[c][k].w);
+                }
+            }
+            s = wave_sum_f64(s);
+            if (lane == 0) sred[c * 16 + wave] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < NWR; ++k) tot += sred[c * 16 + grp * NWR + k];
+            const float scale = (float)(1.0 / sqrt(tot / (double)K + 1e-5));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (act) {
+                    const f4 g = gr[k];
+                    xr[c][k].x = __fmul_rn(g.x, __fmul_rn(xr[c][k].x, scale));
+                    xr[c][k].y = __fmul_rn(g.y, __fmul_rn(xr[c][k].y, scale));
+                    xr[c][k].z = __fmul_rn(g.z, __fmul_rn(xr[c][k].z, scale));
+                    xr[c][k].w = __fmul_rn(g.w, __fmul_rn(xr[c][k].w, scale));
+                }
+            }
+        }
+    }
+
+    auto consume = [&](const u4 (&wd)[U], const float (&sd)[U], uint32_t rb) {
+        float acc[U][NC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f2 w0[4], w1v[4];      // the 16 quants as floats, converted once for all activation rows
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int dq = (int)wd[u][k];
+                w0[k] = f2{(float)(int)(signed char)(dq), (float)(int)(signed char)(dq >> 8)};
+                w1v[k] = f2{(float)(int)(signed char)(dq >> 16), (float)(dq >> 24)};
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {   // dot16_q8's two packed chains and their final adds, per activation row
+                f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a0 = __builtin_elementwise_fma(w0[k], f2{xr[c][k].x, xr[c][k].y}, a0);
+                    a1 = __builtin_elementwise_fma(w1v[k], f2{xr[c][k].z, xr[c][k].w}, a1);
+                }
+                acc[u][c] = fmaf(sd[u], (a0.x + a0.y) + (a1.x + a1.y), 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[u][c] = wave_sum_lane63(acc[u][c]);
+        if (lane == 63) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t row = rb + G * u;
+                if (row < r1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) red[((size_t)(row - r0) * NC + c) * NWR + wr] = acc[u][c];
+                }
+            }
+        }
+    };
+    constexpr uint32_t STEP = G * U;
+    for (uint32_t rb = r0 + grp; rb < r1; rb += 2 * STEP) {
+        fetch(wB, scB, rb + STEP);
+        consume(wA, scA, rb);
+        fetch(wA, scA, rb + 2 * STEP);
+        consume(wB, scB, rb + STEP);   // rows >= r1: loaded from the dummy, results dropped by the row test
+    }
+    __syncthreads();
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    if (r0 + fin >= r1) return;
+    const uint32_t v = r0 + fin;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if ((uint32_t)c >= a.n) break;
+        const float* p0 = red + ((size_t)fin * NC + c) * NWR;
+        float s0v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) s0v += p0[k];
+        if (EPI == EPI_STORE) {
+            a.y[(size_t)c * a.ldy + v] = s0v;
+        } else if (EPI == EPI_RESID) {
+            a.y[(size_t)c * a.ldy + v] = __fadd_rn(s0v, a.resid[(size_t)c * a.ldy + v]);
+        } else {
+            const float* p1 = p0 + (size_t)NC * NWR;
+            float s1v = 0.f;
+#pragma unroll
+            for (int k = 0; k < NWR; ++k) s1v += p1[k];
+            if (EPI == EPI_SILU_MUL) {
+                a.y[(size_t)c * a.ldy + (v >> 1)] = __fmul_rn(silu_ref(s0v), s1v);
+            } else {
+                const uint32_t d = a.d;
+                const uint32_t pos = a.rows ? a.rows[c].pos : a.past + (uint32_t)c;
+                float* kcb = a.rows ? a.rows[c].kc + a.kv_off : a.k_cache;
+                float* vcb = a.rows ? a.rows[c].vc + a.kv_off : a.v_cache;
+                if (v < 2 * d) {
+                    const uint32_t e = v < d ? v : v - d;
+                    const double2 cs = a.rope[(size_t)pos * (a.hd >> 1) + ((e % a.hd) >> 1)];
+                    float o0, o1;
+                    rope_rotate(s0v, s1v, cs, &o0, &o1);
+                    float* dst = v < d ? a.q_out + (size_t)c * d + e : kcb + (size_t)pos * d + e;
+                    dst[0] = o0;
+                    dst[1] = o1;
+                } else {
+                    float* dst = vcb + (size_t)pos * d + (v - 2 * d);
+                    dst[0] = s0v;
+                    dst[1] = s1v;
                 }
             }
         }

@@ -222,11 +222,41 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
         default: return launch_gemv_rows<6, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
     }
 }
+// block-int8 twin (k_gemv_q8_rows): the threads-per-row choice of gemv_q8 for the shapes with ONE 16-quant chunk per thread
+template <int U, int TPR, int NC, int PRO, int EPI, int MAP>
+static int launch_gemv_q8_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, uint64_t bytes) {
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, k_gemv_q8_rows<U, TPR, NC, PRO, EPI, MAP>, FAT_LDS, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    ProfScope ps(ctx->stream, name, bytes);
+    hipLaunchKernelGGL((k_gemv_q8_rows<U, TPR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+static bool gemv_q8_rows_shape_ok(lh_ctx* ctx, uint32_t M, uint32_t K) {
+    const uint32_t K16 = K / 16;
+    return K % 32 == 0 && M % 2 == 0 && (K16 <= 256 || (K16 > 512 && K16 <= 1024)) && (uint64_t)M / ctx->ds->num_cu + 4 <= (uint64_t)TH - 4;
+}
+template <int NC, int PRO, int EPI, int MAP>
+static int gemv_q8_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
+    if (!gemv_q8_rows_shape_ok(ctx, a.M, a.K)) LH_FAIL(ctx, LH_ESHAPE, "gemv_q8_rows %s: %u x %u has no instantiation", name, a.M, a.K);
+    const uint64_t bytes = (uint64_t)a.M * a.K / 32 * 36;
+    if (a.K / 16 <= 256)
+        return a.M / (uint32_t)ctx->ds->num_cu >= 32 ? launch_gemv_q8_rows<2, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes) : launch_gemv_q8_rows<1, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+    return launch_gemv_q8_rows<2, 1024, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+}
 template <int PRO, int EPI, int MAP>
-static int gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
+static int gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, int wtype = 0) {
+    if (wtype == 7) return a.n <= 2 ? gemv_q8_rows_nc<2, PRO, EPI, MAP>(ctx, a, name) : gemv_q8_rows_nc<4, PRO, EPI, MAP>(ctx, a, name);
     return a.n <= 2 ? gemv_rows_nc<2, PRO, EPI, MAP>(ctx, a, name) : gemv_rows_nc<4, PRO, EPI, MAP>(ctx, a, name);
 }
 static constexpr uint32_t GEMV_ROWS_MAX = 4;
+// every launch of a layer (and the lm_head on the last stage) has a multi-row instantiation
+static bool rows_path_ok(lh_ctx* ctx, const ModelDesc& m) {
+    auto ok = [&](uint32_t M, uint32_t K) { return m.wtype == 7 ? gemv_q8_rows_shape_ok(ctx, M, K) : (m.wtype == 0 && gemv_rows_shape_ok(ctx, M, K)); };
+    return m.hd % 2 == 0 && m.d % 4 == 0 && ok(3 * m.d, m.d) && ok(m.d, m.d) && ok(2 * m.F, m.d) && ok(m.d, m.F) && (!m.last_stage() || ok(m.V, m.d));
+}
 
 template <int KI, int U, int NC>
 static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
@@ -1029,7 +1059,8 @@ static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n
 bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     const ModelDesc& m = p->md;
     if (n < 2 || n > BATCH_ROWS_MAX) return false;
-    // block-int8: from 3 rows (one pass of the dequantising stream kernel costs 4.9 ms on 7B whatever the row count <= 16, a single-row
+    if (n <= GEMV_ROWS_MAX && rows_path_ok(p->ctx, m)) return true;   // two to four rows ride the decode stream itself (fp32 and block-int8)
+    // block-int8 on the stream kernel: from 3 rows (one pass of the dequantising stream kernel costs 4.9 ms on 7B whatever the row count <= 16, a single-row
     // int8 GEMV step 2.04 ms: two rows are faster one after the other - profiles/r03_pods_one_gpu.jsonl)
     if (m.wtype == 7) return q8_stream_ok(p->ctx, m, n, 3);
     return m.d % GBK == 0 && m.F % GBK == 0;
@@ -1060,23 +1091,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    // block-int8: 3..48 rows on the stream kernel's dequantising loader
-    const bool q8_stream = q8_stream_ok(ctx, m, n, 3);
-    if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
-        // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
-        // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
-        // On a pipeline stage row i of the received / forwarded residual stream stands in for the token id / the logits row.
-        for (uint32_t i = 0; i < n; ++i) {
-            const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
-            if ((rc = upload_step_params(p, slot, m.first_stage() ? tokens_host[i] : 0, past + i, 0))) return rc;
-            if ((rc = enqueue_decode(p, p->sp_dev + slot, m.first_stage() ? nullptr : x_in_dev + (size_t)i * m.d, m.last_stage() ? nullptr : x_out_dev + (size_t)i * m.d, false,
-                                     nullptr, nullptr, i)))
-                return rc;
-        }
-        return 0;
-    }
-    if (m.wtype == 0 && n <= GEMV_ROWS_MAX && m.hd % 2 == 0 && gemv_rows_shape_ok(ctx, 3 * m.d, m.d) && gemv_rows_shape_ok(ctx, m.d, m.d) &&
-        gemv_rows_shape_ok(ctx, 2 * m.F, m.d) && gemv_rows_shape_ok(ctx, m.d, m.F) && (!m.last_stage() || gemv_rows_shape_ok(ctx, m.V, m.d))) {
+    if (n <= GEMV_ROWS_MAX && rows_path_ok(ctx, m)) {
         // ---- 2..4 rows (a prompt of that many tokens, or a tick of that many pods): the decode launches with NC activation rows each
         // (kernels_rows.h): 5 launches per layer like the decode step, every row bit-identical to its solo step
         const float* x = p->xa;
@@ -1100,9 +1115,9 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
             {   // RMSNorm*gamma -> wq|wk|wv -> RoPE(Q, new K rows) -> K, V appended   (llama.go:255-297)
                 GemvRowsArgs a = {};
-                a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.rows_per_mat = d; a.M = 3 * d; a.K = d; a.x = x; a.ldx = d; a.n = n; a.gamma = L.attn_norm;
+                a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.ws[0] = L.s_wq; a.ws[1] = L.s_wk; a.ws[2] = L.s_wv; a.rows_per_mat = d; a.M = 3 * d; a.K = d; a.x = x; a.ldx = d; a.n = n; a.gamma = L.attn_norm;
                 a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.rope = p->rope; a.hd = m.hd; a.d = d; a.past = past; a.rows = rows; a.kv_off = slot;
-                if ((rc = gemv_rows<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "rows_qkv_rope"))) return rc;
+                if ((rc = gemv_rows<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "rows_qkv_rope", m.wtype))) return rc;
             }
             {   // scores, scale, mask, softmax, PV, head merge per row   (llama.go:300-333)
                 AttnArgs a = {};
@@ -1118,20 +1133,20 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             }
             {   // wo + residual   (llama.go:336-340)
                 GemvRowsArgs a = {};
-                a.w[0] = L.wo; a.M = d; a.K = d; a.x = p->attn; a.ldx = d; a.n = n; a.y = p->xb; a.resid = x; a.ldy = d;
-                if ((rc = gemv_rows<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "rows_wo_resid"))) return rc;
+                a.w[0] = L.wo; a.ws[0] = L.s_wo; a.M = d; a.K = d; a.x = p->attn; a.ldx = d; a.n = n; a.y = p->xb; a.resid = x; a.ldy = d;
+                if ((rc = gemv_rows<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "rows_wo_resid", m.wtype))) return rc;
             }
             {   // RMSNorm*gamma -> w1|w3 -> silu(w1 h) * (w3 h)   (llama.go:346-361)
                 GemvRowsArgs a = {};
-                a.w[0] = L.w1; a.w[1] = L.w3; a.M = 2 * F; a.K = d; a.x = p->xb; a.ldx = d; a.n = n; a.gamma = L.ffn_norm; a.y = p->g; a.ldy = F;
-                if ((rc = gemv_rows<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "rows_w1w3_silu"))) return rc;
+                a.w[0] = L.w1; a.w[1] = L.w3; a.ws[0] = L.s_w1; a.ws[1] = L.s_w3; a.M = 2 * F; a.K = d; a.x = p->xb; a.ldx = d; a.n = n; a.gamma = L.ffn_norm; a.y = p->g; a.ldy = F;
+                if ((rc = gemv_rows<PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>(ctx, a, "rows_w1w3_silu", m.wtype))) return rc;
             }
             {   // w2 + residual   (llama.go:363-366)
                 const bool last = il + 1 == m.layer1;
                 GemvRowsArgs a = {};
-                a.w[0] = L.w2; a.M = d; a.K = F; a.x = p->g; a.ldx = F; a.n = n; a.resid = p->xb; a.ldy = d;
+                a.w[0] = L.w2; a.ws[0] = L.s_w2; a.M = d; a.K = F; a.x = p->g; a.ldx = F; a.n = n; a.resid = p->xb; a.ldy = d;
                 a.y = (last && !m.last_stage()) ? x_out_dev : p->xa;
-                if ((rc = gemv_rows<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "rows_w2_resid"))) return rc;
+                if ((rc = gemv_rows<PRO_PLAIN, EPI_RESID, MAP_SINGLE>(ctx, a, "rows_w2_resid", m.wtype))) return rc;
             }
             x = p->xa;
         }
@@ -1139,15 +1154,30 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
             if (nr == 1) {
                 GemvArgs a = {};
-                a.w[0] = m.output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V;
-                if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", 0))) return rc;
+                a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V;
+                if ((rc = gemv<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "gemv_lmhead", m.wtype))) return rc;
             } else {
                 GemvRowsArgs a = {};
-                a.w[0] = m.output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.ldx = d; a.n = nr; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V; a.ldy = m.V;
-                if ((rc = gemv_rows<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "rows_lmhead"))) return rc;
+                a.w[0] = m.output; a.ws[0] = m.s_output; a.M = m.V; a.K = d; a.x = x + (size_t)r0 * d; a.ldx = d; a.n = nr; a.gamma = m.norm; a.y = p->logits + (size_t)r0 * m.V; a.ldy = m.V;
+                if ((rc = gemv_rows<PRO_RMSNORM, EPI_STORE, MAP_SINGLE>(ctx, a, "rows_lmhead", m.wtype))) return rc;
             }
         }
         LH_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+    // block-int8: 3..48 rows on the stream kernel's dequantising loader
+    const bool q8_stream = q8_stream_ok(ctx, m, n, 3);
+    if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
+        // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
+        // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.
+        // On a pipeline stage row i of the received / forwarded residual stream stands in for the token id / the logits row.
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t slot = 1 + (p->slot_counter++ % (SP_SLOTS - 1));
+            if ((rc = upload_step_params(p, slot, m.first_stage() ? tokens_host[i] : 0, past + i, 0))) return rc;
+            if ((rc = enqueue_decode(p, p->sp_dev + slot, m.first_stage() ? nullptr : x_in_dev + (size_t)i * m.d, m.last_stage() ? nullptr : x_out_dev + (size_t)i * m.d, false,
+                                     nullptr, nullptr, i)))
+                return rc;
+        }
         return 0;
     }
     if (!bc && skinny_ok(m, n) && !stream_shape_ok(ctx, m)) {   // k_skinny only where the streaming MFMA kernel is not built for the shape

@@ -55,6 +55,8 @@ def margins_ok(lg):
     ("small", None, False, [3, 9]),                               # two rows: the smallest batch (decode stream with two activation rows)
     ("small", None, False, [5, 2, 8]),                            # three rows (four-row instantiation, one idle)
     ("7B", 2, False, [3, 1, 4, 2]),                               # four rows on the 7B launches
+    ("small", None, True, [3, 9]),                                # block-int8, two rows (int8 decode stream with two activation rows)
+    ("7B", 2, True, [3, 1, 4, 2]),
     ("small", None, True, [3, 9, 1]),
     ("small", None, False, list(range(1, 18))),                   # 17 rows: two column tiles, K-split wo / w2
     ("small", None, True, list(range(1, 18))),
@@ -109,15 +111,19 @@ def test_row_results_do_not_depend_on_the_neighbours(product):
     assert ids_b2[0] == ids[1]
 
 
+@pytest.mark.parametrize("int8", [False, True])
 @pytest.mark.parametrize("lengths", [[6, 2], [6, 2, 9], [1, 7, 3, 5]])
-def test_ticks_of_two_to_four_pods_are_bit_identical_to_solo_decode(product, lengths):
-    """2..4 rows ride the decode weight stream itself (k_gemv_rows: k_gemv_sa's arithmetic per activation row): a pod's logits are
-    BIT-identical to those of its solo run (llama.Eval per token on its own context), not merely within tolerance."""
+def test_ticks_of_two_to_four_pods_are_bit_identical_to_solo_decode(product, lengths, int8):
+    """2..4 rows ride the decode weight stream itself (k_gemv_rows / k_gemv_q8_rows: k_gemv_sa's / k_gemv_q8s' arithmetic per activation
+    row): a pod's logits are BIT-identical to those of its solo run (llama.Eval per token on its own context), not merely within tolerance."""
     hp = make_hparams(**SHAPES["small"], ctx=48)
     rng = np.random.default_rng(len(lengths))
     prompts = make_prompts(rng, hp.vocabSize, lengths)
     m = product.NewSyntheticModel(hp, 21)
+    if int8:
+        m.QuantizeQ8()
     b = Batch(m, 48, len(prompts))
+    assert b.batched
     ids, lg = b.GreedyDecode(prompts, 6, want_logits=True)
     b.free()
     for i, pr in enumerate(prompts):
