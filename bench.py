@@ -353,7 +353,7 @@ def main():
                     pb[str(P)] = {"tokens_per_s": round(P * K / d_b, 1), "ms_per_tick": round(d_b / K * 1e3, 4),
                                   "ids_match_single_stream": all(t[:n_c] == solo[:n_c] for t in ids_b)}
                 result["pods_batched"] = dict(pb, note="P independent greedy streams on ONE GPU, one pass over the weights per tick for all of them "
-                                                       "(rows = pods: stream-GEMM kernels, per-row KV cache and position); aggregate tokens/s")
+                                                       "(rows = pods: k_gemv_rows up to 4, stream-GEMM kernels beyond; per-row KV cache and position); aggregate tokens/s")
             except Exception as e:  # a side measurement must never take the headline line down
                 result["pods_batched"] = {"error": str(e)}
         ctx.free()
@@ -526,7 +526,7 @@ def main():
         result["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "traffic": None, "bytes_per_launch": dom["bytes_per_launch"],
                               "avg_us": round(dom["avg_us"], 2),
-                              "note": "the rank's batch-1 weight-stream kernel, HIP-event timed (the timed ticks evaluate several rows per pass with the stream-GEMM kernels)"}
+                              "note": "the rank's batch-1 weight-stream kernel, HIP-event timed (the timed ticks carry several rows through the same stream: k_gemv_rows up to 4 rows per pass, the stream-GEMM kernels beyond)"}
         allt = all_ids[0]
         assert len(allt) == 1 + W + K, (len(allt), W, K)
         pl.free()
