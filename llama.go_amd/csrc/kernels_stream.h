@@ -304,7 +304,10 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
 // Q8: block-int8 weights (format of kernels_q8.h).  The loader waves fetch 16 quants + their block's scale per 16-byte load and write
 // fl32(d * q) into the image - literally the checker's dequantise-then-fp32 semantics, like k_gemm_q8 - the compute waves see fp32.
 template <int MAXT, int NCT, int KC, bool Q8 = false>
-__global__ __launch_bounds__(2 * ST_TH) void k_stream_mm2(const StreamArgs a) {
+#ifndef STREAM_KERNEL_ATTR
+#define STREAM_KERNEL_ATTR           // probe builds: e.g. -DSTREAM_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(4,4)))' for two workgroups per CU
+#endif
+__global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(const StreamArgs a) {
     static_assert(KC == 64 || KC == 128 || KC == 256, "chunk");   // 64: four column tiles (49..64 rows) - half-length chunks make room for 6 + 4 tiles twice
     constexpr int ST_PITCH = KC + 4, RPP = 1024 / KC;
     constexpr int NW = MAXT * 16 / RPP, NX = NCT * 16 / RPP;

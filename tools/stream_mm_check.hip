@@ -29,9 +29,11 @@ template <int MAXT, int NCT, int KC> static void run_kc(const StreamArgs& a, int
       for (int w = 0; w < 4; w += 3) { printf("   wave %d, shader clocks per chunk:", w); for (int i = 0; i < 5; ++i) printf(" %s %.0f |", nm[i], tr[w * 8 + i] / nh); printf("\n"); } }
     printf("k_stream_mm<%d,%d,%d>: %.2f us per launch (same weights every launch: L2 / MALL may help), %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
 }
-template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, int nCU) {
-    const size_t lds = std::max<size_t>(stream2_lds_bytes(MAXT, NCT, KC), 82 * 1024);
-    if (lds > 160 * 1024) { printf("k_stream_mm2<%d,%d,%d>: images do not fit\n", MAXT, NCT, KC); return; }
+static int g_wgpcu = 1;   // STREAM_WGPCU=2: two workgroups per CU (grid 2 x #CU, LDS request = the images only; build with a 128-VGPR cap)
+template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, int nCU0) {
+    const int nCU = nCU0 * g_wgpcu;
+    const size_t lds = g_wgpcu == 2 ? stream2_lds_bytes(MAXT, NCT, KC) : std::max<size_t>(stream2_lds_bytes(MAXT, NCT, KC), 82 * 1024);
+    if (lds > 160 * 1024 || (g_wgpcu == 2 && lds > 80 * 1024)) { printf("k_stream_mm2<%d,%d,%d>: images do not fit (%zu B)\n", MAXT, NCT, KC, lds); return; }
     const bool q8 = a.ws[0] != nullptr;
     auto kern = q8 ? k_stream_mm2<MAXT, NCT, KC, true> : k_stream_mm2<MAXT, NCT, KC, false>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -98,7 +100,8 @@ int main(int argc, char** argv) {
     float* dP = nullptr;
     g_yfinal = dY;
     if (S > 1) { CK(hipMalloc(&dP, (size_t)S * N * M * 4)); CK(hipMemset(dP, 0xFF, (size_t)S * N * M * 4)); a.y[0] = dP; a.ksplit = S; a.ysplit = (uint64_t)N * M; }
-    const uint32_t T = M / 16, ngrp = (uint32_t)nCU / S, maxt = (T + ngrp - 1) / ngrp;
+    if (getenv("STREAM_WGPCU")) g_wgpcu = atoi(getenv("STREAM_WGPCU")) == 2 ? 2 : 1;
+    const uint32_t T = M / 16, ngrp = (uint32_t)(nCU * g_wgpcu) / S, maxt = (T + ngrp - 1) / ngrp;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
 #define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64 && N > 80 && MT <= 6) run<(MT <= 6 ? MT : 6), 6>(a, nCU); else if (g_v2 && g_kc == 64 && N > 64 && MT <= 6) run<(MT <= 6 ? MT : 6), 5>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
