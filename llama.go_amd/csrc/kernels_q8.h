@@ -51,10 +51,10 @@ __device__ __forceinline__ float dot16_q8(const u4 q, const f4 (&x)[4]) {
 //   - the loop is unrolled over two register sets (A consumed while B is in flight, then B while A), so no register is copied.
 // Arithmetic and summation order are those of k_gemv_q8: results are bit-identical.
 // ---------------------------------------------------------------------------------------------------
-template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
-__global__ __launch_bounds__(1024) void k_gemv_q8s(const GemvArgs a) {
+template <int KI, int U, int TPR, int PRO, int EPI, int MAP, int TH = 1024>
+__global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TH = 1024, G = TH / TPR, NWR = TPR / 64;
+    constexpr int G = TH / TPR, NWR = TPR / 64;
     static_assert(TPR % 64 == 0, "a row group must be a whole number of waves");
     double* sred = (double*)smem_raw;            // [16]
     float* red = (float*)(smem_raw + 16 * 8);    // [rows of this workgroup][NWR]

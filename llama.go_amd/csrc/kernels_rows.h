@@ -166,13 +166,13 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
 // (16 v_cvt) and multiplied into every row's pair of packed accumulators (8 v_pk_fma per row), the block scale is applied per row as in
 // the single-row kernel; per activation row the arithmetic and its order are those of k_gemv_q8s (dot16_q8, then fmaf with the scale,
 // DPP wave sum, cross-wave sum in wave order): a pod's int8 logits are bit-identical alone and in a tick of two to four.
-// One 16-quant chunk per thread (KI = 1: K <= 4096 with 256 threads per row, 8192 < K <= 16384 with 1024): the 16 x NC activation
-// floats a thread keeps leave no room for more inside the 128 registers of a 1024-thread workgroup.
+// Launch shape = the single-row launch's (gemv_q8 in plan.hip): 256-thread workgroups, 256 threads per row, KI 16-quant chunks per thread
+// (KI = 1: K <= 4096; KI = 3: 8192 < K <= 12288) - the same per-lane partition of a row, hence the same sums.
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int U, int TPR, int NC, int PRO, int EPI, int MAP>
-__global__ __launch_bounds__(1024) void k_gemv_q8_rows(const GemvRowsArgs a) {
+template <int KI, int U, int TPR, int TH, int NC, int PRO, int EPI, int MAP>
+__global__ __launch_bounds__(TH) void k_gemv_q8_rows(const GemvRowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TH = 1024, G = TH / TPR, NWR = TPR / 64;
+    constexpr int G = TH / TPR, NWR = TPR / 64;
     static_assert(TPR % 64 == 0, "a row group must be a whole number of waves");
     double* sred = (double*)smem_raw;                        // [NC][16]
     float* red = (float*)(smem_raw + NC * 16 * 8);           // [weight rows of this workgroup][NC][NWR]
@@ -190,16 +190,23 @@ __global__ __launch_bounds__(1024) void k_gemv_q8_rows(const GemvRowsArgs a) {
     const uint64_t dq2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.w[2]) - q0 - dq1 : 0, ds2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.ws[2]) - s0 - ds1 : 0;
     const uint64_t xdummy = (uint64_t)sgpr_ptr(a.x);         // 4K bytes: covers a quant row (K bytes) and a scale row (K / 8 bytes)
     const uint32_t rpm = a.rows_per_mat;
-    const bool act = (uint32_t)tr < K16;
-    const uint32_t qoff = act ? (uint32_t)tr * 16u : 0u, soff = act ? ((uint32_t)tr >> 1) * 4u : 0u;
-    f4 xr[NC][4];
+    bool act[KI];
+    uint32_t qoff[KI], soff[KI];
+    f4 xr[NC][KI][4];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float* xc = a.x + (size_t)((uint32_t)c < a.n ? c : 0) * a.ldx;
+    for (int j = 0; j < KI; ++j) {
+        const uint32_t ch = (uint32_t)tr + (uint32_t)j * TPR;
+        act[j] = ch < K16;
+        qoff[j] = act[j] ? ch * 16u : 0u;
+        soff[j] = act[j] ? (ch >> 1) * 4u : 0u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xr[c][k] = act ? ((const f4*)xc)[tr * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NC; ++c) {
+            const float* xc = a.x + (size_t)((uint32_t)c < a.n ? c : 0) * a.ldx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xr[c][j][k] = act[j] ? ((const f4*)xc)[ch * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    auto fetch = [&](u4 (&wd)[U], float (&sd)[U], uint32_t row_base) {
+    auto fetch = [&](u4 (&wd)[U][KI], float (&sd)[U][KI], uint32_t row_base) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t row = row_base + G * u;
@@ -213,30 +220,37 @@ __global__ __launch_bounds__(1024) void k_gemv_q8_rows(const GemvRowsArgs a) {
             }
             typedef const u4 __attribute__((address_space(1))) gu4;
             typedef const float __attribute__((address_space(1))) gf32;
-            wd[u] = __builtin_nontemporal_load((gu4*)(qb + qoff));
-            sd[u] = *(gf32*)(sb + soff);
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                wd[u][j] = __builtin_nontemporal_load((gu4*)(qb + qoff[j]));
+                sd[u][j] = *(gf32*)(sb + soff[j]);
+            }
         }
     };
-    u4 wA[U], wB[U];
-    float scA[U], scB[U];
+    u4 wA[U][KI], wB[U][KI];
+    float scA[U][KI], scB[U][KI];
     fetch(wA, scA, r0 + grp);
 
     if (PRO == PRO_RMSNORM) {
-        f4 gr[4];
+        f4 gr[KI][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gr[k] = act ? ((const f4*)a.gamma)[tr * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < KI; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gr[j][k] = act[j] ? ((const f4*)a.gamma)[((uint32_t)tr + (uint32_t)j * TPR) * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             double s = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (act) {
-                    s += (double)__fmul_rn(xr[c][k].x, xr[c][k].x);
-                    s += (double)__fmul_rn(xr[c][k].y, xr[c][k].y);
-                    s += (double)__fmul_rn(xr[c][k].z, xr[c][k].z);
-                    s += (double)__fmul_rn(xr[c][k].w, xr[c][k].w);
+            for (int j = 0; j < KI; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (act[j]) {
+                        s += (double)__fmul_rn(xr[c][j][k].x, xr[c][j][k].x);
+                        s += (double)__fmul_rn(xr[c][j][k].y, xr[c][j][k].y);
+                        s += (double)__fmul_rn(xr[c][j][k].z, xr[c][j][k].z);
+                        s += (double)__fmul_rn(xr[c][j][k].w, xr[c][j][k].w);
+                    }
                 }
-            }
             s = wave_sum_f64(s);
             if (lane == 0) sred[c * 16 + wave] = s;
         }
@@ -248,38 +262,45 @@ __global__ __launch_bounds__(1024) void k_gemv_q8_rows(const GemvRowsArgs a) {
             for (int k = 0; k < NWR; ++k) tot += sred[c * 16 + grp * NWR + k];
             const float scale = (float)(1.0 / sqrt(tot / (double)K + 1e-5));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (act) {
-                    const f4 g = gr[k];
-                    xr[c][k].x = __fmul_rn(g.x, __fmul_rn(xr[c][k].x, scale));
-                    xr[c][k].y = __fmul_rn(g.y, __fmul_rn(xr[c][k].y, scale));
-                    xr[c][k].z = __fmul_rn(g.z, __fmul_rn(xr[c][k].z, scale));
-                    xr[c][k].w = __fmul_rn(g.w, __fmul_rn(xr[c][k].w, scale));
+            for (int j = 0; j < KI; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (act[j]) {
+                        const f4 g = gr[j][k];
+                        xr[c][j][k].x = __fmul_rn(g.x, __fmul_rn(xr[c][j][k].x, scale));
+                        xr[c][j][k].y = __fmul_rn(g.y, __fmul_rn(xr[c][j][k].y, scale));
+                        xr[c][j][k].z = __fmul_rn(g.z, __fmul_rn(xr[c][j][k].z, scale));
+                        xr[c][j][k].w = __fmul_rn(g.w, __fmul_rn(xr[c][j][k].w, scale));
+                    }
                 }
-            }
         }
     }
 
-    auto consume = [&](const u4 (&wd)[U], const float (&sd)[U], uint32_t rb) {
+    auto consume = [&](const u4 (&wd)[U][KI], const float (&sd)[U][KI], uint32_t rb) {
         float acc[U][NC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            f2 w0[4], w1v[4];      // the 16 quants as floats, converted once for all activation rows
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int dq = (int)wd[u][k];
-                w0[k] = f2{(float)(int)(signed char)(dq), (float)(int)(signed char)(dq >> 8)};
-                w1v[k] = f2{(float)(int)(signed char)(dq >> 16), (float)(dq >> 24)};
-            }
+            for (int c = 0; c < NC; ++c) acc[u][c] = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {   // dot16_q8's two packed chains and their final adds, per activation row
-                f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+            for (int j = 0; j < KI; ++j) {
+                f2 w0[4], w1v[4];      // the 16 quants of the chunk as floats, converted once for all activation rows
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    a0 = __builtin_elementwise_fma(w0[k], f2{xr[c][k].x, xr[c][k].y}, a0);
-                    a1 = __builtin_elementwise_fma(w1v[k], f2{xr[c][k].z, xr[c][k].w}, a1);
+                    const int dq = (int)wd[u][j][k];
+                    w0[k] = f2{(float)(int)(signed char)(dq), (float)(int)(signed char)(dq >> 8)};
+                    w1v[k] = f2{(float)(int)(signed char)(dq >> 16), (float)(dq >> 24)};
                 }
-                acc[u][c] = fmaf(sd[u], (a0.x + a0.y) + (a1.x + a1.y), 0.f);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {   // dot16_q8's two packed chains and their final adds, then the chunk's scale: k_gemv_q8s' order
+                    f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a0 = __builtin_elementwise_fma(w0[k], f2{xr[c][j][k].x, xr[c][j][k].y}, a0);
+                        a1 = __builtin_elementwise_fma(w1v[k], f2{xr[c][j][k].z, xr[c][j][k].w}, a1);
+                    }
+                    acc[u][c] = fmaf(sd[u][j], (a0.x + a0.y) + (a1.x + a1.y), acc[u][c]);
+                }
             }
         }
 #pragma unroll

@@ -97,14 +97,14 @@ static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_
     return 0;
 }
 
-template <int KI, int U, int TPR, int PRO, int EPI, int MAP>
+template <int KI, int U, int TPR, int PRO, int EPI, int MAP, int THR = TH>
 static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_t bytes) {
     static bool flags[16] = {};
-    int rc = set_lds_once(ctx, k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>, FAT_LDS, flags);   // one fat workgroup per CU (LDS request > 80 KiB)
+    int rc = set_lds_once(ctx, k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP, THR>, FAT_LDS, flags);   // one fat workgroup per CU (LDS request > 80 KiB)
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    hipLaunchKernelGGL((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP, THR>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -122,6 +122,14 @@ static int gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name) {
     // (501 vs 513 tok/s same-day); 4096 x 4096: U = 1 / 2 / 4 -> 5.8 / 6.0 / 7.6 us (16 rows per CU:
     // deeper batches only add dummy loads); K = 11008: one row across the whole workgroup, U = 2 (U = 4: 13.0 vs 11.6 us)
     const uint32_t rows_wg = a.M / (uint32_t)ctx->ds->num_cu;
+    // Round 3: 256-thread workgroups (ONE row group of four waves, like the fp32 stream) with U rows in flight per register set instead of
+    // 1024 threads = four row groups: 489 -> 534-536 tok/s on 7B (profiles/r03_q8_workgroup_256.txt; per kernel w1|w3 24.8 -> 22.1 us, w2
+    // 14.9 -> 13.4, wo 9.0 -> 8.1, lm_head 34 -> 29, wq|wk|wv 17.4 -> 16.1 with six rows).  U swept 2..8 per shape: 4 (wq|wk|wv: 6), K = 11008: 2.
+    // Same threads per row, same per-lane arithmetic, same cross-wave order: results bit-identical to the 1024-thread launch.
+    if (rows_wg + 4 <= 250) {
+        if (K16 <= 256) return MAP == MAP_BLOCK ? launch_gemv_q8<1, 6, 256, PRO, EPI, MAP, 256>(ctx, a, name, bytes) : launch_gemv_q8<1, 4, 256, PRO, EPI, MAP, 256>(ctx, a, name, bytes);
+        if (K16 > 512 && K16 <= 768) return launch_gemv_q8<3, 2, 256, PRO, EPI, MAP, 256>(ctx, a, name, bytes);
+    }
     if (K16 <= 256) return rows_wg >= 32 ? launch_gemv_q8<1, 2, 256, PRO, EPI, MAP>(ctx, a, name, bytes) : launch_gemv_q8<1, 1, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
     if (K16 <= 512) return launch_gemv_q8<2, 2, 256, PRO, EPI, MAP>(ctx, a, name, bytes);
     if (K16 <= 1024) return launch_gemv_q8<1, 2, 1024, PRO, EPI, MAP>(ctx, a, name, bytes);
@@ -222,29 +230,29 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
         default: return launch_gemv_rows<6, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
     }
 }
-// block-int8 twin (k_gemv_q8_rows): the threads-per-row choice of gemv_q8 for the shapes with ONE 16-quant chunk per thread
-template <int U, int TPR, int NC, int PRO, int EPI, int MAP>
+// block-int8 twin (k_gemv_q8_rows): the launch shape of gemv_q8's 256-thread workgroups (one or three 16-quant chunks per thread)
+template <int KI, int U, int NC, int PRO, int EPI, int MAP>
 static int launch_gemv_q8_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, uint64_t bytes) {
     static bool flags[16] = {};
-    int rc = set_lds_once(ctx, k_gemv_q8_rows<U, TPR, NC, PRO, EPI, MAP>, FAT_LDS, flags);
+    int rc = set_lds_once(ctx, k_gemv_q8_rows<KI, U, 256, 256, NC, PRO, EPI, MAP>, FAT_LDS, flags);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL((k_gemv_q8_rows<U, TPR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    hipLaunchKernelGGL((k_gemv_q8_rows<KI, U, 256, 256, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(256), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
 static bool gemv_q8_rows_shape_ok(lh_ctx* ctx, uint32_t M, uint32_t K) {
     const uint32_t K16 = K / 16;
-    return K % 32 == 0 && M % 2 == 0 && (K16 <= 256 || (K16 > 512 && K16 <= 1024)) && (uint64_t)M / ctx->ds->num_cu + 4 <= (uint64_t)TH - 4;
+    return K % 32 == 0 && M % 2 == 0 && (K16 <= 256 || (K16 > 512 && K16 <= 768)) && (uint64_t)M / ctx->ds->num_cu + 4 <= 250;
 }
 template <int NC, int PRO, int EPI, int MAP>
 static int gemv_q8_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
     if (!gemv_q8_rows_shape_ok(ctx, a.M, a.K)) LH_FAIL(ctx, LH_ESHAPE, "gemv_q8_rows %s: %u x %u has no instantiation", name, a.M, a.K);
     const uint64_t bytes = (uint64_t)a.M * a.K / 32 * 36;
-    if (a.K / 16 <= 256)
-        return a.M / (uint32_t)ctx->ds->num_cu >= 32 ? launch_gemv_q8_rows<2, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes) : launch_gemv_q8_rows<1, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
-    return launch_gemv_q8_rows<2, 1024, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+    constexpr int U = NC <= 2 ? 4 : 2;   // rows in flight per register set: the activation rows take the registers the deeper ring would
+    if (a.K / 16 <= 256) return launch_gemv_q8_rows<1, U, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+    return launch_gemv_q8_rows<3, (NC <= 2 ? 2 : 1), NC, PRO, EPI, MAP>(ctx, a, name, bytes);
 }
 template <int PRO, int EPI, int MAP>
 static int gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, int wtype = 0) {
