@@ -14,8 +14,9 @@
 // Work item = (head, block of 64 queries); a workgroup has two wave PAIRS: the pair splits the 64 queries (interleaved, so both
 // waves see the same causal extent), and the two pairs take the even / odd 32-key tiles with their own (m, l, O) state, merged
 // once per item through LDS — a 64-query item costs at most ceil(T / 64) steps, short enough to balance 640 items over 256 CUs
-// (items are dealt heaviest first).  K and V tiles travel global -> LDS by LDS-DMA (no staging registers); K rows are XOR-swizzled
-// on the source side so that 32 lanes reading the same 16-byte granule of 32 different rows hit 32 different slots.
+// (items are dealt heaviest first, back and forth over the workgroups).  K and V tiles travel global -> LDS by LDS-DMA (no staging
+// registers); K rows are XOR-swizzled on the source side so that 32 lanes reading the same 16-byte granule of 32 different rows hit 32
+// different slots.
 // The K tiles of step s+1 are requested while step s multiplies P.V, the V tiles while step s+1 multiplies K.Q.
 //
 // Rounding: s = fl32(dot) * fl32(1/sqrt(hd)) as in ml.go:2371; p = exp(fl32(s - m)) with m the RUNNING maximum, evaluated by the fp32
@@ -54,8 +55,13 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int lj = lane & 31, lh2 = lane >> 5;
     const uint32_t d = a.d, T = a.past + a.n;
     const uint32_t items = a.nqb * a.H;
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        // heaviest first: the last query blocks see the most keys
+    // Items are numbered heaviest first (the last query blocks see the most keys) and dealt to the workgroups in boustrophedon order: round
+    // 0 left to right, round 1 right to left, ... - the workgroups that drew the longest items of one round get the shortest of the next
+    // (13B, N = 1024: 640 items on 512 workgroups; dealt round-robin the 16-step items shared a workgroup with 4-step ones, 20 steps
+    // on the longest chain against 16 here).  Which workgroup runs an item does not enter its arithmetic.
+    for (uint32_t round = 0;; ++round) {
+        const uint32_t item = round * gridDim.x + ((round & 1u) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
+        if (item >= items) break;   // (every later round lies beyond this index too)
         const uint32_t qb = a.nqb - 1 - item / a.H, h = item % a.H;
         const uint32_t q0 = qb * FA_BQ;
         const uint32_t qend = q0 + FA_BQ < a.n ? q0 + FA_BQ : a.n;
