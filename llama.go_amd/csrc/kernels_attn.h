@@ -13,10 +13,16 @@
 //
 // Work item = (head, block of 64 queries); a workgroup has two wave PAIRS: the pair splits the 64 queries (interleaved, so both
 // waves see the same causal extent), and the two pairs take the even / odd 32-key tiles with their own (m, l, O) state, merged
-// once per item through LDS — a 64-query item costs at most ceil(T / 64) steps, short enough to balance 640 items over 256 CUs
-// (items are dealt heaviest first, back and forth over the workgroups).  K and V tiles travel global -> LDS by LDS-DMA (no staging
-// registers); K rows are XOR-swizzled on the source side so that 32 lanes reading the same 16-byte granule of 32 different rows hit 32
-// different slots.
+// once per item through LDS.  K and V tiles travel global -> LDS by LDS-DMA (no staging registers); K rows are XOR-swizzled on the
+// source side so that 32 lanes reading the same 16-byte granule of 32 different rows hit 32 different slots.
+//
+// Balance: a 64-query block costs ceil(visible keys / 64) steps, so the causal triangle makes the last blocks the longest (13B, N = 1024:
+// 640 blocks of 1..16 steps on 512 workgroups, mean 10.6) and a chunk of a long conversation has few, very long ones (64 queries behind
+// 1984 cached keys: 32 blocks of 32 steps).  The host (plan.hip, attention_flash) therefore cuts the blocks above a chosen length into
+// PARTS by key range, orders all parts longest first (FlashArgs::work) and the workgroups draw them back and forth (round 0 left to
+// right, round 1 right to left, ...).  An uncut block is finished here as before; a part leaves its unnormalised (O, m, l) per query in
+// FlashArgs::part and k_attn_flash_combine adds the parts of a block in part order - a fixed partition and a fixed order, so results
+// do not depend on which workgroup ran what.
 // The K tiles of step s+1 are requested while step s multiplies P.V, the V tiles while step s+1 multiplies K.Q.
 //
 // Rounding: s = fl32(dot) * fl32(1/sqrt(hd)) as in ml.go:2371; p = exp(fl32(s - m)) with m the RUNNING maximum, evaluated by the fp32
@@ -26,6 +32,7 @@
 // (~1e-6 relative against the checker, tolerance 1e-4).  Masked keys contribute exactly 0 (ml.go:2476-2477).
 #pragma once
 #include "kernels_llama.h"
+#include "attn_worklist.h"
 
 namespace lh {
 
@@ -39,9 +46,17 @@ struct FlashArgs {
     uint32_t d, H, n, past;
     float scale;           // fl32(1/sqrt(hd)) llama.go:306
     uint32_t nqb;          // query blocks of FA_BQ
+    // work decomposition (see "Balance" above)
+    float* part;           // [H][nqb - qb_cut][pmax][FA_BQ][FA_PSTRIDE] partial results of the blocks that are cut; null when none is
+    uint32_t chunk;        // a block of more than `chunk` steps is cut into ceil(steps / chunk) parts of near-equal length; 0 = no block is cut
+    uint32_t qb_cut;       // first block that is cut (the step count grows with the block index)
+    uint32_t pmax;         // parts of the longest block
+    uint32_t nwork;        // entries of work[]; 0 = no list: blocks in descending order, uncut
+    uint16_t work[FA_MAXW];   // (block << 4 | part), longest first; every head runs the same list (attn_worklist.h)
 };
 
-constexpr int FA_BQ = 64, FA_TH = 256, FA_HD = 128;
+constexpr int FA_TH = 256, FA_HD = 128;
+constexpr int FA_PSTRIDE = FA_HD + 4;   // a partial record per query: 128 O values, m, l, padding to 16 bytes
 constexpr size_t FA_LDS_BYTES = (size_t)4 * 32 * FA_HD * 4;   // K tiles of the two pairs + V tiles of the two pairs = 64 KiB
 
 // (Tried and dropped, round 3: s_nop 2 / 8 / 16 behind every MFMA so that the other workgroup's softmax issues next to them - 0.792 / 0.792 /
@@ -54,19 +69,22 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
     const int pair = wave >> 1, qhalf = wave & 1;
     const int lj = lane & 31, lh2 = lane >> 5;
     const uint32_t d = a.d, T = a.past + a.n;
-    const uint32_t items = a.nqb * a.H;
-    // Items are numbered heaviest first (the last query blocks see the most keys) and dealt to the workgroups in boustrophedon order: round
-    // 0 left to right, round 1 right to left, ... - the workgroups that drew the longest items of one round get the shortest of the next
-    // (13B, N = 1024: 640 items on 512 workgroups; dealt round-robin the 16-step items shared a workgroup with 4-step ones, 20 steps
-    // on the longest chain against 16 here).  Which workgroup runs an item does not enter its arithmetic.
+    const uint32_t items = (a.nwork ? a.nwork : a.nqb) * a.H;
+    // Items (parts of blocks, every head) are numbered longest first and dealt to the workgroups in boustrophedon order: the workgroups
+    // that drew the longest items of one round get the shortest of the next (13B, N = 1024, uncut: 640 items on 512 workgroups; dealt
+    // round-robin the 16-step items shared a workgroup with 4-step ones, 20 steps on the longest chain against 16).
     for (uint32_t round = 0;; ++round) {
         const uint32_t item = round * gridDim.x + ((round & 1u) ? gridDim.x - 1u - blockIdx.x : blockIdx.x);
         if (item >= items) break;   // (every later round lies beyond this index too)
-        const uint32_t qb = a.nqb - 1 - item / a.H, h = item % a.H;
+        const uint32_t ent = item / a.H, h = item % a.H;
+        const uint32_t code = a.nwork ? (uint32_t)a.work[ent] : (a.nqb - 1 - ent) << 4;
+        const uint32_t qb = code >> 4, part = code & 15u;
         const uint32_t q0 = qb * FA_BQ;
         const uint32_t qend = q0 + FA_BQ < a.n ? q0 + FA_BQ : a.n;
         const uint32_t Tb = a.past + qend;                 // keys any query of this block can see: 0 .. Tb - 1
-        const uint32_t NT = (Tb + 31) / 32, nsteps = (NT + 1) / 2;
+        const uint32_t NT = (Tb + 31) / 32, nsteps = (NT + 1) / 2;   // = fa_steps(past, n, qb)
+        const uint32_t nparts = a.nwork ? fa_parts(nsteps, a.chunk) : 1u;
+        const uint32_t st0 = fa_part_begin(nsteps, nparts, part), st1 = fa_part_begin(nsteps, nparts, part + 1);   // this part's steps
         const uint32_t qi = q0 + 2 * (uint32_t)lj + (uint32_t)qhalf;   // this lane's query (both half-waves hold it)
         const bool qok = qi < a.n;
         const uint32_t qlim = a.past + qi;                 // last visible key of the query
@@ -89,8 +107,8 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             }
         };
         __builtin_amdgcn_s_barrier();   // everybody is done with the previous item's LDS (tiles and merge area)
-        dma(true, 0);
-        dma(false, 0);
+        dma(true, st0);
+        dma(false, st0);
 
         // ---- Q fragment: granule 2g + h of the query row, g = 0..15 (B operand of the 4 MFMAs of granule g)
         f4 qf[16];
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             for (int e = 0; e < 16; ++e) o[ct][e] = 0.f;
         float m = -INFINITY, l = 0.f;
 
-        for (uint32_t st = 0; st < nsteps; ++st) {
+        for (uint32_t st = st0; st < st1; ++st) {
             const uint32_t kt = 2 * st + (uint32_t)pair;       // this pair's key tile
             const bool live = kt < NT;                         // (an odd tile count leaves pair 1 idle in the last step)
             // K(st) landed: my 8 newer V pieces may still be in flight
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
             // V(st) landed, and every wave is done reading K(st): the K tiles of the next step may come in under P.V
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            dma(true, st + 1 < nsteps ? st + 1 : st);          // past the end: a harmless reload (keeps the counts uniform)
+            dma(true, st + 1 < st1 ? st + 1 : st);             // past the end: a harmless reload (keeps the counts uniform)
             if (live) {
                 const float* Vt = Vsm + pair * (32 * FA_HD) + 4 * lj;
 #pragma unroll
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 }
             }
             __builtin_amdgcn_s_barrier();                       // every wave is done reading V(st)
-            dma(false, st + 1 < nsteps ? st + 1 : st);
+            dma(false, st + 1 < st1 ? st + 1 : st);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the redundant tail DMA
         __builtin_amdgcn_s_barrier();
@@ -197,11 +215,16 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
         if (pair == 0 && qok) {
             const float* src = mo + lane * 66;
             const float m1 = src[64], l1 = src[65];
-            const float M = fmaxf(m, m1);                       // finite: key 0 is visible to every query and lives in an even tile
+            const float M = fmaxf(m, m1);                       // an uncut block: finite (key 0 is visible to every query and lives in an even tile)
             const float a0 = m == -INFINITY ? 0.f : expf(__fsub_rn(m, M));
             const float a1 = m1 == -INFINITY ? 0.f : expf(__fsub_rn(m1, M));
-            const float inv = __fdiv_rn(1.0f, fmaf(l1, a1, __fmul_rn(l, a0)));   // ml.go:2496-2499: p *= 1/sum
-            float* orow = a.out + (size_t)qi * d + (size_t)h * FA_HD;
+            const float lsum = fmaf(l1, a1, __fmul_rn(l, a0));
+            // an uncut block: normalise and store (ml.go:2496-2499: p *= 1/sum).  A part: the unnormalised record for k_attn_flash_combine
+            // (a part none of whose keys this query sees leaves O = 0, l = 0, m = -inf).
+            const bool whole = nparts == 1;
+            const float inv = whole ? __fdiv_rn(1.0f, lsum) : 1.0f;
+            float* orow = whole ? a.out + (size_t)qi * d + (size_t)h * FA_HD
+                                : a.part + ((((size_t)h * (a.nqb - a.qb_cut) + (qb - a.qb_cut)) * a.pmax + part) * FA_BQ + (qi - q0)) * FA_PSTRIDE;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c4 = 4 * (8 * (e >> 2) + 4 * lh2 + (e & 3));   // accumulator entry e of O^T tile ct = output column c4 + ct
@@ -212,7 +235,46 @@ __global__ __launch_bounds__(FA_TH) __attribute__((amdgpu_waves_per_eu(2, 2))) v
                 r.w = __fmul_rn(fmaf(src[3 * 16 + e], a1, __fmul_rn(o[3][e], a0)), inv);
                 *(f4*)(orow + c4) = r;
             }
+            if (!whole && lh2 == 0) { orow[FA_HD] = M; orow[FA_HD + 1] = lsum; }
         }
+    }
+}
+
+// The parts of a cut block, added in part order: out = sum_p O_p e^(m_p - M) / sum_p l_p e^(m_p - M), M = max_p m_p (finite: part 0 holds
+// key 0).  grid (H, nqb - qb_cut), 256 threads = 64 queries x 4 column groups of 8 float4.
+__global__ __launch_bounds__(256) void k_attn_flash_combine(const FlashArgs a) {
+    const uint32_t h = blockIdx.x, qb = a.qb_cut + blockIdx.y;
+    const uint32_t nparts = fa_parts(fa_steps(a.past, a.n, qb), a.chunk);
+    const uint32_t ql = threadIdx.x >> 2, cg = threadIdx.x & 3u, qi = qb * FA_BQ + ql;
+    if (nparts == 1 || qi >= a.n) return;
+    const float* rec = a.part + ((((size_t)h * (a.nqb - a.qb_cut) + (qb - a.qb_cut)) * a.pmax) * FA_BQ + ql) * FA_PSTRIDE;   // part p: + p * FA_BQ * FA_PSTRIDE
+    float M = -INFINITY;
+    for (uint32_t p = 0; p < nparts; ++p) M = fmaxf(M, rec[(size_t)p * FA_BQ * FA_PSTRIDE + FA_HD]);
+    f4 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = f4{0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (uint32_t p = 0; p < nparts; ++p) {
+        const float* r = rec + (size_t)p * FA_BQ * FA_PSTRIDE;
+        const float mp = r[FA_HD];
+        const float w = mp == -INFINITY ? 0.f : expf(__fsub_rn(mp, M));
+        den = fmaf(r[FA_HD + 1], w, den);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f4 v = *(const f4*)(r + 4 * (4 * k + (int)cg));
+            acc[k].x = fmaf(v.x, w, acc[k].x);
+            acc[k].y = fmaf(v.y, w, acc[k].y);
+            acc[k].z = fmaf(v.z, w, acc[k].z);
+            acc[k].w = fmaf(v.w, w, acc[k].w);
+        }
+    }
+    const float inv = __fdiv_rn(1.0f, den);
+    float* orow = a.out + (size_t)qi * a.d + (size_t)h * FA_HD;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        f4 v;
+        v.x = __fmul_rn(acc[k].x, inv); v.y = __fmul_rn(acc[k].y, inv); v.z = __fmul_rn(acc[k].z, inv); v.w = __fmul_rn(acc[k].w, inv);
+        *(f4*)(orow + 4 * (4 * k + (int)cg)) = v;
     }
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "kernels_common.h"
+#include "attn_worklist.h"
 
 namespace lh {
 
@@ -47,6 +48,10 @@ struct Plan {
     uint64_t scores_cap = 0, vt_cap = 0;
     float* part = nullptr;                    // raw partial sums between the K-chunk launches of the short-prompt kernel [8][rows]
     uint64_t part_cap = 0;
+    float* fa_part = nullptr;                 // prefill attention: partial (O, m, l) records of the query blocks that are cut by key range
+    uint64_t fa_part_cap = 0;
+    // the work list of the last (n, past) the prefill attention ran for: every layer of an Eval shares it
+    FaWork fa_work;
     uint32_t* tokens_dev = nullptr;
     const double2* rope = nullptr;            // this plan's RoPE table (rotation width hd, >= ctx positions), resolved at plan_create
     // decode graph state

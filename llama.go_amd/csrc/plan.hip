@@ -11,6 +11,7 @@
 #include "kernels_stream.h"
 #include "kernels_rows.h"
 #include <math.h>
+#include <string.h>
 #include <algorithm>
 
 namespace lh {
@@ -479,20 +480,45 @@ static int attention_gemm(Plan* p, const float* q, const float* kc, const float*
     return 0;
 }
 
-// Single-pass causal prefill attention (kernels_attn.h): one kernel per layer, no score tensor, no V^T copy.  hd = 128 (every LLaMA size).
+// Single-pass causal prefill attention (kernels_attn.h): one kernel per layer, no score tensor, no V^T copy (+ the combine pass of the
+// blocks that were cut by key range).  hd = 128 (every LLaMA size).
 static int attention_flash(Plan* p, const float* q, const float* kc, const float* vc, float* out, uint32_t n, uint32_t past, float scale) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     FlashArgs a = {};
     a.q = q; a.k_cache = kc; a.v_cache = vc; a.out = out; a.d = m.d; a.H = m.H; a.n = n; a.past = past; a.scale = scale;
     a.nqb = (n + FA_BQ - 1) / FA_BQ;
+    const uint32_t slots = 2u * (uint32_t)ctx->ds->num_cu;   // 64 KiB of LDS each: two workgroups per CU
+    FaWork& w = p->fa_work;   // attn_worklist.h
+    if (w.n != n || w.past != past) flash_work_list(w, n, past, m.H, slots);
+    a.chunk = w.chunk; a.qb_cut = w.qb_cut; a.pmax = w.pmax; a.nwork = w.nwork;
+    static_assert(sizeof(a.work) == sizeof(w.work), "work list");
+    memcpy(a.work, w.work, sizeof(a.work));
+    const bool cut = w.chunk != 0 && w.qb_cut < a.nqb;
+    if (cut) {
+        const uint64_t need = (uint64_t)m.H * (a.nqb - w.qb_cut) * w.pmax * FA_BQ * FA_PSTRIDE;
+        if (need > p->fa_part_cap) {
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (p->fa_part) LH_HIP(ctx, hipFree(p->fa_part));
+            p->fa_part = nullptr; p->fa_part_cap = 0;
+            LH_HIP(ctx, hipMalloc((void**)&p->fa_part, need * 4));
+            p->fa_part_cap = need;
+        }
+        a.part = p->fa_part;
+    }
     static bool flags[16] = {};
     int rc = set_lds_once(ctx, k_attn_flash, FA_LDS_BYTES, flags);
     if (rc) return rc;
     if (g_prepare_only) return 0;
-    const uint32_t items = a.nqb * m.H, grid = std::min<uint32_t>(items, 2u * (uint32_t)ctx->ds->num_cu);   // 64 KiB of LDS each: two per CU
-    ProfScope ps(ctx->stream, "attn_flash", (uint64_t)2 * (past + n) * m.d * 4);
-    hipLaunchKernelGGL(k_attn_flash, dim3(grid), dim3(FA_TH), FA_LDS_BYTES, ctx->stream, a);
+    const uint32_t items = (a.nwork ? a.nwork : a.nqb) * m.H, grid = std::min<uint32_t>(items, slots);
+    {
+        ProfScope ps(ctx->stream, "attn_flash", (uint64_t)2 * (past + n) * m.d * 4);
+        hipLaunchKernelGGL(k_attn_flash, dim3(grid), dim3(FA_TH), FA_LDS_BYTES, ctx->stream, a);
+    }
+    if (cut) {
+        ProfScope ps(ctx->stream, "attn_flash_combine", (uint64_t)m.H * (a.nqb - w.qb_cut) * w.pmax * FA_BQ * FA_PSTRIDE * 4);
+        hipLaunchKernelGGL(k_attn_flash_combine, dim3(m.H, a.nqb - w.qb_cut), dim3(256), 0, ctx->stream, a);
+    }
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -872,7 +898,7 @@ void plan_destroy(Plan* p) {
     drop_graphs(p, ~0u);
     if (p->ss_dev) hipFree(p->ss_dev);
     if (p->ring_dev) hipFree(p->ring_dev);
-    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part};
+    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part, p->fa_part};
     for (float* b : bufs) if (b) hipFree(b);
     if (p->tokens_dev) hipFree(p->tokens_dev);
     if (p->sp_dev) hipFree(p->sp_dev);

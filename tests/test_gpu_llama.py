@@ -281,6 +281,40 @@ def test_long_prefill_dma_gemm_and_causal_skip_match_oracle(product, oracle):
     assert rel(res["hip"][0], res["hip"][2]) <= TOL   # chunked == single-shot
 
 
+def test_prefill_attention_cut_by_key_range_matches_oracle(product, oracle):
+    """The single-pass prefill attention cuts long query blocks into parts by key range when there are fewer blocks than workgroups
+    or the causal triangle leaves them unbalanced (kernels_attn.h "Balance"; plan.hip flash_work_list): a long first Eval (every late
+    block cut in two or more, the early ones whole), then chunks of a conversation behind a deep cache (one or three blocks, each
+    cut into many parts), a ragged last block, and a decode step on the cache all of them wrote.  Each Eval against the restatement,
+    and the chunked logits against a single Eval of the same 960 tokens."""
+    kw = dict(SHAPES["small"])
+    kw["layers"] = 2
+    ctx = 1024
+    hp = make_hparams(**kw, ctx=ctx)
+    rng = np.random.default_rng(23)
+    toks = [int(t) for t in rng.integers(0, kw["vocab"], 960)]
+    chunks = [700, 64, 163, 33]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 1234)
+        c = m.NewContext(ctx, 16, False)
+        out, past = [], 0
+        for n in chunks:
+            out.append(c.Eval(toks[past:past + n], past))
+            past += n
+        out.append(c.Eval([7], past))
+        c.free()
+        if name == "hip":
+            c = m.NewContext(ctx, 16, False)
+            out.append(c.Eval(toks, 0))
+            c.free()
+        m.free()
+        res[name] = out
+    for a, b in zip(res["hip"], res["orc"]):
+        assert rel(a, b) <= TOL
+    assert rel(res["hip"][3], res["hip"][5]) <= TOL   # last chunk == single Eval of the 960 tokens
+
+
 def test_generic_path_matches_fused_and_oracle(product, oracle):
     """Node-by-node execution of the very same graph (what an arbitrary ml graph gets) agrees with both."""
     hp = make_hparams(**SHAPES["tiny"], ctx=32)

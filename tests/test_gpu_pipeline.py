@@ -96,7 +96,7 @@ def test_pipeline_two_ranks_share_one_gpu_greedy_and_sampled(product, sample):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "pipeline_worker.py"), "small", "40", "3", str(sample), json.dumps(prompts)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-8000:])
     got = last_json(r.stdout)
     assert got["groups"] == 2
     hp = make_hparams(**SHAPES["small"], ctx=40)
