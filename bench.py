@@ -589,6 +589,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()   # every rank is through its last exchange before any of them tears the control group down
         dist.destroy_process_group()
 
 
