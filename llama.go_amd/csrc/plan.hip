@@ -1840,9 +1840,13 @@ int lh_batch_create(lh_ctx* ctx, lh_llama* const* pods, uint32_t n_pods, lh_batc
     if (ok && m.last_stage() && !b->batched && n_pods > 1) ok = al((void**)&b->logits_own, 4 * (size_t)n_pods * m.V);
     if (ok && b->batched && p0->attn_part) ok = al((void**)&b->attn_part, 4 * (size_t)n_pods * m.H * ((m.ctx + ATT_TC - 1) / ATT_TC) * (m.hd + 2));
     if (ok) {
+        // The zero fills above run on the context's stream, which is non-blocking: a synchronous copy (null stream) is NOT ordered behind
+        // them.  Without this wait the fill of rows_dev could land after the table below and leave null cache pointers in it (seen as a GPU
+        // memory fault at cache position 8 x embd, twice in ~40 two-rank runs of round 3).
+        ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
         std::vector<BatchRow> hr(n_pods);
         for (uint32_t i = 0; i < n_pods; ++i) hr[i] = BatchRow{b->pods[i]->md.kc, b->pods[i]->md.vc, 0u, 0u};
-        ok = hipMemcpy(b->rows_dev, hr.data(), sizeof(BatchRow) * n_pods, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMemcpy(b->rows_dev, hr.data(), sizeof(BatchRow) * n_pods, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); batch_free(b); LH_FAIL(ctx, LH_ENOMEM, "lh_batch_create: device allocation failed"); }
     lh_batch* h = new lh_batch();
