@@ -591,10 +591,6 @@ def main():
     if world > 1:
         dist.barrier()   # every rank is through its last exchange before any of them tears the control group down
         dist.destroy_process_group()
-        # the run is complete and reported: leave without the interpreter's teardown of the communication libraries' threads (an abort
-        # there - seen once in ~30 two-rank runs of the test worker - would turn a finished measurement into a failed process)
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
 
 
 if __name__ == "__main__":
