@@ -19,6 +19,12 @@
  *    wg.Wait() join of the reference (ml.go:1652).
  *  - no host pointer is retained past the call that received it (cgo pointer rule): weights are
  *    copied to HBM at registration.
+ *  - ordering: an entry point that reads or writes HOST memory (uploads, reads, prompts, produced ids,
+ *    logits) returns after the context's stream has drained; one that only takes DEVICE pointers
+ *    (lh_llama_stage, lh_batch_stage, lh_comm_exchange over RCCL) enqueues on the context's stream and
+ *    returns.  The private stream is non-blocking, i.e. NOT ordered with the null stream: the library
+ *    itself waits for its stream before any synchronous (null-stream) copy, and a caller that touches
+ *    the same buffers from another stream orders that stream against lh_ctx_stream() itself.
  */
 #ifndef LLAMAHIP_H
 #define LLAMAHIP_H
