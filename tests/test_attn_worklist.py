@@ -114,3 +114,62 @@ def test_expected_decisions(wl):
     # short prompts: one or two blocks of one or two steps
     r = run(wl, 100, 0, 32)
     assert r["chunk"] == 0 and r["nwork"] == 2 and r["work"] == [1 << 4, 0]
+
+
+@pytest.mark.parametrize("n,past,H", [(64, 960, 8), (163, 764, 8), (200, 0, 4), (130, 520, 2)])
+def test_parts_and_combine_reproduce_softmax_attention(wl, n, past, H):
+    """The arithmetic the decomposition relies on, emulated in numpy with the real work list: every part keeps an un-normalised
+    (O, m, l) per query over its key range (a query that sees none of the part's keys: O = 0, l = 0, m = -inf), the combine pass
+    adds the parts in part order with weights e^(m_p - M); an uncut block normalises directly.  Equal to causal softmax attention
+    computed in float64 over all keys (kernels_attn.h k_attn_flash / k_attn_flash_combine)."""
+    import numpy as np
+    r = run(wl, n, past, H, slots=512)
+    rng = np.random.default_rng(n + past)
+    hd, T = 16, past + n
+    q = rng.standard_normal((n, hd)).astype(np.float32)
+    k = rng.standard_normal((T, hd)).astype(np.float32)
+    v = rng.standard_normal((T, hd)).astype(np.float32)
+    scale = np.float32(1.0 / np.sqrt(hd))
+    # reference: float64, key t visible to query j iff t <= past + j
+    s = (q.astype(np.float64) @ k.astype(np.float64).T) * float(scale)
+    mask = np.arange(T)[None, :] <= (past + np.arange(n))[:, None]
+    s = np.where(mask, s, -np.inf)
+    p = np.exp(s - s.max(axis=1, keepdims=True))
+    want = (p / p.sum(axis=1, keepdims=True)) @ v.astype(np.float64)
+    got = np.full((n, hd), np.nan, dtype=np.float32)
+    recs = {}
+    for code in r["work"]:
+        qb, pt = code >> 4, code & 15
+        st = wl.steps(past, n, qb)
+        np_ = wl.parts(st, r["chunk"])
+        k0, k1 = 64 * wl.part_begin(st, np_, pt), min(64 * wl.part_begin(st, np_, pt + 1), T)
+        rows = np.arange(qb * 64, min(qb * 64 + 64, n))
+        ss = (q[rows] @ k[k0:k1].T).astype(np.float32) * scale
+        vis = np.arange(k0, k1)[None, :] <= (past + rows)[:, None]
+        ss = np.where(vis, ss, -np.inf).astype(np.float32)
+        m = ss.max(axis=1)
+        with np.errstate(invalid="ignore"):
+            pp = np.where(vis, np.exp((ss - np.where(np.isinf(m), 0, m)[:, None]).astype(np.float32)), 0).astype(np.float32)
+        l = pp.sum(axis=1, dtype=np.float32)
+        o = (pp @ v[k0:k1]).astype(np.float32)
+        if np_ == 1:
+            got[rows] = o / l[:, None]
+        else:
+            recs[(qb, pt)] = (o, m, l, np_, rows)
+    for qb in sorted({qb for qb, _ in recs}):
+        np_ = recs[(qb, 0)][3]
+        rows = recs[(qb, 0)][4]
+        M = np.max(np.stack([recs[(qb, pt)][1] for pt in range(np_)]), axis=0)
+        assert np.all(np.isfinite(M))                      # part 0 holds key 0
+        acc = np.zeros((len(rows), hd), np.float32)
+        den = np.zeros(len(rows), np.float32)
+        for pt in range(np_):
+            o, m, l, _, _ = recs[(qb, pt)]
+            w = np.where(np.isinf(m), 0, np.exp((m - M).astype(np.float32))).astype(np.float32)
+            acc += o * w[:, None]
+            den += l * w
+        got[rows] = acc / den[:, None]
+    assert not np.isnan(got).any()
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
+    if (n, past) in ((64, 960), (163, 764), (130, 520)):
+        assert r["chunk"] != 0 and r["pmax"] >= 2          # these shapes are cut: the combine path above ran
