@@ -14,7 +14,7 @@ for step in "$@"; do
   t0=$(date +%s)
   case $kind in
     tests) if [ -n "$rest" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$rest" > "$O/tests.log" 2>&1; else timeout 1500 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; fi
-           echo "rc=$?" >> "$O/tests.log"; tail -5 "$O/tests.log" ;;
+           echo "rc=$?" >> "$O/tests.log"; grep -E "^(FAILED|ERROR)|passed|failed|^rc=" "$O/tests.log" | tail -8 ;;   # (a tail would show RCCL's exit banner, not the verdict)
     bench) timeout 900 python bench.py $rest > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"; tail -c 1500 "$O/bench.json" ;;
     trace) tag=${rest%%:*}; cmd=${rest#*:}
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$O/prof_$tag" -o "$tag" -- bash -c "cd $OLDPWD && $cmd") > "$O/trace_$tag.log" 2>&1; echo "trace $tag rc=$?"
