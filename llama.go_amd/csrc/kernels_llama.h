@@ -793,6 +793,11 @@ __global__ void k_batch_advance(BatchRow* rows, StepParams* sp, uint32_t n) {
     sp[i].past += 1;
     sp[i].step += 1;
 }
+// lh_batch_set_sampler: the rows' output lists restart; ids and positions are untouched (rows[] and sp[] stay in lockstep)
+__global__ void k_batch_reset_steps(BatchRow* rows, StepParams* sp, uint32_t n) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) { rows[i].step = 0; sp[i].step = 0; }
+}
 // after the per-row sampler launches (each advanced its row's StepParams: token, past + 1, step + 1, and appended the id to the row's
 // ring and output list): the row table follows
 __global__ void k_batch_from_sp(BatchRow* rows, uint32_t* tok, uint32_t* ids, const StepParams* sp, uint32_t n) {

@@ -293,6 +293,100 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Epilogue of the wave-specialised kernels (k_stream_mm2, k_stream_dma): the partial tiles of the four MFMA waves (waves 4..7, each holding
+// the sums over its share of every chunk's k-blocks) meet in LDS, thread (column, row quad) adds them in wave order (bit-reproducible) and
+// applies the launch's epilogue: + residual | silu(w1 h) * (w3 h) on a (w1, w3) tile pair | RoPE + cache append.  lds_floats = floats of
+// the dynamic LDS that may be overwritten (the images are dead: the caller has passed a workgroup barrier); scales = per-column factors of
+// a folded RMSNorm (k_stream_mm2) or nullptr; acc_of(t, c) = this wave's partial tile.
+template <int MAXT, int NCT, typename AccFn>
+__device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_raw, uint32_t lds_floats, const float* scales, uint32_t t0, uint32_t nt, uint32_t ks,
+                                                uint32_t tiles_per_mat, AccFn&& acc_of) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
+    const bool pairs = a.epi == ST_EPI_SILU_MUL;
+    auto tile_of = [&](uint32_t v, uint32_t* g, uint32_t* tile) {   // virtual tile -> (matrix, 16-row tile in it)
+        if (pairs) { *g = v & 1u; *tile = v >> 1; }
+        else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
+    };
+    constexpr int NC = NCT * 16;
+    float* part = (float*)smem_raw;
+    constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
+    const uint32_t batch = (lds_floats / TILE_FLOATS) & ~1u;   // even: a pair never straddles two batches
+    const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
+    const float nscale = (scales && col < (uint32_t)NC) ? scales[col] : 1.0f;
+    auto tile_sum = [&](uint32_t slot_in_batch) {
+        const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
+        f4 s = *(const f4*)p;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+        if (scales) { s.x = __fmul_rn(s.x, nscale); s.y = __fmul_rn(s.y, nscale); s.z = __fmul_rn(s.z, nscale); s.w = __fmul_rn(s.w, nscale); }
+        return s;
+    };
+    for (uint32_t tb = 0; tb < nt; tb += batch) {
+        if (wave >= 4) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) {
+                        const f4m v = acc_of(t, c);
+                        *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)(wave - 4) * NC + c * 16 + r16) * 16 + slot * 4) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 4 * NC && col < a.n) {
+            if (a.epi == ST_EPI_SILU_MUL) {
+                for (uint32_t t = tb; t + 1 < tb + batch && t + 1 < nt; t += 2) {   // (w1 tile, w3 tile) of the same rows
+                    const f4 s1 = tile_sum(t - tb), s3 = tile_sum(t + 1 - tb);
+                    const uint32_t row = ((t0 + t) >> 1) * 16 + quad * 4;
+                    f4 o;   // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
+                    o.x = __fmul_rn(silu_ref(s1.x), s3.x); o.y = __fmul_rn(silu_ref(s1.y), s3.y);
+                    o.z = __fmul_rn(silu_ref(s1.z), s3.z); o.w = __fmul_rn(silu_ref(s1.w), s3.w);
+                    *(f4*)(a.y[0] + (size_t)col * a.ldy + row) = o;
+                }
+            } else {
+                for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
+                    f4 s = tile_sum(t - tb);
+                    uint32_t g, tile;
+                    tile_of(t0 + t, &g, &tile);
+                    const uint32_t row = tile * 16 + quad * 4;
+                    if (a.epi == ST_EPI_QKV_ROPE) {   // Rope mode 0 on Q / mode 1 on the new K rows (ml.go:2253-2328), K, V appended (llama.go:274-278)
+                        const uint32_t pos = a.rows ? a.rows[col].pos : a.past + col, half = a.hd >> 1;
+                        if (g < 2) {
+                            const double2 c0 = a.rope[(size_t)pos * half + ((row % a.hd) >> 1)], c1 = a.rope[(size_t)pos * half + (((row + 2) % a.hd) >> 1)];
+                            float o0, o1, o2, o3;
+                            rope_rotate(s.x, s.y, c0, &o0, &o1);
+                            rope_rotate(s.z, s.w, c1, &o2, &o3);
+                            s = f4{o0, o1, o2, o3};
+                        }
+                        float* kcb = a.rows ? a.rows[col].kc + a.kv_off : a.k_cache;
+                        float* vcb = a.rows ? a.rows[col].vc + a.kv_off : a.v_cache;
+                        float* dst = g == 0 ? a.q_out + (size_t)col * a.M + row : (g == 1 ? kcb : vcb) + (size_t)pos * a.M + row;
+                        *(f4*)dst = s;
+                    } else {
+                        const size_t o = (size_t)col * a.ldy + row;
+                        const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
+                        float* yp = (g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2])) + (size_t)ks * a.ysplit;
+                        if (rp) {
+                            const f4 rv = *(const f4*)(rp + o);
+                            s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
+                        }
+                        *(f4*)(yp + o) = s;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // k_stream_mm2 — the same computation with SPECIALISED waves: 8 waves per workgroup, waves 0-3 only move data (global -> registers ->
 // LDS image), waves 4-7 only run the matrix cores on the image of the previous chunk; two LDS images, ONE workgroup barrier per chunk.
 // Why: in k_stream_mm every wave alternates between issuing a burst of loads and computing.  Its phase trace (tools/stream_mm_check,
@@ -735,87 +829,187 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
 #endif
     }
     __syncthreads();
-    // ---- epilogue: the partial tiles of the four compute waves meet in LDS (as in k_stream_mm), thread (column, row quad) adds them in
-    // wave order and applies the launch's epilogue: + residual | silu(w1 h) * (w3 h) on a (w1, w3) tile pair | RoPE + cache append
-    constexpr int NC = NCT * 16;
-    float* part = (float*)smem_raw;
-    constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
-    const uint32_t batch = ((uint32_t)(2 * IMG / TILE_FLOATS)) & ~1u;   // even: a pair never straddles two batches
-    const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
-    // the folded RMSNorm's per-token scale (written by the loader waves behind the image memory; read before `part` is touched)
-    const float nscale = (a.gamma && col < (uint32_t)NC) ? ((const float*)smem_raw)[2 * IMG + col] : 1.0f;
-    auto tile_sum = [&](uint32_t slot_in_batch) {
-        const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
-        f4 s = *(const f4*)p;
+    // the folded RMSNorm's per-token scales sit behind the image memory (written by the loader waves; read before `part` is touched)
+    stream_epilogue<MAXT, NCT>(a, smem_raw, (uint32_t)(2 * IMG), a.gamma ? (const float*)smem_raw + 2 * IMG : nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) {
+        f4m v = acc[0][t][c];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
-            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
-        }
-        if (a.gamma) { s.x = __fmul_rn(s.x, nscale); s.y = __fmul_rn(s.y, nscale); s.z = __fmul_rn(s.z, nscale); s.w = __fmul_rn(s.w, nscale); }
-        return s;
-    };
-    for (uint32_t tb = 0; tb < nt; tb += batch) {
-        if (wave >= 4) {
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c) {
-                        f4m v = acc[0][t][c];
-#pragma unroll
-                        for (int q = 1; q < KA; ++q) v += acc[q][t][c];
-                        *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)(wave - 4) * NC + c * 16 + r16) * 16 + slot * 4) = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 4 * NC && col < a.n) {
-            if (a.epi == ST_EPI_SILU_MUL) {
-                for (uint32_t t = tb; t + 1 < tb + batch && t + 1 < nt; t += 2) {   // (w1 tile, w3 tile) of the same rows
-                    const f4 s1 = tile_sum(t - tb), s3 = tile_sum(t + 1 - tb);
-                    const uint32_t row = ((t0 + t) >> 1) * 16 + quad * 4;
-                    f4 o;   // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
-                    o.x = __fmul_rn(silu_ref(s1.x), s3.x); o.y = __fmul_rn(silu_ref(s1.y), s3.y);
-                    o.z = __fmul_rn(silu_ref(s1.z), s3.z); o.w = __fmul_rn(silu_ref(s1.w), s3.w);
-                    *(f4*)(a.y[0] + (size_t)col * a.ldy + row) = o;
-                }
-            } else {
-                for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
-                    f4 s = tile_sum(t - tb);
-                    uint32_t g, tile;
-                    tile_of(t0 + t, &g, &tile);
-                    const uint32_t row = tile * 16 + quad * 4;
-                    if (a.epi == ST_EPI_QKV_ROPE) {   // Rope mode 0 on Q / mode 1 on the new K rows (ml.go:2253-2328), K, V appended (llama.go:274-278)
-                        const uint32_t pos = a.rows ? a.rows[col].pos : a.past + col, half = a.hd >> 1;
-                        if (g < 2) {
-                            const double2 c0 = a.rope[(size_t)pos * half + ((row % a.hd) >> 1)], c1 = a.rope[(size_t)pos * half + (((row + 2) % a.hd) >> 1)];
-                            float o0, o1, o2, o3;
-                            rope_rotate(s.x, s.y, c0, &o0, &o1);
-                            rope_rotate(s.z, s.w, c1, &o2, &o3);
-                            s = f4{o0, o1, o2, o3};
-                        }
-                        float* kcb = a.rows ? a.rows[col].kc + a.kv_off : a.k_cache;
-                        float* vcb = a.rows ? a.rows[col].vc + a.kv_off : a.v_cache;
-                        float* dst = g == 0 ? a.q_out + (size_t)col * a.M + row : (g == 1 ? kcb : vcb) + (size_t)pos * a.M + row;
-                        *(f4*)dst = s;
-                    } else {
-                        const size_t o = (size_t)col * a.ldy + row;
-                        const float* rp = g == 0 ? a.r[0] : (g == 1 ? a.r[1] : a.r[2]);
-                        float* yp = (g == 0 ? a.y[0] : (g == 1 ? a.y[1] : a.y[2])) + (size_t)ks * a.ysplit;
-                        if (rp) {
-                            const f4 rv = *(const f4*)(rp + o);
-                            s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
-                        }
-                        *(f4*)(yp + o) = s;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+        for (int q = 1; q < KA; ++q) v += acc[q][t][c];
+        return v;
+    });
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_stream_dma — the wave-specialised kernel with LDS-DMA loader waves: fp32 weights, two column tiles on (17..96 token rows, where the
+// launch is bound inside the CU, not by memory).
+// Why (round 3's diagnosis, profiles/r03_stream_mfma_pmc.txt): from 17 rows on k_stream_mm2 takes the SUM of its HBM time and its matrix-pipe
+// time per chunk instead of their maximum - the loader wave of a SIMD needs per KB one load, one ds_write_b128 (13 LDS-port cycles each,
+// MI355X_MICROARCH "LDS") and the waits between them, and it only gets issue slots in the gaps of the MFMA wave it shares the SIMD with.
+// Here a loader wave issues ONE instruction per KB and nothing else: `buffer_load_dwordx4 ... lds` (uniform resource per instruction, the
+// lane's byte offset a constant VGPR, the chunk offset an SGPR: no vector ALU, no LDS write, no staging registers), and the chunks in
+// flight live in a ring of NIMG LDS images instead of registers.  Measured round 4 (profiles/r04_stream_dma_probe.txt, same box, w1|w3 /
+// wq|wk|wv / w2 / wo of 7B): 32 rows 78.5 -> 67.9 / 44.1 -> 33.5 / 52.2 -> 40.0 / 22.2 -> 20.2 us, 48 rows 102.0 -> 87.6 / 57.4 -> 44.7 / 68.2 -> 46.8 / 29.0 -> 21.6,
+// 64 rows 127.9 -> 110.3 / 71.2 -> 58.3 / 85.4 -> 59.5 / 34.4 -> 24.6.
+//   * image = [(MAXT + NCT) * 16 rows][KC floats], DENSE (an LDS-DMA instruction writes lane i at base + 16 i: no row padding); the operand
+//     reads stay conflict-free through a source-side swizzle (the LDS destination is lane-linear, so the permutation goes on the SOURCE
+//     address and the same involution on the read, as in k_gemm_glds): 16-byte granule g of image row r is stored at granule position
+//     g ^ (r & 15).  A ds_read_b128 lane group (16 lanes: eight rows at slot s, eight at slot s + 1) then touches 16 different positions.
+//   * ring: chunk c lives in image c % NIMG.  Loader: wait until ITS DMAs of chunk c have landed (counted vmcnt: the NIMG - 2 younger
+//     chunks stay in flight), raw s_barrier c (a __syncthreads would drain the DMAs: an LDS-DMA is a pending LDS write on the VM
+//     counter), then request chunk c + NIMG - 1 into the image chunk c - 1 has left.  One workgroup barrier per chunk as in k_stream_mm2.
+//   * MFMA waves: k-blocks of a chunk dealt to the four waves, every wave all tiles, partial tiles added in wave order (stream_epilogue):
+//     the summation structure of k_stream_mm2.  PIPE: the operands of chunk c are read behind barrier c while chunk c - 1 multiplies out
+//     of registers (no LDS latency between a barrier and the first MFMA behind it; the loader side is the same either way: chunk c's
+//     image is last read in period c).
+// Grouped matrices, (w1, w3) tile pairs, K-split pairs, batched rows and the fused epilogues as in k_stream_mm2; no folded norm (the
+// DMA cannot multiply by gamma on the way: the host keeps the <= 16-row launches that fold it on k_stream_mm2).
+#ifndef STREAM_DMA_WAUX
+#define STREAM_DMA_WAUX 2   // cache policy of the weight DMAs (2 = nt); probe builds override
+#endif
+__host__ __device__ inline size_t stream_dma_lds_bytes(int maxt, int nct, int kc, int nimg) { return (size_t)nimg * (maxt + nct) * 16 * kc * 4; }
+
+template <int MAXT, int NCT, int KC, int NIMG, bool PIPE>
+__global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
+    static_assert(KC == 64 || KC == 128, "chunk");
+    static_assert(NIMG >= 2 && NIMG <= 5, "ring");
+    constexpr int GR = KC / 4;                  // 16-byte granules per image row
+    constexpr int RPI = 64 / GR;                // image rows one DMA instruction covers (1 KB): 4 at KC = 64, 2 at KC = 128
+    constexpr int ROWS = (MAXT + NCT) * 16;
+    constexpr int NIW = ROWS / RPI / 4;         // DMA instructions per loader wave and chunk ...
+    constexpr int JW = MAXT * 16 / RPI / 4;     // ... the first JW of them weight rows, the others activation rows (16 rows = a multiple of 4 RPI)
+    static_assert(ROWS % (RPI * 4) == 0, "rows per loader wave");
+    constexpr int WAITN = NIW * (NIMG - 2) < 64 ? NIW * (NIMG - 2) : 63;   // (the counter holds 63: a stricter wait is still a correct one)
+    constexpr size_t IMGF = (size_t)ROWS * KC;  // floats per image
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* img = (float*)smem_raw;              // [NIMG][ROWS][KC]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
+    const bool pairs = a.epi == ST_EPI_SILU_MUL;   // virtual tile v = (tile v >> 1 of matrix v & 1), dealt in PAIRS (k_stream_mm2)
+    const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
+    const uint32_t S = a.ksplit > 1 ? a.ksplit : 1u, bg = (uint32_t)blockIdx.x / S, ks = (uint32_t)blockIdx.x - bg * S, ng = (uint32_t)gridDim.x / S;
+    if (bg >= ng) return;
+    const uint32_t t0 = um * (uint32_t)(((uint64_t)bg * units) / ng), t1 = um * (uint32_t)(((uint64_t)(bg + 1) * units) / ng);
+    if (t1 <= t0) return;
+    const uint32_t nt = t1 - t0;                // <= MAXT (host)
+    const uint32_t nch_all = a.K / KC, ch0 = (uint32_t)(((uint64_t)ks * nch_all) / S);
+    const uint32_t nch = (uint32_t)(((uint64_t)(ks + 1) * nch_all) / S) - ch0;      // this workgroup's K-chunks (all of them without a split)
+    const uint32_t kbase = ch0 * KC;
+    if (nch == 0) return;                                                           // (the host keeps S <= K / KC)
+    const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
+    constexpr int KB = KC / 64;                 // k-blocks (of 16 columns) per MFMA wave and chunk
+    f4m acc[MAXT][NCT];
+    if (wave < 4) {
+        // ---- loader waves: instruction j of wave w covers image rows [(4 j + w) RPI, +RPI): all in ONE 16-row tile, so the tile's first
+        // row (at this workgroup's first column) is a uniform resource base; the lane keeps (row in tile) * K + its swizzled granule
+        uint32_t voff[NIW];
+        const float* base[NIW];
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            const uint32_t q = (uint32_t)j * 4 + (uint32_t)wave;
+            const uint32_t rr = q * RPI + (uint32_t)lane / GR;          // image row this lane feeds
+            const uint32_t gd = (uint32_t)lane % GR;                    // granule position it lands on
+            const uint32_t gs = gd ^ (rr & 15u);                        // source granule stored there
+            if (j < JW) {
+                uint32_t ti = (q * RPI) >> 4;                           // tile slot of the instruction: uniform
+                ti = ti < nt ? ti : nt - 1;                             // slots beyond the block: a valid tile again, its sums are never stored
+                const uint32_t v = t0 + ti;
+                uint32_t g, tile;
+                if (pairs) { g = v & 1u; tile = v >> 1; }
+                else { g = v / tiles_per_mat; tile = v - g * tiles_per_mat; }
+                const float* mb = g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2]);
+                base[j] = mb + (size_t)tile * 16 * a.K + kbase;
+                voff[j] = ((rr & 15u) * a.K + gs * 4u) * 4u;
+            } else {
+                uint32_t c = rr - (uint32_t)MAXT * 16;
+                c = c < a.n ? c : a.n - 1;                              // columns past the batch: the last row again (never stored)
+                base[j] = a.x + kbase;
+                voff[j] = (c * a.ldx + gs * 4u) * 4u;
+            }
+        }
+        auto issue = [&](uint32_t ch) {
+            const uint32_t cc = ch < nch ? ch : nch - 1;                // past the end: a harmless reload into a free image (uniform counts)
+            const uint32_t k0b = cc * (uint32_t)KC * 4u;
+            float* im = img + (size_t)(ch % NIMG) * IMGF;
+            // (resource and destination as named locals: with the expressions written straight into the builtin's argument list hipcc / ROCm 7.2
+            // silently drops the kernel's HOST stub - the library then fails to load with an undefined symbol)
+#pragma unroll
+            for (int j = 0; j < NIW; ++j) {     // 1 KB per instruction
+                const __amdgpu_buffer_rsrc_t rs = stream_rsrc(base[j]);
+                __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(im + (size_t)(j * 4 + wave) * 256);
+                if (j < JW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, (int)voff[j], (int)k0b, 0, STREAM_DMA_WAUX);   // weights: read once (nt)
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, (int)voff[j], (int)k0b, 0, 0);                        // activations: every workgroup reads them, out of L2
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NIMG - 1; ++c) issue((uint32_t)c);
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            wait_vm<WAITN>();                   // chunk ch of this wave has landed; the NIMG - 2 younger ones may still be in flight
+            __builtin_amdgcn_s_barrier();       // barrier ch: every part of chunk ch is in its image, and the MFMA waves have left chunk ch - 1's
+            issue(ch + NIMG - 1);               // ... whose image takes chunk ch + NIMG - 1
+        }
+        if constexpr (PIPE) __builtin_amdgcn_s_barrier();   // the MFMA waves' extra period (the last chunk's MFMAs)
+        wait_vm<0>();                           // the clamped tail requests
+    } else {
+        // ---- MFMA waves (k_stream_mm2's structure; operands out of the dense, swizzled image)
+        const int cw = wave - 4;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+        constexpr int NO = MAXT + NCT;
+        auto read_ops = [&](f4 (&o)[KB][NO], const float* im) {
+#pragma unroll
+            for (int h = 0; h < KB; ++h) {
+                const uint32_t g = ((uint32_t)(KB * cw + h) * 4 + slot) ^ r16;   // granule position of (k-block, slot) in a row with r & 15 = r16
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) o[h][MAXT + c] = *(const f4*)(im + ((size_t)(MAXT * 16 + c * 16 + r16) * GR + g) * 4);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) o[h][t] = *(const f4*)(im + ((size_t)(t * 16 + r16) * GR + g) * 4);
+            }
+        };
+        auto mfmas = [&](const f4 (&o)[KB][NO]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int h = 0; h < KB; ++h)
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[h][t][s], o[h][MAXT + c][s], acc[t][c], 0, 0, 0);
+        };
+        if constexpr (PIPE) {
+            f4 ops[2][KB][NO];
+            barrier_lds_only();                 // barrier 0: chunk 0 is in image 0
+            read_ops(ops[0], img);
+            for (uint32_t ch = 0; ch < nch; ch += 2) {   // two chunks per trip: the operand buffers swap by name
+                // period ch + 1: operands of chunk ch + 1 are requested, then chunk ch multiplies out of registers.  Scheduling fences: the
+                // reads are ISSUED in front of the MFMAs they hide behind and no MFMA drifts across the workgroup barrier.
+                barrier_lds_only();             // barrier ch + 1 (or the loader's extra barrier behind the last chunk)
+                if (ch + 1 < nch) read_ops(ops[1], img + (size_t)((ch + 1) % NIMG) * IMGF);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(ops[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ch + 1 < nch) {
+                    barrier_lds_only();         // barrier ch + 2
+                    if (ch + 2 < nch) read_ops(ops[0], img + (size_t)((ch + 2) % NIMG) * IMGF);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfmas(ops[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            for (uint32_t ch = 0; ch < nch; ++ch) {
+                const float* im = img + (size_t)(ch % NIMG) * IMGF;
+                barrier_lds_only();             // barrier ch (this wave's operand reads of chunk ch - 1 are complete: lgkmcnt(0))
+                f4 ops[KB][NO];
+                read_ops(ops, im);
+                mfmas(ops);
+            }
+        }
+    }
+    __syncthreads();   // the images are dead (the loader waves have drained their DMAs: a pending LDS-DMA would land in `part`)
+    stream_epilogue<MAXT, NCT>(a, smem_raw, (uint32_t)(NIMG * IMGF), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
+}
+
 // Second half of a K-split launch: token row b of  y = resid + ((p_0 + p_1) + ...) + p_{S-1}  (fixed order: bit-reproducible; Add
 // ml.go:2515-2584), and - gamma != nullptr - the RMSNorm * weight of that row for the next matmul into h (ml.go:1753-1812, 1877-1914: fp32
 // squares, f64 sum, one fp32 scale, two roundings per element - k_rmsnorm_rows' arithmetic on a row that is in registers anyway, so the

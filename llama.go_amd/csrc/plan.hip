@@ -561,6 +561,54 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
+// ---- k_stream_dma (kernels_stream.h): fp32 weights, two column tiles on, no folded norm.  Variant = (chunk length, images in the ring,
+// operand pipelining); LLAMAHIP_STREAM_V=<n> overrides the per-shape choice for same-box A/B runs (-1: k_stream_mm2 as in round 3).
+static int stream_dma_variant_env() {
+    static int v = -100;
+    if (v == -100) { const char* e = getenv("LLAMAHIP_STREAM_V"); v = e ? atoi(e) : -2; }
+    return v;   // -2: not set
+}
+constexpr int dma_nimg_fit(int maxt, int nct, int kc, int cap) {
+    int n = (int)(160 * 1024 / ((size_t)(maxt + nct) * 16 * kc * 4));
+    return n < cap ? n : cap;
+}
+constexpr bool dma_pipe_ok(int maxt, int nct, int kc) { return maxt * nct * 4 + 2 * (maxt + nct) * 4 * (kc / 64) <= 200; }
+template <int MAXT, int NCT, int KC, int NIMG, bool PIPE>
+static int launch_stream_dma(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    static_assert(NIMG >= 2, "ring");
+    static bool flags[16] = {};
+    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG, PIPE>;
+    const size_t lds = std::max<size_t>(stream_dma_lds_bytes(MAXT, NCT, KC, NIMG), 82 * 1024);   // one workgroup per CU
+    int rc = set_lds_once(ctx, kern, lds, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+// variants: 0 = 64-column chunks, as many images as fit (<= 4); 1 = the same with pipelined operands; 2 / 3 = 128-column chunks, two images,
+// without / with pipelined operands; 4 = 64-column chunks, three images, pipelined
+template <int MAXT, int NCT>
+static int launch_stream_dma_v(lh_ctx* ctx, const StreamArgs& a, const char* name, int v) {
+    constexpr int N64 = dma_nimg_fit(MAXT, NCT, 64, 4), N128 = dma_nimg_fit(MAXT, NCT, 128, 2);
+    constexpr bool P64 = dma_pipe_ok(MAXT, NCT, 64), P128 = dma_pipe_ok(MAXT, NCT, 128);
+    static_assert(N64 >= 2, "two images of 64-column chunks always fit");
+    if constexpr (N128 >= 2) {
+        if (v == 2 || (v == 3 && !P128)) return launch_stream_dma<MAXT, NCT, 128, 2, false>(ctx, a, name);
+        if constexpr (P128) if (v == 3) return launch_stream_dma<MAXT, NCT, 128, 2, true>(ctx, a, name);
+    }
+    if constexpr (P64) {
+        if (v == 1 || ((v == 3 || v == 4) && N64 < 4)) return launch_stream_dma<MAXT, NCT, 64, N64, true>(ctx, a, name);
+        if constexpr (N64 == 4) if (v == 4) return launch_stream_dma<MAXT, NCT, 64, 3, true>(ctx, a, name);
+    }
+    return launch_stream_dma<MAXT, NCT, 64, N64, false>(ctx, a, name);
+}
+static int stream_dma_default_variant(int maxt, int nct) {
+    (void)maxt; (void)nct;
+    return 1;
+}
 // K-chunk: 128 columns; 256 for single-tile workgroups on long rows (w2: 37.5 -> 34.9 us).  Longer chunks (a whole 1 KB of ONE row per
 // load instruction, more bytes in flight) measured slower on the other 7B shapes, and a chunk-major copy of the weights (contiguous
 // runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02c_stream_mm_check.txt.
@@ -572,15 +620,23 @@ static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) 
         return launch_stream<MAXT, NCT, 128>(ctx, a, name);
     }
 }
+template <int MAXT, int NCT>
+static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    if constexpr (NCT >= 2) {
+        const int ve = stream_dma_variant_env();
+        if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
+    }
+    return launch_stream_kc<MAXT, NCT>(ctx, a, name);
+}
 template <int MAXT>
 static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    if (a.n <= 16) return launch_stream_kc<MAXT, 1>(ctx, a, name);
-    if (a.n <= 32) return launch_stream_kc<MAXT, 2>(ctx, a, name);
-    if (a.n <= 48) return launch_stream_kc<MAXT, 3>(ctx, a, name);
-    if (a.n <= 64) return launch_stream_kc<MAXT, 4>(ctx, a, name);
+    if (a.n <= 16) return launch_stream_nct<MAXT, 1>(ctx, a, name);
+    if (a.n <= 32) return launch_stream_nct<MAXT, 2>(ctx, a, name);
+    if (a.n <= 48) return launch_stream_nct<MAXT, 3>(ctx, a, name);
+    if (a.n <= 64) return launch_stream_nct<MAXT, 4>(ctx, a, name);
     if constexpr (MAXT <= 6) {   // (8 x 5 / 8 x 6 accumulator tiles do not fit the registers: those launches take the tile GEMM)
-        if (a.n <= 80) return launch_stream_kc<MAXT, 5>(ctx, a, name);
-        return launch_stream_kc<MAXT, 6>(ctx, a, name);
+        if (a.n <= 80) return launch_stream_nct<MAXT, 5>(ctx, a, name);
+        return launch_stream_nct<MAXT, 6>(ctx, a, name);
     }
     return ST_NA;
 }
@@ -1491,6 +1547,10 @@ struct Batch {
     uint64_t scratch_gen() const { uint64_t g = 0; for (const Plan* p : pods) g += p->scratch_gen; return g; }   // grows when any pod's scratch moved
     bool cap_sampling = false;
     bool warm = false;
+    // host mirror of the rows' positions (rows_dev[i].pos): the tick kernels advance them in device memory with no bound of their own, so
+    // the window check of every other Eval entry point (plan_eval: past + n <= ctx) is made here before a tick is enqueued
+    std::vector<uint32_t> pos;
+    bool pos_known = false;        // false until lh_batch_set / lh_batch_prompt placed the rows
     float* logits() const { return batched || B == 1 ? pods[0]->logits : logits_own; }
 };
 
@@ -1535,7 +1595,20 @@ static int batch_enqueue_tick(Batch* b, const float* x_in, float* x_out) {
 
 // One tick on the stream: the first one eagerly (it sets kernel attributes and makes the allocations a capture must not make), then a
 // captured graph, re-captured when an address it holds has changed.
+static int batch_tick_unchecked(Batch* b, const float* x_in, float* x_out);
 static int batch_tick(Batch* b, const float* x_in, float* x_out) {
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    // a tick evaluates row i at position pos[i]: RoPE table row, KV append and the attention's key range all index by it (Eval's
+    // pastCount + N <= CtxSize, checked like plan_eval / lh_llama_stage do)
+    if (!b->pos_known) LH_FAIL(ctx, LH_EINVAL, "lh_batch: tick before lh_batch_set / lh_batch_prompt placed the rows");
+    for (uint32_t i = 0; i < b->B; ++i)
+        if (b->pos[i] >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch: row %u at position %u has left the context window of %u", i, b->pos[i], m.ctx);
+    const int rc = batch_tick_unchecked(b, x_in, x_out);
+    if (rc == 0) for (uint32_t i = 0; i < b->B; ++i) b->pos[i] += 1;
+    return rc;
+}
+static int batch_tick_unchecked(Batch* b, const float* x_in, float* x_out) {
     lh_ctx* ctx = b->ctx;
     Plan* p0 = b->pods[0];
     int rc;
@@ -1574,13 +1647,16 @@ static int batch_set(Batch* b, const uint32_t* tokens, const uint32_t* past, uin
     const ModelDesc& m = b->pods[0]->md;
     BatchSetArgs v = {};
     for (uint32_t i = 0; i < b->B; ++i) {
-        if (past[i] >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_set: row %u at position %u outside the context window of %u", i, past[i], m.ctx);
+        // past == ctx is a legal resting place (a prompt that filled the window, Eval's pastCount + N <= CtxSize): a tick from there is refused by batch_tick
+        if (past[i] > m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_set: row %u at position %u outside the context window of %u", i, past[i], m.ctx);
         if (tokens && tokens[i] >= m.V) LH_FAIL(ctx, LH_EINVAL, "lh_batch_set: token id %u of row %u outside the vocabulary of %u", tokens[i], i, m.V);
         v.pos[i] = past[i];
         v.tok[i] = tokens ? tokens[i] : 0;
     }
     hipLaunchKernelGGL(k_batch_set, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->B, tokens ? 1 : 0, v, b->sp_dev, step0);
     LH_HIP(ctx, hipGetLastError());
+    b->pos.assign(past, past + b->B);
+    b->pos_known = true;
     return 0;
 }
 
@@ -1913,7 +1989,10 @@ int lh_batch_set_sampler(lh_batch* h, const lh_sample_params* sp, uint32_t ring_
     }
     LH_HIP(ctx, hipMemcpy(b->ring_dev, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
     LH_HIP(ctx, hipMemcpy(b->ss_dev, st.data(), sizeof(SampleState) * b->B, hipMemcpyHostToDevice));
-    LH_HIP(ctx, hipMemset(b->sp_dev, 0, sizeof(StepParams) * b->B));   // .step = index into the rows' output lists
+    // the rows' output lists restart (.step = index into them); token ids and positions stay what lh_batch_set / lh_batch_prompt / the ticks made them
+    hipLaunchKernelGGL(k_batch_reset_steps, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, b->B);
+    LH_HIP(ctx, hipGetLastError());
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     b->sampling = true;
     return LH_OK;
 }
@@ -1929,7 +2008,7 @@ int lh_batch_prompt(lh_batch* h, const uint32_t* const* prompts, const uint32_t*
     if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: non-final stage needs an output buffer");
     uint32_t past[64];
     for (uint32_t i = 0; i < b->B; ++i) {   // everything is checked before anything runs
-        if (!n_prompt[i] || n_prompt[i] >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: row %u: prompt of %u tokens outside 1..%u", i, n_prompt[i], m.ctx - 1);
+        if (!n_prompt[i] || n_prompt[i] > m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: row %u: prompt of %u tokens outside 1..%u", i, n_prompt[i], m.ctx);
         if (m.first_stage()) {
             if (!prompts[i]) LH_FAIL(ctx, LH_EINVAL, "lh_batch_prompt: row %u has no prompt", i);
             for (uint32_t j = 0; j < n_prompt[i]; ++j)

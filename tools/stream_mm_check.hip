@@ -1,13 +1,12 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
 // (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit]]]
 // mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 3 specialised waves + block-int8, 4 specialised waves with LDS-DMA
-// loaders (tools/kernels_stream_dma.h, a probe; STREAM_DMA_IMAGES=2..4 images in the ring, default 3); ksplit S > 1 (mode 2 / 3): groups of S
+// loaders (k_stream_dma; STREAM_DMA_IMAGES=2..4 images in the ring, default 3; STREAM_DMA_PIPE=1 pipelined operands); ksplit S > 1 (mode 2 / 3 / 4): groups of S
 // workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
 // Built with -DSTREAM_PROBE=bits (tools/build_probes.sh -> stream_mm_check_p<bits>) the specialised kernel takes one traffic class out of
 // its loop (kernels_stream.h: 1 X from L1, 2 X non-temporal, 4 W temporal, 8 W from cache): timing only, run with STREAM_CHECK_SKIP=1.
 #define STREAM_TRACE
 #include "../llama.go_amd/csrc/kernels_stream.h"
-#include "kernels_stream_dma.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -60,11 +59,11 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
         printf("   with the reduce pass: %.2f us per pair of launches\n", ms * 200);
     }
 }
-static int g_v2 = 0, g_dma = 0, g_nimg = 3;
-template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_img(const StreamArgs& a, int nCU) {
+static int g_v2 = 0, g_dma = 0, g_nimg = 3, g_pipe = 0;
+template <int MAXT, int NCT, int KC, int NIMG, bool PIPE> static void run_dma_img(const StreamArgs& a, int nCU) {
     const size_t lds = stream_dma_lds_bytes(MAXT, NCT, KC, NIMG);
     if (lds > 160 * 1024) { printf("k_stream_dma<%d,%d,%d,%d>: images do not fit (%zu B)\n", MAXT, NCT, KC, NIMG, lds); return; }
-    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG>;
+    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG, PIPE>;
     const size_t req = std::max<size_t>(lds, 82 * 1024);   // one workgroup per CU
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)req));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -73,10 +72,28 @@ template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_img(const Str
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("k_stream_dma<%d,%d,%d> with %d images (LDS-DMA loaders): %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, NIMG, ms * 200, (double)a.M * a.K * 4.0 / (ms * 200) / 1e3);
+    printf("k_stream_dma<%d,%d,%d> with %d images%s%s: %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, NIMG, PIPE ? ", pipelined operands" : "", a.ksplit > 1 ? ", K-split" : "", ms * 200,
+           (double)a.M * a.K * 4.0 / (ms * 200) / 1e3);
+    if (a.ksplit > 1) {
+        StreamReduceArgs r = {}; r.part = a.y[0]; r.stride = a.ysplit; r.y = g_yfinal; r.S = a.ksplit; r.d = a.M; r.ldy = a.ldy;
+        hipLaunchKernelGGL(k_stream_reduce_norm, dim3(a.n), dim3(256), 0, 0, r);
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; ++i) { hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, a); hipLaunchKernelGGL(k_stream_reduce_norm, dim3(a.n), dim3(256), 0, 0, r); }
+        CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("   with the reduce pass: %.2f us per pair of launches\n", ms * 200);
+    }
+}
+template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const StreamArgs& a, int nCU) {
+    if constexpr (NCT >= 2) {
+        constexpr bool POK = MAXT * NCT * 4 + 2 * (MAXT + NCT) * 4 * (KC / 64) <= 200;   // (plan.hip: dma_pipe_ok)
+        if constexpr (POK) { if (g_pipe) { run_dma_img<MAXT, NCT, KC, NIMG, true>(a, nCU); return; } }
+        else if (g_pipe) { printf("k_stream_dma<%d,%d,%d>: two operand sets do not fit the registers\n", MAXT, NCT, KC); return; }
+        run_dma_img<MAXT, NCT, KC, NIMG, false>(a, nCU);
+    } else printf("k_stream_dma: two column tiles on\n");
 }
 template <int MAXT, int NCT, int KC> static void run_dma(const StreamArgs& a, int nCU) {
-    if (g_nimg == 2) run_dma_img<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_img<MAXT, NCT, KC, 4>(a, nCU); else run_dma_img<MAXT, NCT, KC, 3>(a, nCU);
+    if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
 }
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
     if (g_dma) { if (g_kc == 64) run_dma<MAXT, NCT, 64>(a, nCU); else run_dma<MAXT, NCT, 128>(a, nCU); return; }
@@ -93,6 +110,7 @@ int main(int argc, char** argv) {
     g_v2 = argc > 5 && (atoi(argv[5]) == 2 || atoi(argv[5]) == 3 || atoi(argv[5]) == 4);   // (mode 4 takes mode 2's dispatch over the tile counts)
     g_dma = argc > 5 && atoi(argv[5]) == 4;
     if (getenv("STREAM_DMA_IMAGES")) g_nimg = atoi(getenv("STREAM_DMA_IMAGES"));
+    if (getenv("STREAM_DMA_PIPE")) g_pipe = atoi(getenv("STREAM_DMA_PIPE"));
     const bool q8 = argc > 5 && atoi(argv[5]) == 3;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); const int nCU = p.multiProcessorCount;
     std::vector<float> W((size_t)M * K), X((size_t)N * K), Y((size_t)N * M);
