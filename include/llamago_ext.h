@@ -48,6 +48,10 @@ int llamago_ProfileDecode(llama_context* c, uint32_t token, uint32_t past, uint3
 int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_dev, const void* x_in_dev, void* x_out_dev, uint32_t n, uint32_t past,
                   void* logits_dev, void* argmax_dev);
 
+/* ModelParams.KeepCount (llama.go:47): the tokens a context swap keeps (server.go:166-167); 0 in the reference's own main.go.  The generation
+ * loops (llama_GreedyDecode, llama_SampleDecode, llamago_DecodeGreedyResident) swap context at the window's end as server.Do does. */
+void llamago_SetKeepCount(llama_context* c, uint32_t keep);
+
 /* ---- [product] the pods of one GPU in ONE weight pass (lh_batch; server.go:88-101, 151) ------------------------------- */
 typedef struct llama_batch llama_batch;
 /* `pods` llama.Contexts (one KV cache each, llama.go:91-103) over one whole Model on one stream, bound into an lh_batch. */
@@ -57,6 +61,11 @@ int llamago_BatchBatched(llama_batch* b);            /* lh_batch_batched */
 /* Every pod: its prompt as one Eval, then n_predict - 1 greedy steps of ALL pods per weight pass.  out[i * n_predict + s] = s-th id
  * of pod i (= llama_GreedyDecode of that prompt alone); logits (optional): [pods][vocab] of the last tick. */
 int llamago_BatchGreedyDecode(llama_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t n_predict, uint32_t* out, float* logits);
+/* The twins of the Go shim's BatchHIP.Prompt / BatchHIP.Tick (go/ml_hip.go): every pod's prompt as one Eval / one decode step of every pod
+ * in one pass over the weights; ids_out[pods] = the ids produced.  A tick that would leave a pod's context window is an error
+ * (llama.Eval's pastCount + N <= CtxSize), never a write past its KV cache. */
+int llamago_BatchPrompt(llama_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t* ids_out);
+int llamago_BatchTick(llama_batch* b, uint32_t* ids_out);
 
 /* ---- [product] pods as pipeline streams over a layer-sharded model ---------------------------- */
 typedef struct llama_pipeline llama_pipeline;

@@ -132,9 +132,17 @@ int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out);
 void lh_llama_destroy(lh_llama* m);
 /* llama.Eval (llama.go:211-426) on a whole model: logits of the last token to host (vocab floats). */
 int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past, float* logits_host);
+/* ModelParams.KeepCount (llama.go:47) of this context: the first tokens a context swap keeps.  The generation loops below do what
+ * server.Do does when the window is full (pkg/server/server.go:160-172: leftCount = pastCount - KeepCount; pastCount = KeepCount; the
+ * last leftCount / 2 entries of lastNTokens - which already holds the pending token - are re-fed in front of it and evaluated as one
+ * Eval): they go on generating instead of failing.  The swap needs the tokens of the window, which the context knows from the Evals
+ * that went through it with host token ids and from its own resident loops; otherwise the loop fails with LH_EINVAL at the window's
+ * end.  A single Eval past the window (lh_llama_eval, lh_llama_stage, lh_graph_compute) stays an error, as llama.Eval would panic. */
+int lh_llama_set_keep(lh_llama* m, uint32_t keep);
 /* Device-resident greedy decode: step i evaluates one token at position past+i; the argmax (lowest
  * index on ties) is taken on the GPU and feeds step i+1 without a host round trip.  out_tokens[i]
- * = id produced by step i.  logits_last_host (optional) receives the final step's logits. */
+ * = id produced by step i.  logits_last_host (optional) receives the final step's logits.  Past the
+ * window the loop swaps context (above): one host synchronisation per (ctx - keep) / 2 tokens. */
 int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uint32_t n_steps,
                            uint32_t* out_tokens, float* logits_last_host);
 /* One pipeline stage of Eval for a layer-sharded model (residual stream in/out in device memory,

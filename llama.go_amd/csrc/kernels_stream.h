@@ -297,8 +297,10 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
 // the sums over its share of every chunk's k-blocks) meet in LDS, thread (column, row quad) adds them in wave order (bit-reproducible) and
 // applies the launch's epilogue: + residual | silu(w1 h) * (w3 h) on a (w1, w3) tile pair | RoPE + cache append.  lds_floats = floats of
 // the dynamic LDS that may be overwritten (the images are dead: the caller has passed a workgroup barrier); scales = per-column factors of
-// a folded RMSNorm (k_stream_mm2) or nullptr; acc_of(t, c) = this wave's partial tile.
-template <int MAXT, int NCT, typename AccFn>
+// a folded RMSNorm (k_stream_mm2) or nullptr; acc_of(t, c) = this wave's partial tile.  CS = 2 (k_stream_dma, seven / eight column tiles):
+// the MFMA waves are dealt as 2 K-groups x 2 column halves, MFMA wave w holds the sums of K-group w >> 1 for column tiles
+// (w & 1) NCT / 2 + c; two partials per tile meet instead of four.
+template <int MAXT, int NCT, int CS = 1, typename AccFn>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_raw, uint32_t lds_floats, const float* scales, uint32_t t0, uint32_t nt, uint32_t ks,
                                                 uint32_t tiles_per_mat, AccFn&& acc_of) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -309,17 +311,19 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         if (pairs) { *g = v & 1u; *tile = v >> 1; }
         else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
     };
-    constexpr int NC = NCT * 16;
+    constexpr int NC = NCT * 16, NKG = 4 / CS, NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
+    static_assert(CS == 1 || (CS == 2 && NCT % 2 == 0), "column split");
     float* part = (float*)smem_raw;
-    constexpr uint32_t TILE_FLOATS = 4u * NC * 16;
+    constexpr uint32_t TILE_FLOATS = (uint32_t)NKG * NC * 16;
     const uint32_t batch = (lds_floats / TILE_FLOATS) & ~1u;   // even: a pair never straddles two batches
     const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
     const float nscale = (scales && col < (uint32_t)NC) ? scales[col] : 1.0f;
+    const uint32_t kg = CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4), cbase = CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u;
     auto tile_sum = [&](uint32_t slot_in_batch) {
         const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
         f4 s = *(const f4*)p;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NKG; ++w) {
             const f4 q = *(const f4*)(p + (size_t)w * NC * 16);
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
@@ -332,9 +336,9 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
             for (int t = 0; t < MAXT; ++t) {
                 if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c) {
+                    for (int c = 0; c < NCW; ++c) {
                         const f4m v = acc_of(t, c);
-                        *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)(wave - 4) * NC + c * 16 + r16) * 16 + slot * 4) = v;
+                        *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)kg * NC + (cbase + c) * 16 + r16) * 16 + slot * 4) = v;
                     }
                 }
             }
@@ -856,9 +860,12 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
 //     chunks stay in flight), raw s_barrier c (a __syncthreads would drain the DMAs: an LDS-DMA is a pending LDS write on the VM
 //     counter), then request chunk c + NIMG - 1 into the image chunk c - 1 has left.  One workgroup barrier per chunk as in k_stream_mm2.
 //   * MFMA waves: k-blocks of a chunk dealt to the four waves, every wave all tiles, partial tiles added in wave order (stream_epilogue):
-//     the summation structure of k_stream_mm2.  PIPE: the operands of chunk c are read behind barrier c while chunk c - 1 multiplies out
-//     of registers (no LDS latency between a barrier and the first MFMA behind it; the loader side is the same either way: chunk c's
-//     image is last read in period c).
+//     the summation structure of k_stream_mm2.  PIPE: software pipeline over k-blocks - the operands of the next k-block are read while
+//     the current one multiplies out of registers (no LDS latency between a barrier and the first MFMA behind it; the loader side is
+//     the same either way: chunk c's image is last read in the period behind barrier c).
+//   * CS = 2 (97..128 rows = eight column tiles): the MFMA waves are 2 K-groups x 2 column halves - 6 x 4 accumulator tiles per wave
+//     instead of 6 x 8, which would not fit; every wave then reads all weight operands of its K-group's k-blocks and half of the
+//     activation operands.
 // Grouped matrices, (w1, w3) tile pairs, K-split pairs, batched rows and the fused epilogues as in k_stream_mm2; no folded norm (the
 // DMA cannot multiply by gamma on the way: the host keeps the <= 16-row launches that fold it on k_stream_mm2).
 #ifndef STREAM_DMA_WAUX
@@ -866,7 +873,7 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
 #endif
 __host__ __device__ inline size_t stream_dma_lds_bytes(int maxt, int nct, int kc, int nimg) { return (size_t)nimg * (maxt + nct) * 16 * kc * 4; }
 
-template <int MAXT, int NCT, int KC, int NIMG, bool PIPE>
+template <int MAXT, int NCT, int KC, int NIMG, bool PIPE, int CS = 1>
 __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
     static_assert(KC == 64 || KC == 128, "chunk");
     static_assert(NIMG >= 2 && NIMG <= 5, "ring");
@@ -895,8 +902,11 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
     const uint32_t kbase = ch0 * KC;
     if (nch == 0) return;                                                           // (the host keeps S <= K / KC)
     const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
-    constexpr int KB = KC / 64;                 // k-blocks (of 16 columns) per MFMA wave and chunk
-    f4m acc[MAXT][NCT];
+    static_assert(CS == 1 || (CS == 2 && NCT % 2 == 0), "column split");
+    constexpr int NKG = 4 / CS, NCW = NCT / CS; // the four MFMA waves = NKG K-groups x CS column parts of NCW tiles (CS = 2: seven / eight column tiles,
+                                                // whose MAXT x NCT accumulator tiles would not fit one wave's registers)
+    constexpr int KB = KC / 16 / NKG;           // k-blocks (of 16 columns) per MFMA wave and chunk
+    f4m acc[MAXT][NCW];
     if (wave < 4) {
         // ---- loader waves: instruction j of wave w covers image rows [(4 j + w) RPI, +RPI): all in ONE 16-row tile, so the tile's first
         // row (at this workgroup's first column) is a uniform resource base; the lane keeps (row in tile) * K + its swizzled granule
@@ -951,63 +961,84 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
     } else {
         // ---- MFMA waves (k_stream_mm2's structure; operands out of the dense, swizzled image)
         const int cw = wave - 4;
+#ifdef STREAM_TRACE
+        // tools/stream_mm_check: shader clocks and 100 MHz real-time ticks of one MFMA wave's main loop -> the clock the launch ran at
+        const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const uint32_t kq = CS == 2 ? (uint32_t)cw >> 1 : (uint32_t)cw, c0 = CS == 2 ? ((uint32_t)cw & 1u) * NCW : 0u;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
-        constexpr int NO = MAXT + NCT;
-        auto read_ops = [&](f4 (&o)[KB][NO], const float* im) {
+            for (int c = 0; c < NCW; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+        constexpr int NO = MAXT + NCW;
+        auto read_kb = [&](f4 (&o)[NO], const float* im, int h) {   // operands of this wave's k-block h of the chunk in `im`
+            const uint32_t g = ((kq * KB + (uint32_t)h) * 4 + slot) ^ r16;   // granule position of (k-block, slot) in a row with r & 15 = r16
 #pragma unroll
-            for (int h = 0; h < KB; ++h) {
-                const uint32_t g = ((uint32_t)(KB * cw + h) * 4 + slot) ^ r16;   // granule position of (k-block, slot) in a row with r & 15 = r16
+            for (int c = 0; c < NCW; ++c) o[MAXT + c] = *(const f4*)(im + ((size_t)(MAXT * 16 + (c0 + c) * 16 + r16) * GR + g) * 4);
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) o[h][MAXT + c] = *(const f4*)(im + ((size_t)(MAXT * 16 + c * 16 + r16) * GR + g) * 4);
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) o[h][t] = *(const f4*)(im + ((size_t)(t * 16 + r16) * GR + g) * 4);
-            }
+            for (int t = 0; t < MAXT; ++t) o[t] = *(const f4*)(im + ((size_t)(t * 16 + r16) * GR + g) * 4);
         };
-        auto mfmas = [&](const f4 (&o)[KB][NO]) {
+        auto mfma_kb = [&](const f4 (&o)[NO]) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int h = 0; h < KB; ++h)
+                for (int t = 0; t < MAXT; ++t)
 #pragma unroll
-                    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-                        for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[h][t][s], o[h][MAXT + c][s], acc[t][c], 0, 0, 0);
+                    for (int c = 0; c < NCW; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(o[t][s], o[MAXT + c][s], acc[t][c], 0, 0, 0);
         };
+        auto image = [&](uint32_t ch) { return (const float*)(img + (size_t)(ch % NIMG) * IMGF); };
         if constexpr (PIPE) {
-            f4 ops[2][KB][NO];
+            // software pipeline over k-blocks, two operand sets swapped by name: the operands of the NEXT k-block are requested, then the
+            // current one multiplies out of registers.  Scheduling fences: the reads are ISSUED in front of the MFMAs they hide behind and no
+            // MFMA drifts across a workgroup barrier.  A chunk's image is last read in the period behind its own barrier.
+            static_assert(KB == 1 || KB == 2, "k-blocks per wave and chunk");
+            f4 opa[NO], opb[NO];
             barrier_lds_only();                 // barrier 0: chunk 0 is in image 0
-            read_ops(ops[0], img);
-            for (uint32_t ch = 0; ch < nch; ch += 2) {   // two chunks per trip: the operand buffers swap by name
-                // period ch + 1: operands of chunk ch + 1 are requested, then chunk ch multiplies out of registers.  Scheduling fences: the
-                // reads are ISSUED in front of the MFMAs they hide behind and no MFMA drifts across the workgroup barrier.
-                barrier_lds_only();             // barrier ch + 1 (or the loader's extra barrier behind the last chunk)
-                if (ch + 1 < nch) read_ops(ops[1], img + (size_t)((ch + 1) % NIMG) * IMGF);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(ops[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ch + 1 < nch) {
-                    barrier_lds_only();         // barrier ch + 2
-                    if (ch + 2 < nch) read_ops(ops[0], img + (size_t)((ch + 2) % NIMG) * IMGF);
+            read_kb(opa, img, 0);
+            if constexpr (KB == 2) {
+                for (uint32_t ch = 0; ch < nch; ++ch) {
+                    read_kb(opb, image(ch), 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfmas(ops[1]);
+                    mfma_kb(opa);
                     __builtin_amdgcn_sched_barrier(0);
+                    barrier_lds_only();         // barrier ch + 1 (behind the last chunk: the loader's extra one)
+                    if (ch + 1 < nch) read_kb(opa, image(ch + 1), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_kb(opb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (uint32_t ch = 0; ch < nch; ch += 2) {   // two chunks per trip
+                    barrier_lds_only();         // barrier ch + 1
+                    if (ch + 1 < nch) read_kb(opb, image(ch + 1), 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_kb(opa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ch + 1 < nch) {
+                        barrier_lds_only();     // barrier ch + 2
+                        if (ch + 2 < nch) read_kb(opa, image(ch + 2), 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_kb(opb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         } else {
             for (uint32_t ch = 0; ch < nch; ++ch) {
-                const float* im = img + (size_t)(ch % NIMG) * IMGF;
                 barrier_lds_only();             // barrier ch (this wave's operand reads of chunk ch - 1 are complete: lgkmcnt(0))
                 f4 ops[KB][NO];
-                read_ops(ops, im);
-                mfmas(ops);
+#pragma unroll
+                for (int h = 0; h < KB; ++h) read_kb(ops[h], image(ch), h);
+#pragma unroll
+                for (int h = 0; h < KB; ++h) mfma_kb(ops[h]);
             }
         }
+#ifdef STREAM_TRACE
+        if (blockIdx.x == gridDim.x / 2 && tid == 256) { a.trace[40] = __builtin_amdgcn_s_memtime() - tr_c0; a.trace[41] = __builtin_amdgcn_s_memrealtime() - tr_r0; }
+#endif
     }
     __syncthreads();   // the images are dead (the loader waves have drained their DMAs: a pending LDS-DMA would land in `part`)
-    stream_epilogue<MAXT, NCT>(a, smem_raw, (uint32_t)(NIMG * IMGF), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
+    stream_epilogue<MAXT, NCT, CS>(a, smem_raw, (uint32_t)(NIMG * IMGF), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
 }
 
 // Second half of a K-split launch: token row b of  y = resid + ((p_0 + p_1) + ...) + p_{S-1}  (fixed order: bit-reproducible; Add

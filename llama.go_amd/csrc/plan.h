@@ -74,7 +74,20 @@ struct Plan {
     uint32_t smp_topk = 0;                    // topK the sampler launches (and the captured graph) were chosen for
     uint32_t slot_counter = 0;   // round-robin over the pinned StepParams slots of eager (non-graph) steps
     bool use_graph = true;
+    // Context swap of the generation loops (pkg/server/server.go:160-172): the token evaluated at every position of this plan's KV cache, as far as
+    // the host knows it (first stage; HIST_UNKNOWN elsewhere), and ModelParams.KeepCount (llama.go:47).  Evals with host token ids record
+    // themselves; the resident loops record what they produced when they synchronise.
+    static constexpr uint32_t HIST_UNKNOWN = 0xFFFFFFFFu;
+    std::vector<uint32_t> hist;
+    uint32_t keep = 0;
+    void record(uint32_t pos, uint32_t tok) { if (pos < hist.size()) hist[pos] = tok; }
 };
+
+// The re-fed run of a context swap (server.go:166-171) for a stream whose window is full: positions [0, past) hold hist[], `pending` is the
+// sampled token that has not been evaluated yet (the reference has already appended it to lastNTokens, server.go:207, so the run ENDS with it
+// and it is then evaluated once more behind the run - restated as the reference does it).  Returns the n = (past - keep) / 2 tokens that are
+// evaluated as ONE Eval at position keep; the stream continues with `pending` at position keep + n.  false: a token of the run is unknown.
+bool swap_refeed_tokens(const Plan* p, uint32_t past, uint32_t pending, std::vector<uint32_t>* out);
 
 // A batched Eval: n rows that belong to n DIFFERENT streams (the pods of a rank, server.go:88-101), evaluated in one pass over the weights.
 struct BatchCtx {

@@ -205,13 +205,19 @@ static int launch_gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
-static bool gemv_rows_shape_ok(lh_ctx* ctx, uint32_t M, uint32_t K) {
+// nc = activation rows of the instantiation (2, 4, 8), norm = the launch folds the RMSNorm prologue.  Eight rows keep 8 KI float4 of
+// activations per thread: they fit the 512 registers of a 256-thread workgroup's waves (K <= 4096) and, without the norm's gamma registers,
+// the 256 of a 512-thread one; the other combinations would spill (ISA-checked: tools/isa_check.py) and are not built.
+static bool gemv_rows_shape_ok(lh_ctx* ctx, uint32_t M, uint32_t K, uint32_t nc = 4, bool norm = false) {
     const uint32_t K4 = K / 4, rows_wg = M / (uint32_t)ctx->ds->num_cu + 4;
-    return K % 4 == 0 && M % 2 == 0 && ((K4 <= 4 * 256 && rows_wg <= 256) || (K4 <= 6 * 512 && rows_wg <= 512));
+    if (K % 4 || M % 2) return false;
+    if (K4 <= 4 * 256 && rows_wg <= 256) return true;
+    if (nc > 4 && (norm || K4 > 6 * 512)) return false;
+    return K4 <= 6 * 512 && rows_wg <= 512;
 }
 template <int NC, int PRO, int EPI, int MAP>
 static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
-    if (!gemv_rows_shape_ok(ctx, a.M, a.K)) LH_FAIL(ctx, LH_ESHAPE, "gemv_rows %s: %u x %u has no instantiation", name, a.M, a.K);
+    if (!gemv_rows_shape_ok(ctx, a.M, a.K, NC, PRO == PRO_RMSNORM)) LH_FAIL(ctx, LH_ESHAPE, "gemv_rows %s: %u x %u has no %d-row instantiation", name, a.M, a.K, NC);
     const uint32_t K4 = a.K / 4, rows_wg = a.M / (uint32_t)ctx->ds->num_cu + 4;
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
     if (K4 <= 4 * 256 && rows_wg <= 256) {
@@ -222,6 +228,8 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
             default: return launch_gemv_rows<4, 2, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
         }
     }
+    if constexpr (NC > 4 && PRO == PRO_RMSNORM) return LH_ESHAPE;   // (refused above)
+    else {
     switch ((K4 + 511) / 512) {
         case 1: return launch_gemv_rows<1, 2, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 2: return launch_gemv_rows<2, 2, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
@@ -229,6 +237,7 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
         case 4: return launch_gemv_rows<4, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
         case 5: return launch_gemv_rows<5, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
         default: return launch_gemv_rows<6, 1, 512, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+    }
     }
 }
 // block-int8 twin (k_gemv_q8_rows): the launch shape of gemv_q8's 256-thread workgroups (one or three 16-quant chunks per thread)
@@ -258,13 +267,23 @@ static int gemv_q8_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name)
 template <int PRO, int EPI, int MAP>
 static int gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, int wtype = 0) {
     if (wtype == 7) return a.n <= 2 ? gemv_q8_rows_nc<2, PRO, EPI, MAP>(ctx, a, name) : gemv_q8_rows_nc<4, PRO, EPI, MAP>(ctx, a, name);
+    if (a.n > 4) return gemv_rows_nc<8, PRO, EPI, MAP>(ctx, a, name);
     return a.n <= 2 ? gemv_rows_nc<2, PRO, EPI, MAP>(ctx, a, name) : gemv_rows_nc<4, PRO, EPI, MAP>(ctx, a, name);
 }
-static constexpr uint32_t GEMV_ROWS_MAX = 4;
-// every launch of a layer (and the lm_head on the last stage) has a multi-row instantiation
-static bool rows_path_ok(lh_ctx* ctx, const ModelDesc& m) {
-    auto ok = [&](uint32_t M, uint32_t K) { return m.wtype == 7 ? gemv_q8_rows_shape_ok(ctx, M, K) : (m.wtype == 0 && gemv_rows_shape_ok(ctx, M, K)); };
-    return m.hd % 2 == 0 && m.d % 4 == 0 && ok(3 * m.d, m.d) && ok(m.d, m.d) && ok(2 * m.F, m.d) && ok(m.d, m.F) && (!m.last_stage() || ok(m.V, m.d));
+// rows the decode stream carries: fp32 up to 8 (round 4; 32 FMAs per 16-byte load = a sixth of a CU's vector rate at the stream's pace),
+// block-int8 up to 4 (its 16 converts + 16 NC FMAs per load saturate the vector ALU from there on)
+static constexpr uint32_t GEMV_ROWS_MAX_F32 = 8, GEMV_ROWS_MAX_Q8 = 4;
+static uint32_t gemv_rows_max(int wtype) {
+    static int cap = -1;   // LLAMAHIP_ROWS_MAX=<n>: same-box A/B runs against the stream kernel (4 = round 3's split)
+    if (cap < 0) { const char* e = getenv("LLAMAHIP_ROWS_MAX"); cap = e ? atoi(e) : 1 << 20; }
+    return std::min<uint32_t>((uint32_t)cap, wtype == 7 ? GEMV_ROWS_MAX_Q8 : GEMV_ROWS_MAX_F32);
+}
+// every launch of a layer (and the lm_head on the last stage) has an n-row instantiation
+static bool rows_path_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n) {
+    if (n > gemv_rows_max(m.wtype)) return false;
+    const uint32_t nc = n <= 2 ? 2 : (n <= 4 ? 4 : 8);
+    auto ok = [&](uint32_t M, uint32_t K, bool norm) { return m.wtype == 7 ? gemv_q8_rows_shape_ok(ctx, M, K) : (m.wtype == 0 && gemv_rows_shape_ok(ctx, M, K, nc, norm)); };
+    return m.hd % 2 == 0 && m.d % 4 == 0 && ok(3 * m.d, m.d, true) && ok(m.d, m.d, false) && ok(2 * m.F, m.d, true) && ok(m.d, m.F, false) && (!m.last_stage() || ok(m.V, m.d, true));
 }
 
 template <int KI, int U, int NC>
@@ -531,8 +550,8 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // the tile GEMM): 49..64 rows run half-length chunks (KC = 64: 2 x (6 + 4) x 16 x 68 floats = 87 KB), fp32 weights only.
 // 65..96 rows (round 3): five / six column tiles on the same half-length chunks (2 x (6 + 6) x 16 x 68 floats = 104 KB; 6 x 6 accumulator tiles =
 // 144 registers of the MFMA waves).  The tile GEMM's single row of 128-row tiles cost 17.6 ms at 65 rows against 10.2 ms at 64.
-static constexpr uint32_t STREAM_ROWS_BUILT = 96, STREAM_ROWS_Q8 = 48, BATCH_ROWS_MAX = 64;
-static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
+static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 48, BATCH_ROWS_MAX = 64;
+static int stream_nct(uint32_t n) { return n > 96 ? 8 : (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
 
@@ -572,12 +591,13 @@ constexpr int dma_nimg_fit(int maxt, int nct, int kc, int cap) {
     int n = (int)(160 * 1024 / ((size_t)(maxt + nct) * 16 * kc * 4));
     return n < cap ? n : cap;
 }
-constexpr bool dma_pipe_ok(int maxt, int nct, int kc) { return maxt * nct * 4 + 2 * (maxt + nct) * 4 * (kc / 64) <= 200; }
-template <int MAXT, int NCT, int KC, int NIMG, bool PIPE>
+// registers of an MFMA wave: the accumulator tiles + two operand sets of one k-block each (the pipeline is k-block by k-block)
+constexpr bool dma_pipe_ok(int maxt, int ncw) { return maxt * ncw * 4 + 2 * (maxt + ncw) * 4 <= 210; }
+template <int MAXT, int NCT, int KC, int NIMG, bool PIPE, int CS = 1>
 static int launch_stream_dma(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     static_assert(NIMG >= 2, "ring");
     static bool flags[16] = {};
-    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG, PIPE>;
+    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG, PIPE, CS>;
     const size_t lds = std::max<size_t>(stream_dma_lds_bytes(MAXT, NCT, KC, NIMG), 82 * 1024);   // one workgroup per CU
     int rc = set_lds_once(ctx, kern, lds, flags);
     if (rc) return rc;
@@ -588,27 +608,26 @@ static int launch_stream_dma(lh_ctx* ctx, const StreamArgs& a, const char* name)
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
-// variants: 0 = 64-column chunks, as many images as fit (<= 4); 1 = the same with pipelined operands; 2 / 3 = 128-column chunks, two images,
-// without / with pipelined operands; 4 = 64-column chunks, three images, pipelined
+// variants: 0 = 64-column chunks, as many images as fit (<= 4); 2 = 128-column chunks, two images; 1 / 3 = the same with pipelined operands
+// (measured round 4, profiles/r04_stream_dma_variants.txt: the operand pipeline buys nothing on two to six column tiles - the LDS
+// latency behind a barrier is not what idles the matrix pipe - so only the eight-column-tile launches are built with it)
 template <int MAXT, int NCT>
 static int launch_stream_dma_v(lh_ctx* ctx, const StreamArgs& a, const char* name, int v) {
     constexpr int N64 = dma_nimg_fit(MAXT, NCT, 64, 4), N128 = dma_nimg_fit(MAXT, NCT, 128, 2);
-    constexpr bool P64 = dma_pipe_ok(MAXT, NCT, 64), P128 = dma_pipe_ok(MAXT, NCT, 128);
     static_assert(N64 >= 2, "two images of 64-column chunks always fit");
-    if constexpr (N128 >= 2) {
-        if (v == 2 || (v == 3 && !P128)) return launch_stream_dma<MAXT, NCT, 128, 2, false>(ctx, a, name);
-        if constexpr (P128) if (v == 3) return launch_stream_dma<MAXT, NCT, 128, 2, true>(ctx, a, name);
+    if constexpr (NCT > 6) {   // seven / eight column tiles: MFMA waves as 2 K-groups x 2 column halves, 64-column chunks
+        static_assert(NCT == 8 && dma_pipe_ok(MAXT, NCT / 2), "column split");
+        if (v == 0) return launch_stream_dma<MAXT, NCT, 64, N64, false, 2>(ctx, a, name);
+        return launch_stream_dma<MAXT, NCT, 64, N64, true, 2>(ctx, a, name);
+    } else {
+        if constexpr (N128 >= 2) if (v == 2) return launch_stream_dma<MAXT, NCT, 128, 2, false>(ctx, a, name);
+        return launch_stream_dma<MAXT, NCT, 64, N64, false>(ctx, a, name);
     }
-    if constexpr (P64) {
-        if (v == 1 || ((v == 3 || v == 4) && N64 < 4)) return launch_stream_dma<MAXT, NCT, 64, N64, true>(ctx, a, name);
-        if constexpr (N64 == 4) if (v == 4) return launch_stream_dma<MAXT, NCT, 64, 3, true>(ctx, a, name);
-    }
-    return launch_stream_dma<MAXT, NCT, 64, N64, false>(ctx, a, name);
 }
-static int stream_dma_default_variant(int maxt, int nct) {
-    (void)maxt; (void)nct;
-    return 1;
-}
+// per shape (7B launches, same box, tools/stream_mm_check mode 4): long chunks where a workgroup streams five or more row tiles next to two
+// column tiles (w1|w3 at 17..32 rows: 63.2 us against 67.2-68.4; memory-bound there, and a DMA instruction then moves 512 contiguous bytes
+// of a row); everywhere else the deeper ring of short chunks (wq|wk|wv at 32 rows 36.6 against 37.1, wo 19.1 against 25.6, w2 46.5 against 67.2)
+static int stream_dma_default_variant(int maxt, int nct) { return (nct == 2 && maxt >= 5) ? 2 : (nct > 6 ? 1 : 0); }
 // K-chunk: 128 columns; 256 for single-tile workgroups on long rows (w2: 37.5 -> 34.9 us).  Longer chunks (a whole 1 KB of ONE row per
 // load instruction, more bytes in flight) measured slower on the other 7B shapes, and a chunk-major copy of the weights (contiguous
 // runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02c_stream_mm_check.txt.
@@ -626,7 +645,8 @@ static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name)
         const int ve = stream_dma_variant_env();
         if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
     }
-    return launch_stream_kc<MAXT, NCT>(ctx, a, name);
+    if constexpr (NCT > 6) return ST_NA;   // (k_stream_mm2 holds MAXT x NCT accumulator tiles per wave: up to six column tiles)
+    else return launch_stream_kc<MAXT, NCT>(ctx, a, name);
 }
 template <int MAXT>
 static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
@@ -636,7 +656,8 @@ static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if (a.n <= 64) return launch_stream_nct<MAXT, 4>(ctx, a, name);
     if constexpr (MAXT <= 6) {   // (8 x 5 / 8 x 6 accumulator tiles do not fit the registers: those launches take the tile GEMM)
         if (a.n <= 80) return launch_stream_nct<MAXT, 5>(ctx, a, name);
-        return launch_stream_nct<MAXT, 6>(ctx, a, name);
+        if (a.n <= 96) return launch_stream_nct<MAXT, 6>(ctx, a, name);
+        return launch_stream_nct<MAXT, 8>(ctx, a, name);   // 97..128 rows (round 4): eight column tiles, fp32 weights only
     }
     return ST_NA;
 }
@@ -938,6 +959,7 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
     rc = plan_ensure_rows(p, 1);
     if (rc) { plan_destroy(p); return rc; }
+    p->hist.assign(md.ctx, Plan::HIST_UNKNOWN);
     if (md.ctx > 256 && md.hd == 128) {   // long contexts: decode attention split over the keys (k_attention_split)
         const size_t nch = (md.ctx + ATT_TC - 1) / ATT_TC;
         e = hipMalloc((void**)&p->attn_part, (size_t)md.H * nch * (md.hd + 2) * 4);
@@ -1119,11 +1141,73 @@ static int upload_step_params(Plan* p, uint32_t slot, uint32_t token, uint32_t p
     return 0;
 }
 
+bool swap_refeed_tokens(const Plan* p, uint32_t past, uint32_t pending, std::vector<uint32_t>* out) {
+    out->clear();
+    if (p->keep > past) return false;
+    const uint32_t n = (past - p->keep) / 2;
+    if (n == 0) return true;
+    for (uint32_t i = 0; i + 1 < n; ++i) {              // the n - 1 newest evaluated tokens ...
+        const uint32_t t = p->hist[past - (n - 1) + i];
+        if (t == Plan::HIST_UNKNOWN) return false;
+        out->push_back(t);
+    }
+    out->push_back(pending);                            // ... and the pending one, which lastNTokens already holds
+    return true;
+}
+
+// n_steps resident decode steps (greedy: slots G_ADV*, sampled: G_SMP*) from the state in sp_dev[0] = {token, past, step}, with the reference's
+// context swap whenever the window is full (server.go:160-172): the host then learns the ids produced so far (one synchronisation per
+// (ctx - keep) / 2 tokens), re-feeds the run as ONE Eval at position keep and goes on.  first_token / past / step0 = what sp_dev[0] holds at
+// entry; the ids produced by step i land in out_tokens_dev[step0 + i].  *past_io returns the position behind the last evaluated token.
+static int resident_steps_swapping(Plan* p, uint32_t first_token, uint32_t* past_io, uint32_t step0, uint32_t n_steps, bool sampled) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& md = p->md;
+    const int slot1 = sampled ? Plan::G_SMP1 : Plan::G_ADV1, slotn = sampled ? Plan::G_SMPN : Plan::G_ADVN;
+    uint32_t past = *past_io, done = 0, pending = first_token;
+    int rc;
+    std::vector<uint32_t> got, refeed;
+    // records the tokens evaluated by steps [from, done): step j evaluated (j == 0 ? first_token : the id step j - 1 produced) at position pos0 + (j - from)
+    auto learn = [&](uint32_t from, uint32_t pos0) -> int {
+        if (done == 0) return 0;
+        got.resize(done);
+        LH_HIP(ctx, hipMemcpyAsync(got.data(), p->out_tokens_dev + step0, (size_t)done * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t j = from; j < done; ++j) p->record(pos0 + (j - from), j == 0 ? first_token : got[j - 1]);
+        pending = got[done - 1];
+        return 0;
+    };
+    uint32_t seg_from = 0, seg_pos0 = past;
+    while (done < n_steps) {
+        if (past >= md.ctx) {
+            if ((rc = learn(seg_from, seg_pos0))) return rc;
+            if (p->keep >= md.ctx) LH_FAIL(ctx, LH_EINVAL, "context swap: KeepCount %u leaves no room in a window of %u", p->keep, md.ctx);
+            if (!swap_refeed_tokens(p, past, pending, &refeed))
+                LH_FAIL(ctx, LH_EINVAL, "context swap at position %u: the tokens of the window are not known to this context (evaluate the prompt through it first)", past);
+            if (!refeed.empty() && (rc = plan_eval(p, refeed.data(), nullptr, nullptr, (uint32_t)refeed.size(), p->keep, true))) return rc;
+            past = p->keep + (uint32_t)refeed.size();
+            if ((rc = upload_step_params(p, 0, pending, past, step0 + done))) return rc;
+            seg_from = done; seg_pos0 = past;
+        }
+        const uint32_t k = std::min(n_steps - done, md.ctx - past);
+        if (p->use_graph) {
+            if ((rc = launch_resident_steps(p, k, slot1, slotn))) return rc;
+        } else {
+            for (uint32_t s2 = 0; s2 < k; ++s2)
+                if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, sampled ? 2 : 1, nullptr))) return rc;
+        }
+        done += k; past += k;
+    }
+    if ((rc = learn(seg_from, seg_pos0))) return rc;   // (also the synchronisation the callers' host copies wait for)
+    *past_io = past;
+    return 0;
+}
+
 int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     if (past >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: position %u outside the context window of %u", past, m.ctx);
     if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "plan_decode_step needs a whole-model plan");
+    p->record(past, token);
     int rc;
     if (p->use_graph) {
         if ((rc = ensure_decode_graph(p, Plan::G_STEP))) return rc;
@@ -1149,7 +1233,7 @@ static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n
 bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     const ModelDesc& m = p->md;
     if (n < 2 || n > BATCH_ROWS_MAX) return false;
-    if (n <= GEMV_ROWS_MAX && rows_path_ok(p->ctx, m)) return true;   // two to four rows ride the decode stream itself (fp32 and block-int8)
+    if (rows_path_ok(p->ctx, m, n)) return true;   // two to eight (block-int8: four) rows ride the decode stream itself
     // block-int8 on the stream kernel: from 3 rows (one pass of the dequantising stream kernel costs 4.9 ms on 7B whatever the row count <= 16, a single-row
     // int8 GEMV step 2.04 ms: two rows are faster one after the other - profiles/r03_pods_one_gpu.jsonl)
     if (m.wtype == 7) return q8_stream_ok(p->ctx, m, n, 3);
@@ -1169,6 +1253,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if (m.first_stage())  // Go panics on tokEmbeddings.Data[id*NE[0]:] past the table (ml.go:1748); the GPU must never gather out of range
             for (uint32_t i = 0; i < n; ++i)
                 if (tokens_host[i] >= m.V) LH_FAIL(ctx, LH_EINVAL, "Eval: token id %u at index %u outside the vocabulary of %u", tokens_host[i], i, m.V);
+        if (m.first_stage()) for (uint32_t i = 0; i < n; ++i) p->record(past + i, tokens_host[i]);
     }
     if (!m.first_stage() && !x_in_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: later stage needs the residual stream");
     if (!m.last_stage() && !x_out_dev) LH_FAIL(ctx, LH_EINVAL, "Eval: non-final stage needs an output buffer");
@@ -1181,8 +1266,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         if ((rc = upload_step_params(p, slot, tokens_host ? tokens_host[0] : 0, past, 0))) return rc;
         return enqueue_decode(p, p->sp_dev + slot, x_in_dev, x_out_dev, false, nullptr);
     }
-    if (n <= GEMV_ROWS_MAX && rows_path_ok(ctx, m)) {
-        // ---- 2..4 rows (a prompt of that many tokens, or a tick of that many pods): the decode launches with NC activation rows each
+    if (rows_path_ok(ctx, m, n)) {
+        // ---- 2..8 rows (block-int8: 2..4) (a prompt of that many tokens, or a tick of that many pods): the decode launches with NC activation rows each
         // (kernels_rows.h): 5 launches per layer like the decode step, every row bit-identical to its solo step
         const float* x = p->xa;
         if (m.first_stage()) {
@@ -1767,6 +1852,12 @@ int lh_llama_eval(lh_llama* m, const uint32_t* tokens, uint32_t n, uint32_t past
     return LH_OK;
 }
 
+int lh_llama_set_keep(lh_llama* m, uint32_t keep) {
+    if (!m) return LH_EINVAL;
+    m->plan->keep = keep;
+    return LH_OK;
+}
+
 int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host) {
     if (!m || !n_steps) return LH_EINVAL;
     lh_ctx* ctx = m->ctx;
@@ -1774,17 +1865,13 @@ int lh_llama_decode_greedy(lh_llama* m, uint32_t first_token, uint32_t past, uin
     const ModelDesc& md = p->md;
     LH_HIP(ctx, hipSetDevice(ctx->device));
     if (!md.first_stage() || !md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_greedy needs a whole-model plan");
-    if ((uint64_t)past + n_steps > md.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: past %u + %u steps exceed the context window of %u", past, n_steps, md.ctx);
+    if (past > md.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: position %u outside the context window of %u", past, md.ctx);
     if (first_token >= md.V) LH_FAIL(ctx, LH_EINVAL, "decode: token id %u outside the vocabulary of %u", first_token, md.V);
     int rc;
     if ((rc = ensure_out_tokens(p, n_steps))) return rc;
     if ((rc = upload_step_params(p, 0, first_token, past, 0))) return rc;
-    if (p->use_graph) {
-        if ((rc = launch_resident_steps(p, n_steps, Plan::G_ADV1, Plan::G_ADVN))) return rc;
-    } else {
-        for (uint32_t s = 0; s < n_steps; ++s)
-            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, true, nullptr))) return rc;
-    }
+    // past + n_steps > ctx: the loop swaps context like server.Do does (server.go:160-172) instead of failing
+    if ((rc = resident_steps_swapping(p, first_token, &past, 0, n_steps, false))) return rc;
     if (out_tokens) LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_steps * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, p->logits, (size_t)md.V * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1801,9 +1888,7 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
     if (!prompt || !n_prompt || !n_predict || !out_tokens) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_sample: empty prompt, no tokens to predict or null output");
     if (!md.first_stage() || !md.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_sample needs a whole-model plan");
     if (ring_size == 0) LH_FAIL(ctx, LH_EINVAL, "lh_llama_decode_sample: the lastNTokens ring needs at least one slot (the reference uses CtxSize, server.go:127)");
-    // the reference swaps context when pastCount + len(embd) > CtxSize (server.go:163-172); that re-evaluation is not part of this path
-    if ((uint64_t)n_prompt + n_predict - 1 > md.ctx)
-        LH_FAIL(ctx, LH_EINVAL, "decode: %u prompt + %u predicted tokens exceed the context window of %u", n_prompt, n_predict, md.ctx);
+    if (n_prompt > md.ctx) LH_FAIL(ctx, LH_EINVAL, "decode: a prompt of %u tokens exceeds the context window of %u", n_prompt, md.ctx);
     int rc;
     if ((rc = sample_check(ctx, sp, md.V))) return rc;
     if ((rc = ensure_out_tokens(p, n_predict))) return rc;
@@ -1836,11 +1921,13 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
     if ((rc = upload_step_params(p, 0, 0, n_prompt - 1, 0))) return rc;
     const float* last_row = n_prompt == 1 ? p->logits : p->logits + (size_t)(n_prompt - 1) * md.V;
     if ((rc = sample_launch(ctx, last_row, md.V, p->ss_dev, p->ring_dev, p->sp_dev, p->out_tokens_dev, nullptr, nullptr, nullptr, nullptr, 1, p->smp_topk))) return rc;
-    if (p->use_graph) {
-        if (n_predict > 1 && (rc = launch_resident_steps(p, n_predict - 1, Plan::G_SMP1, Plan::G_SMPN))) return rc;
-    } else {
-        for (uint32_t s = 1; s < n_predict; ++s)
-            if ((rc = enqueue_decode(p, p->sp_dev, nullptr, nullptr, 2, nullptr))) return rc;
+    if (n_predict > 1) {
+        // the first id (entry 0 of the output list) is the first token the resident steps evaluate; past the window the loop swaps context
+        // (server.go:160-172)
+        uint32_t first = 0, past = n_prompt;
+        LH_HIP(ctx, hipMemcpyAsync(&first, p->out_tokens_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = resident_steps_swapping(p, first, &past, 1, n_predict - 1, true))) return rc;
     }
     LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_predict * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -378,6 +378,7 @@ struct llama_context {  // llama.go:83-88
     ml_context* mlctx;
     llama_model* model;
     uint32_t ctxSize;
+    uint32_t keepCount = 0;        // ModelParams.KeepCount llama.go:47
     lh_llama* resident = nullptr;  // plan handle for the device-resident loop / stages (created on demand)
     bool holds_model = false;
 };
@@ -820,20 +821,38 @@ static uint32_t argmax_f32(const float* x, uint32_t n) {  // strict
     return best;
 }
 int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t* out_tokens,
-                       float* step_logits) {  // loop shape of server.Do, server.go:153-217
+                       float* step_logits) {  // loop shape of server.Do, server.go:153-217, one llama.Eval (= one ml_GraphCompute) per token
     uint32_t past = 0;
-    const uint32_t V = m->hp.vocabSize;
+    const uint32_t V = m->hp.vocabSize, ringSize = lctx->ctxSize ? lctx->ctxSize : 1;
+    std::vector<uint32_t> ring(ringSize, 0u), embd;   // lastNTokens: CtxSize zeros (server.go:127-138)
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < n_prompt; i++) ring[pos++ % ringSize] = prompt[i];   // server.go:193-197
     if (llama_Eval(lctx, m, prompt, n_prompt, past)) return 1;
     past += n_prompt;
     for (uint32_t s = 0; s < n_predict; s++) {
         const uint32_t id = argmax_f32(lctx->logits.data(), V);
+        ring[pos++ % ringSize] = id;   // appendToken, server.go:207
         out_tokens[s] = id;
         if (step_logits) memcpy(step_logits + (uint64_t)s * V, lctx->logits.data(), (size_t)V * 4);
         if (s + 1 == n_predict) break;
-        if (llama_Eval(lctx, m, &id, 1, past)) return 1;
-        past += 1;
+        embd.assign(1, id);
+        if (past + 1 > lctx->ctxSize) {   // context swap, server.go:160-172 (lastNTokens already holds id: it is re-fed and then evaluated once more)
+            if (lctx->keepCount > past) { g_err = "llama_GreedyDecode: KeepCount beyond the context"; return 1; }
+            const uint32_t leftCount = past - lctx->keepCount, n = leftCount / 2;
+            past = lctx->keepCount;
+            embd.clear();
+            for (uint32_t i = 0; i < n; i++) embd.push_back(ring[(pos - n + i) % ringSize]);
+            embd.push_back(id);
+        }
+        if (llama_Eval(lctx, m, embd.data(), (uint32_t)embd.size(), past)) return 1;
+        past += (uint32_t)embd.size();
     }
     return 0;
+}
+void llamago_SetKeepCount(llama_context* c, uint32_t keep) {
+    if (!c) return;
+    c->keepCount = keep;
+    if (c->resident) lh_llama_set_keep(c->resident, keep);
 }
 
 // ---- product extensions: device-resident decode loop, kernel timing, pipeline stage -----------------------
@@ -858,7 +877,10 @@ static lh_llama* make_stage(llama_model* m, lh_ctx* hip, lh_buf k_cache, lh_buf 
     return out;
 }
 static lh_llama* resident(llama_context* c) {
-    if (!c->resident) c->resident = make_stage(c->model, c->mlctx->hip, c->K->buf, c->V->buf, c->ctxSize);
+    if (!c->resident) {
+        c->resident = make_stage(c->model, c->mlctx->hip, c->K->buf, c->V->buf, c->ctxSize);
+        if (c->resident) lh_llama_set_keep(c->resident, c->keepCount);
+    }
     return c->resident;
 }
 // ---- sampler (llama.go:455-707) on the device ----------------------------------------------------------------
@@ -974,6 +996,21 @@ int llamago_BatchGreedyDecode(llama_batch* p, const uint32_t* const* prompts, co
     if (lh_batch_decode(p->b, first.data(), n_prompt, n_predict - 1, rest.data(), logits)) return halt_rc(lh_last_error(hip));
     for (uint32_t i = 0; i < B; i++)
         for (uint32_t s2 = 0; s2 + 1 < n_predict; s2++) out[(size_t)i * n_predict + 1 + s2] = rest[(size_t)i * (n_predict - 1) + s2];
+    return 0;
+}
+int llamago_BatchPrompt(llama_batch* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t* ids_out) {
+    if (!p || !prompts || !n_prompt || !ids_out) return halt_rc("llamago_BatchPrompt: bad arguments");
+    lh_ctx* hip = p->mlctx->hip;
+    if (lh_batch_set_sampler(p->b, nullptr, 0, nullptr, nullptr)) return halt_rc(lh_last_error(hip));
+    if (lh_batch_prompt(p->b, prompts, n_prompt, nullptr, nullptr)) return halt_rc(lh_last_error(hip));
+    if (lh_batch_read_ids(p->b, ids_out)) return halt_rc(lh_last_error(hip));
+    return 0;
+}
+int llamago_BatchTick(llama_batch* p, uint32_t* ids_out) {
+    if (!p || !ids_out) return halt_rc("llamago_BatchTick: bad arguments");
+    lh_ctx* hip = p->mlctx->hip;
+    if (lh_batch_stage(p->b, nullptr, nullptr, nullptr, nullptr)) return halt_rc(lh_last_error(hip));
+    if (lh_batch_read_ids(p->b, ids_out)) return halt_rc(lh_last_error(hip));
     return 0;
 }
 

@@ -302,6 +302,12 @@ class Context:
             raise MLError(f"llama_GreedyDecode: {self.ml.last_error()}")
         return list(out), lg
 
+    def SetKeepCount(self, keep):
+        """ModelParams.KeepCount (llama.go:47): what a context swap keeps (server.go:166-167)."""
+        self.ml.lib.llamago_SetKeepCount.restype = None
+        self.ml.lib.llamago_SetKeepCount.argtypes = [VP, c_u32]
+        self.ml.lib.llamago_SetKeepCount(self.h, keep)
+
     def SampleDecode(self, prompt, n_predict, topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=0):
         """server.Do's generation loop (server.go:127-217) with SampleTopPTopK; returns the n_predict sampled ids."""
         toks = (c_u32 * len(prompt))(*[int(t) for t in prompt])
@@ -372,6 +378,10 @@ def _bind_extensions(ml):
     L.llamago_BatchBatched.argtypes = [VP]
     L.llamago_BatchGreedyDecode.restype = C.c_int
     L.llamago_BatchGreedyDecode.argtypes = [VP, C.POINTER(c_u32p), c_u32p, c_u32, c_u32p, c_f32p]
+    L.llamago_BatchPrompt.restype = C.c_int
+    L.llamago_BatchPrompt.argtypes = [VP, C.POINTER(c_u32p), c_u32p, c_u32p]
+    L.llamago_BatchTick.restype = C.c_int
+    L.llamago_BatchTick.argtypes = [VP, c_u32p]
     L.llamago_FreePipeline.restype = None
     L.llamago_FreePipeline.argtypes = [VP]
     L.llamago_PipelineRun.restype = C.c_int
@@ -485,6 +495,24 @@ class Batch:
             raise MLError(f"llamago_BatchGreedyDecode: {self.ml.last_error()}")
         ids = [list(out[i * n_predict:(i + 1) * n_predict]) for i in range(self.pods)]
         return (ids, lg) if want_logits else ids
+
+    def Prompt(self, prompts):
+        """BatchHIP.Prompt (go/ml_hip.go): every pod's prompt as one Eval; returns the id each prompt produced."""
+        assert len(prompts) == self.pods
+        arrs = [(c_u32 * len(p))(*[int(t) for t in p]) for p in prompts]
+        pp = (c_u32p * self.pods)(*[C.cast(a, c_u32p) for a in arrs])
+        nn = (c_u32 * self.pods)(*[len(p) for p in prompts])
+        out = (c_u32 * self.pods)()
+        if self.ml.lib.llamago_BatchPrompt(self.h, pp, nn, out):
+            raise MLError(f"llamago_BatchPrompt: {self.ml.last_error()}")
+        return list(out)
+
+    def Tick(self):
+        """BatchHIP.Tick: one decode step of every pod in one pass over the weights; returns the ids produced."""
+        out = (c_u32 * self.pods)()
+        if self.ml.lib.llamago_BatchTick(self.h, out):
+            raise MLError(f"llamago_BatchTick: {self.ml.last_error()}")
+        return list(out)
 
     def free(self):
         if self.h:

@@ -1,0 +1,149 @@
+"""The context swap of the reference's generation loop (pkg/server/server.go:160-172; the same lines in main.go:188-200):
+
+    if pastCount+uint32(len(embd)) > Params.CtxSize {
+        leftCount := pastCount - Params.KeepCount
+        pastCount = Params.KeepCount
+        embd = append(llama.ExtractTokens(lastNTokens.Move(-int(leftCount/2)), int(leftCount/2)), embd...)
+    }
+
+lastNTokens already holds the pending token when this runs (appendToken precedes `embd = append(embd, id)`, server.go:207-214), so the
+re-fed run ends with that token and the token follows once more.  CPU: the checker's loops (oracle.c eval_pending_token) against a loop
+written here straight from the Go lines, with container/ring's semantics, over the checker's own llama.Eval.  GPU: the product's loops
+(the host loop over ml_GraphCompute, the device-resident greedy and sampling loops, pods in one weight pass) against the checker."""
+import collections
+
+import numpy as np
+import pytest
+
+from llama_go_amd.mlapi import SHAPES, make_hparams
+
+TOL = 1e-4
+MARGIN = 2.5 * TOL
+
+
+def go_loop(ctx, prompt, n_predict, ctx_size, keep):
+    """server.Do, greedy, prompt in one batch: returns (ids, the (tokens, pastCount) of every Eval)."""
+    ring = collections.deque([0] * ctx_size, maxlen=ctx_size)     # ring.New(CtxSize), zeroed; appendToken = overwrite the oldest
+    past, embd, consumed, remained, out, evals = 0, [], 0, n_predict, [], []
+    logits = None
+    while remained > 0:
+        if embd:
+            if past + len(embd) > ctx_size:
+                left = past - keep
+                past = keep
+                embd = list(ring)[ctx_size - left // 2:] + embd    # Move(-n) then n x Next(): the n newest entries, oldest first
+            logits = ctx.Eval(embd, past)
+            evals.append((list(embd), past))
+        past += len(embd)
+        embd = []
+        if consumed < len(prompt):
+            while consumed < len(prompt):
+                embd.append(prompt[consumed])
+                ring.append(prompt[consumed])
+                consumed += 1
+        else:
+            tok = int(np.argmax(logits))                           # greedy = lowest-index argmax
+            ring.append(tok)
+            embd.append(tok)
+            out.append(tok)
+            remained -= 1
+    return out, evals
+
+
+@pytest.mark.parametrize("ctx_size,keep,n_prompt,n_predict", [(16, 0, 5, 40), (16, 3, 5, 40), (12, 0, 12, 20), (9, 8, 4, 15), (8, 7, 3, 10)])
+def test_checker_loop_swaps_like_the_go_lines(oracle, ctx_size, keep, n_prompt, n_predict):
+    hp = make_hparams(**SHAPES["tiny"], ctx=ctx_size)
+    rng = np.random.default_rng(ctx_size * 100 + keep)
+    prompt = [int(t) for t in rng.integers(0, hp.vocabSize, n_prompt)]
+    m = oracle.NewSyntheticModel(hp, 31)
+    c = m.NewContext(ctx_size, 4, False)
+    c.SetKeepCount(keep)
+    ids, _ = c.GreedyDecode(prompt, n_predict)
+    c.free()
+    c2 = m.NewContext(ctx_size, 4, False)
+    want, evals = go_loop(c2, prompt, n_predict, ctx_size, keep)
+    c2.free()
+    m.free()
+    assert ids == want
+    swaps = [e for e in evals[1:] if len(e[0]) != 1 or e[1] == keep]
+    assert swaps, "the case never reached the window's end"
+    for toks, past in evals:
+        assert past + len(toks) <= ctx_size
+    # a swap Eval is (ctx - keep) / 2 re-fed tokens + the pending one at position keep, and the pending token appears twice at its end
+    toks, past = next(e for e in evals[1:] if e[1] == keep and len(e[0]) == (ctx_size - keep) // 2 + 1)
+    assert past == keep and (len(toks) == 1 or toks[-1] == toks[-2])
+
+
+def _streams(lib, hp, seed, prompts, n_predict, ctx_size, keep, int8=False):
+    m = lib.NewSyntheticModel(hp, seed)
+    if int8:
+        m.QuantizeQ8()
+    out, margin = [], np.inf
+    for pr in prompts:
+        c = m.NewContext(ctx_size, 16, False)
+        c.SetKeepCount(keep)
+        ids, lg = c.GreedyDecode(pr, n_predict)
+        c.free()
+        srt = np.sort(lg, axis=-1)
+        margin = min(margin, float(((srt[:, -1] - srt[:, -2]) / np.abs(lg).max(axis=-1)).min()))
+        out.append((ids, lg))
+    m.free()
+    return out, margin
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,ctx_size,keep,n_prompt,n_predict,seed", [("small", 32, 0, 8, 80, 11), ("small", 32, 5, 8, 80, 11), ("tiny", 16, 0, 16, 40, 3), ("small", 24, 23, 4, 30, 11)])
+def test_generation_loops_swap_context_like_the_checker(product, oracle, shape, ctx_size, keep, n_prompt, n_predict, seed):
+    """80 tokens through a window of 32: the host loop (llama_GreedyDecode: one ml_GraphCompute per Eval, the Go shim's route), the
+    device-resident greedy loop and the device-resident sampling loop against the checker's loops."""
+    from llama_go_amd.mlapi import decode_greedy_resident
+    hp = make_hparams(**SHAPES[shape], ctx=ctx_size)
+    rng = np.random.default_rng(ctx_size + keep)
+    prompt = [int(t) for t in rng.integers(0, hp.vocabSize, n_prompt)]
+    out, margin = _streams(oracle, hp, seed, [prompt], n_predict, ctx_size, keep)
+    want, wlg = out[0]
+    if margin <= MARGIN:
+        pytest.fail(f"the checker's own top-2 margin is {margin:.2e}: pick another seed")
+    m = product.NewSyntheticModel(hp, seed)
+    # (1) host loop
+    c = m.NewContext(ctx_size, 1)
+    c.SetKeepCount(keep)
+    ids, lg = c.GreedyDecode(prompt, n_predict)
+    c.free()
+    assert ids == want
+    assert float(np.abs(lg.astype(np.float64) - wlg).max() / np.abs(wlg).max()) <= TOL
+    # (2) resident greedy loop: prompt through the context (so it knows the window's tokens), then n_predict - 1 steps from the first id
+    c = m.NewContext(ctx_size, 1)
+    c.SetKeepCount(keep)
+    first = int(np.argmax(c.Eval(prompt, 0)))
+    rest, _ = decode_greedy_resident(c, first, n_prompt, n_predict - 1)
+    c.free()
+    assert [first] + rest == want
+    # (3) resident sampling loop == the checker's sampling loop with the same seed (top-k 40, temperature 0.8)
+    smp = dict(topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=99)
+    c = m.NewContext(ctx_size, 1)
+    c.SetKeepCount(keep)
+    got = c.SampleDecode(prompt, n_predict, **smp)
+    c.free()
+    m.free()
+    om = oracle.NewSyntheticModel(hp, seed)
+    oc = om.NewContext(ctx_size, 16, False)
+    oc.SetKeepCount(keep)
+    wsmp = oc.SampleDecode(prompt, n_predict, **smp)
+    oc.free()
+    om.free()
+    assert got == wsmp
+
+
+@pytest.mark.gpu
+def test_resident_loop_without_the_windows_tokens_fails_cleanly(product):
+    """A context that never saw the tokens of its window (KV cache filled by someone else) cannot swap: an error at the window's end,
+    not a guess."""
+    from llama_go_amd.mlapi import MLError, decode_greedy_resident
+    hp = make_hparams(**SHAPES["tiny"], ctx=16)
+    m = product.NewSyntheticModel(hp, 3)
+    c = m.NewContext(16, 1)
+    with pytest.raises(MLError, match="not known"):
+        decode_greedy_resident(c, 5, 10, 12)      # positions 0..9 were never evaluated through this context
+    c.free()
+    m.free()

@@ -19,6 +19,7 @@ from llama_go_amd.mlapi import SHAPES, Batch, Pipeline, make_hparams
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+SEED_40 = 5003   # (tools/check_test_margins.py --search 13: 4321 leaves a 1.7e-6 near-tie among the 240 steps)
 
 
 def rel(a, b):
@@ -29,45 +30,69 @@ def make_prompts(rng, vocab, lengths):
     return [[int(t) for t in rng.integers(0, vocab, n)] for n in lengths]
 
 
+MARGIN = 2.5 * TOL   # a greedy id is only a function of the logits where the top two differ by more than both may move (tolerance each)
+
+
+class CheckerStreams:
+    """Every stream alone on the checker: its ids, the logits of its last step, and the smallest top-2 margin over ALL its steps."""
+
+    def __init__(self, oracle, hp, seed, prompts, n_predict, ctx, int8=False):
+        om = oracle.NewSyntheticModel(hp, seed)
+        if int8:
+            om.QuantizeQ8()
+        self.ids, last, self.margin = [], [], np.inf
+        for pr in prompts:
+            oc = om.NewContext(ctx, 16, False)
+            t, lg = oc.GreedyDecode(pr, n_predict)
+            oc.free()
+            self.ids.append(list(t))
+            last.append(lg[-1])
+            srt = np.sort(lg, axis=-1)
+            self.margin = min(self.margin, float(((srt[:, -1] - srt[:, -2]) / np.abs(lg).max(axis=-1)).min()))
+        om.free()
+        self.last = np.stack(last)
+
+    def assert_ids(self, got, what=""):
+        """Token ids are asserted UNCONDITIONALLY: a configuration whose checker run has a near-tie is a broken test, not a skipped one
+        (tools/check_test_margins.py picks the seeds)."""
+        if self.margin <= MARGIN:
+            pytest.fail(f"the checker's own top-2 margin is {self.margin:.2e} <= {MARGIN:.1e} at some step: pick another seed (tools/check_test_margins.py)")
+        assert got == self.ids, what
+
+
 def oracle_streams(oracle, hp, seed, prompts, n_predict, ctx, int8=False):
-    om = oracle.NewSyntheticModel(hp, seed)
-    if int8:
-        om.QuantizeQ8()
-    ids, last = [], []
-    for pr in prompts:
-        oc = om.NewContext(ctx, 16, False)
-        t, lg = oc.GreedyDecode(pr, n_predict)
-        oc.free()
-        ids.append(list(t))
-        last.append(lg[-1])
-    om.free()
-    return ids, np.stack(last)
+    return CheckerStreams(oracle, hp, seed, prompts, n_predict, ctx, int8)
 
 
-def margins_ok(lg):
-    s = np.sort(lg, axis=-1)
-    return float(((s[..., -1] - s[..., -2]) / np.abs(lg).max(axis=-1)).min()) > 10 * TOL
-
-
-@pytest.mark.parametrize("shape,layers,int8,lengths", [
-    ("tiny", None, False, [4, 1, 11, 2, 7]),
-    ("tiny", None, True, [4, 1, 11, 2, 7]),
-    ("small", None, False, [3, 9]),                               # two rows: the smallest batch (decode stream with two activation rows)
-    ("small", None, False, [5, 2, 8]),                            # three rows (four-row instantiation, one idle)
-    ("7B", 2, False, [3, 1, 4, 2]),                               # four rows on the 7B launches
-    ("small", None, True, [3, 9]),                                # block-int8, two rows (int8 decode stream with two activation rows)
-    ("7B", 2, True, [3, 1, 4, 2]),
-    ("small", None, True, [3, 9, 1]),
-    ("small", None, False, list(range(1, 18))),                   # 17 rows: two column tiles, K-split wo / w2
-    ("small", None, True, list(range(1, 18))),
-    ("7B", 2, False, [8, 3, 1, 5, 2, 9, 4, 6]),                   # the 7B launches (8 rows, folded norm)
-    ("7B", 2, True, [8, 3, 1, 5, 2, 9, 4, 6]),
-    ("7B", 2, False, [1 + (i % 5) for i in range(24)]),           # 24 rows
-    ("7B", 2, False, [1 + (i % 7) for i in range(40)]),           # 40 rows: three column tiles
-    ("7B", 2, True, [1 + (i % 7) for i in range(40)]),
-    ("7B", 2, False, [1 + (i % 3) for i in range(64)]),           # 64 rows: four column tiles, half-length chunks
+@pytest.mark.parametrize("shape,layers,int8,lengths,seed", [
+    ("tiny", None, False, [4, 1, 11, 2, 7], 4321),
+    ("tiny", None, True, [4, 1, 11, 2, 7], 4321),
+    ("small", None, False, [3, 9], 4321),                               # two rows: the smallest batch (decode stream with two activation rows)
+    ("small", None, False, [5, 2, 8], 4321),                            # three rows (four-row instantiation, one idle)
+    ("7B", 2, False, [3, 1, 4, 2], 4321),                               # four rows on the 7B launches
+    ("small", None, True, [3, 9], 5000),                                # block-int8, two rows (int8 decode stream with two activation rows)
+    ("7B", 2, True, [3, 1, 4, 2], 4321),
+    ("small", None, True, [3, 9, 1], 4321),
+    ("small", None, False, list(range(1, 18)), 4321),                   # 17 rows: two column tiles, K-split wo / w2
+    ("small", None, True, list(range(1, 18)), 4321),
+    ("7B", 2, False, [8, 3, 1, 5, 2, 9, 4, 6], 4321),                   # the 7B launches, 8 rows (the decode stream with eight activation rows)
+    ("7B", 2, True, [8, 3, 1, 5, 2, 9, 4, 6], 5000),                    #   block-int8: the dequantising stream kernel, folded norm
+    ("7B", 2, False, [1 + (i % 5) for i in range(24)], 4321),           # 24 rows
+    ("7B", 2, False, [1 + (i % 7) for i in range(40)], SEED_40),        # 40 rows: three column tiles
+    ("7B", 2, True, [1 + (i % 7) for i in range(40)], 5000),
+    ("7B", 2, False, [1 + (i % 3) for i in range(64)], 4321),           # 64 rows: four column tiles
+    # both sides of every launch-shape boundary of the P-row kernels (the configurations above sit inside the ranges)
+    ("7B", 2, False, [1 + (i % 4) for i in range(5)], 4321),            # 5 rows: first count past the four-row instantiation
+    ("7B", 2, False, [1 + (i % 4) for i in range(9)], 4321),            # 9 rows: first count on the MFMA stream kernel (folded norm)
+    ("7B", 2, False, [1 + (i % 4) for i in range(16)], 4321),           # 16 / 17 rows: one / two column tiles (folded norm / LDS-DMA loaders)
+    ("7B", 2, False, [1 + (i % 4) for i in range(17)], 4321),
+    ("7B", 2, False, [1 + (i % 4) for i in range(32)], 5001),           # 32 / 33 rows: two / three column tiles
+    ("7B", 2, False, [1 + (i % 4) for i in range(33)], 5000),
+    ("7B", 2, False, [1 + (i % 4) for i in range(48)], 4321),           # 48 / 49 rows: three / four column tiles
+    ("7B", 2, False, [1 + (i % 4) for i in range(49)], 4321),
+    ("7B", 2, True, [1 + (i % 4) for i in range(48)], 4321),            # block-int8 at its last batched row count
 ])
-def test_batched_decode_equals_every_stream_alone(product, oracle, shape, layers, int8, lengths):
+def test_batched_decode_equals_every_stream_alone(product, oracle, shape, layers, int8, lengths, seed):
     kw = dict(SHAPES[shape])
     if layers:
         kw["layers"] = layers
@@ -75,7 +100,7 @@ def test_batched_decode_equals_every_stream_alone(product, oracle, shape, layers
     hp = make_hparams(**kw, ctx=ctx)
     rng = np.random.default_rng(len(lengths) * 131 + int(int8))
     prompts = make_prompts(rng, kw["vocab"], lengths)
-    m = product.NewSyntheticModel(hp, 4321)
+    m = product.NewSyntheticModel(hp, seed)
     if int8:
         m.QuantizeQ8()
     b = Batch(m, ctx, len(prompts))
@@ -84,11 +109,10 @@ def test_batched_decode_equals_every_stream_alone(product, oracle, shape, layers
     ids2 = b.GreedyDecode(prompts[::-1], n_predict)     # the same batch object again, rows permuted: state fully reset, captured tick reused
     b.free()
     m.free()
-    want, wlg = oracle_streams(oracle, hp, 4321, prompts, n_predict, ctx, int8)
-    assert rel(lg, wlg) <= TOL
-    if margins_ok(wlg):
-        assert ids == want
-        assert ids2 == want[::-1]
+    want = oracle_streams(oracle, hp, seed, prompts, n_predict, ctx, int8)
+    assert rel(lg, want.last) <= TOL
+    want.assert_ids(ids)
+    want.assert_ids(ids2[::-1], "rows permuted")
 
 
 def test_row_results_do_not_depend_on_the_neighbours(product):
@@ -111,11 +135,12 @@ def test_row_results_do_not_depend_on_the_neighbours(product):
     assert ids_b2[0] == ids[1]
 
 
-@pytest.mark.parametrize("int8", [False, True])
-@pytest.mark.parametrize("lengths", [[6, 2], [6, 2, 9], [1, 7, 3, 5]])
-def test_ticks_of_two_to_four_pods_are_bit_identical_to_solo_decode(product, lengths, int8):
-    """2..4 rows ride the decode weight stream itself (k_gemv_rows / k_gemv_q8_rows: k_gemv_sa's / k_gemv_q8s' arithmetic per activation
-    row): a pod's logits are BIT-identical to those of its solo run (llama.Eval per token on its own context), not merely within tolerance."""
+@pytest.mark.parametrize("lengths,int8", [([6, 2], False), ([6, 2, 9], False), ([1, 7, 3, 5], False), ([6, 2], True), ([6, 2, 9], True), ([1, 7, 3, 5], True),
+                                          ([1, 7, 3, 5, 2], False), ([4, 1, 6, 2, 9, 3], False), ([4, 1, 6, 2, 9, 3, 5], False), ([2, 8, 1, 5, 3, 7, 4, 6], False)])
+def test_ticks_of_two_to_eight_pods_are_bit_identical_to_solo_decode(product, lengths, int8):
+    """2..8 rows (block-int8: 2..4) ride the decode weight stream itself (k_gemv_rows / k_gemv_q8_rows: k_gemv_sa's / k_gemv_q8s' arithmetic per
+    activation row): a pod's logits are BIT-identical to those of its solo run (llama.Eval per token on its own context), not merely within
+    tolerance."""
     hp = make_hparams(**SHAPES["small"], ctx=48)
     rng = np.random.default_rng(len(lengths))
     prompts = make_prompts(rng, hp.vocabSize, lengths)
@@ -148,10 +173,9 @@ def test_batched_decode_long_context_split_attention(product, oracle):
     assert b.batched
     b.free()
     m.free()
-    want, wlg = oracle_streams(oracle, hp, 8, prompts, 4, ctx)
-    assert rel(lg, wlg) <= TOL
-    if margins_ok(wlg):
-        assert ids == want
+    want = oracle_streams(oracle, hp, 8, prompts, 4, ctx)
+    assert rel(lg, want.last) <= TOL
+    want.assert_ids(ids)
 
 
 @pytest.mark.parametrize("kw", [
@@ -169,10 +193,9 @@ def test_batched_decode_odd_shapes(product, oracle, kw):
     ids, lg = b.GreedyDecode(prompts, 5, want_logits=True)
     b.free()
     m.free()
-    want, wlg = oracle_streams(oracle, hp, 3, prompts, 5, ctx)
-    assert rel(lg, wlg) <= TOL
-    if margins_ok(wlg):
-        assert ids == want
+    want = oracle_streams(oracle, hp, 3, prompts, 5, ctx)
+    assert rel(lg, want.last) <= TOL
+    want.assert_ids(ids)
 
 
 @pytest.mark.parametrize("int8", [False, True])
@@ -194,10 +217,9 @@ def test_pipeline_groups_streams_into_one_weight_pass(product, oracle, int8):
         got[mr] = [pl.tokens(i) for i in range(len(prompts))]
         pl.free()
     m.free()
-    want, wlg = oracle_streams(oracle, hp, 17, prompts, 6, 40, int8)
-    if margins_ok(wlg):
-        for mr in got:
-            assert got[mr] == want, mr
+    want = oracle_streams(oracle, hp, 17, prompts, 6, 40, int8)
+    for mr in got:
+        want.assert_ids(got[mr], mr)
     assert got[0] == got[4]
 
 
@@ -228,6 +250,56 @@ def test_pipeline_samples_like_the_solo_loop(product, oracle):
         oc.free()
         assert got[i] == want, i
     om.free()
+
+
+def test_ticks_never_leave_the_context_window(product):
+    """lh_batch_stage (BatchHIP.Tick) is an Eval entry point like every other: a tick whose row would stand at position ctx is refused
+    with an error before anything is enqueued - the tick kernels index the row's KV cache and the RoPE table by that position."""
+    from llama_go_amd.mlapi import MLError
+    ctx = 12
+    hp = make_hparams(**SHAPES["tiny"], ctx=ctx)
+    m = product.NewSyntheticModel(hp, 5)
+    b = Batch(m, ctx, 3)
+    prompts = [[1, 2, 3], [4] * (ctx - 2), [7, 8]]          # row 1 stands at position ctx - 2 behind its prompt
+    b.Prompt(prompts)
+    ids1 = b.Tick()                                          # positions 3, ctx - 2, 2 -> row 1 now at ctx - 1
+    ids2 = b.Tick()                                          # row 1 evaluates position ctx - 1: the last legal one
+    assert len(ids1) == 3 and len(ids2) == 3
+    with pytest.raises(MLError, match="context window"):
+        b.Tick()                                             # row 1 would evaluate position ctx
+    with pytest.raises(MLError, match="context window"):
+        b.Tick()                                             # ... and the refusal left the batch where it was
+    # the batch is still usable: new prompts reset every row, and the results are those of a fresh batch
+    again = b.GreedyDecode([[1, 2, 3], [4, 4], [7, 8]], 4)
+    b.free()
+    b2 = Batch(m, ctx, 3)
+    fresh = b2.GreedyDecode([[1, 2, 3], [4, 4], [7, 8]], 4)
+    b2.free()
+    # a prompt may fill the window exactly (Eval's pastCount + N <= CtxSize); the first tick behind it is the error
+    b3 = Batch(m, ctx, 2)
+    b3.Prompt([[5] * ctx, [6, 7]])
+    with pytest.raises(MLError, match="context window"):
+        b3.Tick()
+    b3.free()
+    m.free()
+    assert again == fresh
+
+
+def test_batches_come_and_go(product):
+    """200 x { lh_batch_create -> prompts -> two ticks -> destroy } over one model: every cycle decodes the ids of the first (the create path once
+    raced its own zero fill of the row table: a null KV-cache pointer in roughly one of forty two-rank runs, round 3)."""
+    hp = make_hparams(**SHAPES["tiny"], ctx=24)
+    m = product.NewSyntheticModel(hp, 77)
+    rng = np.random.default_rng(4)
+    prompts = make_prompts(rng, hp.vocabSize, [3, 1, 6, 2, 4])
+    want = None
+    for cycle in range(200):
+        b = Batch(m, 24, len(prompts))
+        ids = b.GreedyDecode(prompts, 3)
+        b.free()
+        want = want or ids
+        assert ids == want, cycle
+    m.free()
 
 
 def test_batch_argument_errors(product):

@@ -17,6 +17,7 @@ from llama_go_amd.mlapi import PROMPT, SHAPES, make_hparams
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+MARGIN = 2.5 * TOL   # ids are asserted only where the checker itself is not at a near-tie; a near-tie FAILS the test (pick another seed)
 
 
 def rel(a, b):
@@ -69,8 +70,8 @@ def test_odd_shapes_match_oracle(product, oracle, kw, ctx, n_prompt):
         m.free()
     (th, lh_), (to, lo) = res["hip"], res["orc"]
     assert rel(lh_, lo) <= TOL
-    if greedy_margin(lo) > 10 * TOL:
-        assert th == to
+    assert greedy_margin(lo) > MARGIN, "the checker's own logits have a near-tie: pick another seed (tools/check_test_margins.py)"
+    assert th == to
 
 
 @pytest.mark.parametrize("kw,ctx,n_prompt", [
@@ -91,8 +92,8 @@ def test_odd_shapes_block_int8(product, oracle, kw, ctx, n_prompt):
         m.free()
     (th, lh_), (to, lo) = res["hip"], res["orc"]
     assert rel(lh_, lo) <= TOL
-    if greedy_margin(lo) > 10 * TOL:
-        assert th == to
+    assert greedy_margin(lo) > MARGIN, "the checker's own logits have a near-tie: pick another seed (tools/check_test_margins.py)"
+    assert th == to
 
 
 @pytest.mark.parametrize("n_prompt", [8, 40, 100, 300])
@@ -481,19 +482,21 @@ def test_7b_shape_slice_matches_oracle(product, oracle, layers):
     assert toks_h == toks_o
 
 
-@pytest.mark.parametrize("n_prompt", [12, 24, 40, 56, 72, 90])
+@pytest.mark.parametrize("n_prompt", [3, 6, 8, 12, 24, 40, 56, 72, 90, 97, 112, 127, 128, 129])
 def test_7b_shape_slice_short_prompts_match_oracle(product, oracle, n_prompt):
-    """The 7B layer shape at the prompt lengths where the stream kernel changes its launch shape: 12 rows (RMSNorm folded into the
-    GEMMs), 24 rows (two column tiles; wo / w2 as K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles),
-    56 rows (four column tiles on half-length K-chunks), 72 / 90 rows (five / six column tiles) - 2 layers, then 2 decode steps on the cache
-    the prompt wrote."""
+    """The 7B layer shape at the prompt lengths where the launch shape changes: 3 / 6 / 8 rows (the decode weight stream with four / eight
+    activation rows), 12 rows (MFMA stream kernel, RMSNorm folded into the GEMMs), 24 rows (two column tiles, LDS-DMA loader waves; wo / w2 as
+    K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles), 56 rows (four), 72 / 90 rows (five / six),
+    97 / 112 / 127 / 128 rows (eight column tiles, MFMA waves as 2 K-groups x 2 column halves), 129 rows (the tile GEMM) - 2 layers, then 2
+    decode steps on the cache the prompt wrote."""
     rng = np.random.default_rng(100 + n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["7B"]["vocab"], n_prompt)]
-    out = decode_both(product, oracle, "7B", 64 if n_prompt <= 56 else 128, prompt, 3, layers=2, threads=64)
+    out = decode_both(product, oracle, "7B", 64 if n_prompt <= 56 else (128 if n_prompt <= 120 else 192), prompt, 3, layers=2, threads=64)
     toks_h, lg_h = out["hip"]
     toks_o, lg_o = out["orc"]
     assert out["fused"] == 1
     assert rel(lg_h, lg_o) <= TOL
+    assert greedy_margin(lg_o) > MARGIN, "the checker's own logits have a near-tie: pick another prompt seed (tools/check_test_margins.py)"
     assert toks_h == toks_o
 
 

@@ -60,10 +60,10 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
     }
 }
 static int g_v2 = 0, g_dma = 0, g_nimg = 3, g_pipe = 0;
-template <int MAXT, int NCT, int KC, int NIMG, bool PIPE> static void run_dma_img(const StreamArgs& a, int nCU) {
+template <int MAXT, int NCT, int KC, int NIMG, bool PIPE, int CS = 1> static void run_dma_img(const StreamArgs& a, int nCU) {
     const size_t lds = stream_dma_lds_bytes(MAXT, NCT, KC, NIMG);
     if (lds > 160 * 1024) { printf("k_stream_dma<%d,%d,%d,%d>: images do not fit (%zu B)\n", MAXT, NCT, KC, NIMG, lds); return; }
-    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG, PIPE>;
+    auto kern = k_stream_dma<MAXT, NCT, KC, NIMG, PIPE, CS>;
     const size_t req = std::max<size_t>(lds, 82 * 1024);   // one workgroup per CU
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)req));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -72,6 +72,10 @@ template <int MAXT, int NCT, int KC, int NIMG, bool PIPE> static void run_dma_im
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    { unsigned long long tr[64]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost));
+      const double mf = (double)(a.K / KC / (a.ksplit > 1 ? a.ksplit : 1)) * (KC / 16 / (4 / CS)) * 4 * MAXT * (NCT / CS);   // MFMAs of one wave's main loop
+      if (tr[41]) printf("   MFMA wave: %.0f shader clocks in %.2f us = %.2f GHz; %.0f MFMAs x 32 clocks = %.0f%% of them\n", (double)tr[40], tr[41] / 100.0, tr[40] / (tr[41] * 10.0), mf,
+                         100.0 * mf * 32 / (double)tr[40]); }
     printf("k_stream_dma<%d,%d,%d> with %d images%s%s: %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, NIMG, PIPE ? ", pipelined operands" : "", a.ksplit > 1 ? ", K-split" : "", ms * 200,
            (double)a.M * a.K * 4.0 / (ms * 200) / 1e3);
     if (a.ksplit > 1) {
@@ -85,8 +89,11 @@ template <int MAXT, int NCT, int KC, int NIMG, bool PIPE> static void run_dma_im
     }
 }
 template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const StreamArgs& a, int nCU) {
-    if constexpr (NCT >= 2) {
-        constexpr bool POK = MAXT * NCT * 4 + 2 * (MAXT + NCT) * 4 * (KC / 64) <= 200;   // (plan.hip: dma_pipe_ok)
+    if constexpr (NCT == 8) {   // eight column tiles: 2 K-groups x 2 column halves, 64-column chunks, pipelined
+        if constexpr (KC == 64 && MAXT <= 6) { if (g_pipe) run_dma_img<MAXT, NCT, KC, NIMG, true, 2>(a, nCU); else run_dma_img<MAXT, NCT, KC, NIMG, false, 2>(a, nCU); }
+        else printf("k_stream_dma: eight column tiles run 64-column chunks, up to six row tiles\n");
+    } else if constexpr (NCT >= 2) {
+        constexpr bool POK = MAXT * NCT * 4 + 2 * (MAXT + NCT) * 4 <= 210;   // (plan.hip: dma_pipe_ok)
         if constexpr (POK) { if (g_pipe) { run_dma_img<MAXT, NCT, KC, NIMG, true>(a, nCU); return; } }
         else if (g_pipe) { printf("k_stream_dma<%d,%d,%d>: two operand sets do not fit the registers\n", MAXT, NCT, KC); return; }
         run_dma_img<MAXT, NCT, KC, NIMG, false>(a, nCU);
@@ -96,12 +103,15 @@ template <int MAXT, int NCT, int KC> static void run_dma(const StreamArgs& a, in
     if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
 }
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
+    if constexpr (NCT == 8) { run_dma<MAXT, NCT, 64>(a, nCU); return; }   // (mode 4 only: the other kernels hold MAXT x NCT tiles per wave)
+    else {
     if (g_dma) { if (g_kc == 64) run_dma<MAXT, NCT, 64>(a, nCU); else run_dma<MAXT, NCT, 128>(a, nCU); return; }
     if (g_v2) { if (g_kc >= 256) run2_kc<MAXT, NCT, 256>(a, nCU); else if (g_kc == 64) run2_kc<MAXT, NCT, 64>(a, nCU); else run2_kc<MAXT, NCT, 128>(a, nCU); return; }
     constexpr int R = MAXT + NCT;
     if (g_kc == 512 && R * 512 <= 2048) run_kc<MAXT, NCT, (R * 512 <= 2048 ? 512 : 128)>(a, nCU);
     else if (g_kc >= 256 && R * 256 <= 2048) run_kc<MAXT, NCT, (R * 256 <= 2048 ? 256 : 128)>(a, nCU);
     else run_kc<MAXT, NCT, 128>(a, nCU);
+    }
 }
 int main(int argc, char** argv) {
     const uint32_t M = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 33;
@@ -143,7 +153,7 @@ int main(int argc, char** argv) {
     if (getenv("STREAM_WGPCU")) g_wgpcu = atoi(getenv("STREAM_WGPCU")) == 2 ? 2 : 1;
     const uint32_t T = M / 16, ngrp = (uint32_t)(nCU * g_wgpcu) / S, maxt = (T + ngrp - 1) / ngrp;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
-#define GO(MT) { if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64 && N > 80 && MT <= 6) run<(MT <= 6 ? MT : 6), 6>(a, nCU); else if (g_v2 && g_kc == 64 && N > 64 && MT <= 6) run<(MT <= 6 ? MT : 6), 5>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
+#define GO(MT) { if (g_dma && N > 96) run<(MT <= 6 ? MT : 6), 8>(a, nCU); else if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64 && N > 80 && MT <= 6) run<(MT <= 6 ? MT : 6), 6>(a, nCU); else if (g_v2 && g_kc == 64 && N > 64 && MT <= 6) run<(MT <= 6 ? MT : 6), 5>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
     if (getenv("STREAM_CHECK_SKIP")) return 0;   // timing-only runs (the -DSTREAM_PROBE builds compute wrong sums on purpose)
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
@@ -151,7 +161,8 @@ int main(int argc, char** argv) {
     std::vector<double> blk((size_t)T * CT, 0.0);
     for (uint32_t c = 0; c < N; ++c) for (uint32_t r = 0; r < M; ++r) {
         double ref = 0; for (uint32_t k = 0; k < K; ++k) ref += (double)W[(size_t)r * K + k] * X[(size_t)c * K + k];
-        const double e = fabs(ref - Y[(size_t)c * M + r]); worst = e > worst ? e : worst;
+        double e = fabs(ref - Y[(size_t)c * M + r]); if (!(e == e)) e = 1e30;   // a NaN (unwritten output) is an error, not a pass
+        worst = e > worst ? e : worst;
         double& b = blk[(size_t)(r / 16) * CT + c / 16]; b = e > b ? e : b;
     }
     printf("max abs err %.3e (values ~ %.1f)\nblock map (rows = 16-row tiles, columns = 16-column tiles; x = wrong):\n", worst, sqrt((double)K) / 3);
