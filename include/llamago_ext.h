@@ -64,6 +64,7 @@ int llamago_BatchGreedyDecode(llama_batch* b, const uint32_t* const* prompts, co
 /* The twins of the Go shim's BatchHIP.Prompt / BatchHIP.Tick (go/ml_hip.go): every pod's prompt as one Eval / one decode step of every pod
  * in one pass over the weights; ids_out[pods] = the ids produced.  A tick that would leave a pod's context window is an error
  * (llama.Eval's pastCount + N <= CtxSize), never a write past its KV cache. */
+void llamago_BatchSetKeepCount(llama_batch* b, uint32_t keep);   /* ModelParams.KeepCount of every pod (see llamago_SetKeepCount) */
 int llamago_BatchPrompt(llama_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t* ids_out);
 int llamago_BatchTick(llama_batch* b, uint32_t* ids_out);
 

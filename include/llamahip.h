@@ -217,7 +217,12 @@ int lh_batch_stage(lh_batch* b, const float* x_in_dev, float* x_out_dev, float* 
  * already appended to row i's lastNTokens ring of ring_size slots (the prompt, server.go:193-197).  sp = NULL: back to greedy. */
 int lh_batch_set_sampler(lh_batch* b, const lh_sample_params* sp, uint32_t ring_size, const uint32_t* const* ring_init, const uint32_t* n_init);
 /* Whole-model pods: n_steps device-resident ticks from (first_tokens[i], past[i]); out_tokens[i * n_steps + s] = id row i
- * produced at step s; logits_last_host (optional) = [rows][vocab] logits of the final tick. */
+ * produced at step s; logits_last_host (optional) = [rows][vocab] logits of the final tick.
+ * Context swap: a tick (here and in lh_batch_stage) of a WHOLE-MODEL batch whose row stands at the window's end first swaps that row's
+ * context as server.Do does (server.go:160-172, lh_llama_set_keep per pod): the re-fed run is evaluated as one Eval on the row's own
+ * cache, then the tick takes the row's pending token behind it.  It needs the tokens of the row's window, which the batch knows when the
+ * row's prompt ran through lh_batch_prompt (or its Evals through its lh_llama with host ids); otherwise, and for a stage of a layer shard,
+ * such a tick fails with LH_EINVAL before anything is enqueued. */
 int lh_batch_decode(lh_batch* b, const uint32_t* first_tokens, const uint32_t* past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last_host);
 
 /* ---- multi-GPU: layer shard over RCCL point-to-point ------------------------------------------------

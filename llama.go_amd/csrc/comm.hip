@@ -378,7 +378,11 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
     for (uint32_t p = 0; p < P; ++p) {
         const uint32_t np = prefill ? n_prompt[p] : 0;
         if (prefill && !np) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u has an empty prompt", p);
-        if ((uint64_t)(prefill ? 0 : pl->past[p]) + np + steps > pl->ctx_size) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u would leave the context window of %u", p, pl->ctx_size);
+        if (np > pl->ctx_size) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u: a prompt of %u tokens exceeds the context window of %u", p, np, pl->ctx_size);
+        // an unsharded pipeline swaps context at the window's end like server.Do (server.go:160-172; lh_batch does it per row); across ranks
+        // the re-fed run would have to travel through the stages like a prompt: not built - the run is refused before anything starts
+        if (R > 1 && (uint64_t)(prefill ? 0 : pl->past[p]) + np + steps > pl->ctx_size)
+            LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u would leave the context window of %u (the context swap is built for unsharded pipelines only)", p, pl->ctx_size);
     }
     // what only ONE rank can see (the prompts live on rank 0, and on the last rank of a sampled run): that rank tears the communicator
     // down before it returns, so the others' first receive fails instead of waiting for it
@@ -424,7 +428,15 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
     };
     // ids of a finished unit: a copy into the group's history (what lh_pipeline_tokens reads)
     auto record = [&](Group& gr, const uint32_t* ids_dev) -> int {
-        if (gr.n_hist >= gr.hist_cap) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: id history full");
+        if (gr.n_hist >= gr.hist_cap) {   // streams that swap context outlive the window: the history grows
+            const uint32_t cap2 = gr.hist_cap * 2;
+            uint32_t* h2 = nullptr;
+            LH_HIP(ctx, hipMalloc((void**)&h2, (size_t)cap2 * gr.pods.size() * 4));
+            LH_HIP(ctx, hipMemcpyAsync(h2, gr.hist, (size_t)gr.n_hist * gr.pods.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            LH_HIP(ctx, hipFree(gr.hist));
+            gr.hist = h2; gr.hist_cap = cap2;
+        }
         LH_HIP(ctx, hipMemcpyAsync(gr.hist + (size_t)gr.n_hist * gr.pods.size(), ids_dev, gr.pods.size() * 4, hipMemcpyDeviceToDevice, ctx->stream));
         gr.n_hist++;
         return 0;

@@ -41,6 +41,10 @@ struct Buffer {
     uint32_t rows = 0, cols = 0;
     uint64_t key = 0;
     int device = 0;
+    // a KV cache: the token evaluated at every position, as far as the host knows it (0xFFFFFFFF = unknown).  Lives with the BUFFER so that
+    // every plan over the cache (the graph path's and the resident loop's) sees the same history, and a new cache starts without one;
+    // created on first use (plan.hip: context swap of the generation loops, server.go:160-172).
+    std::shared_ptr<std::vector<uint32_t>> kv_hist;
 };
 
 // Per-device shared state: buffer registry (Model is shared read-only across pods, server.go:45).

@@ -288,6 +288,8 @@ struct Matcher {
         if (!kb || !vb || kb == vb || vb->nfloats != kb->nfloats) return false;
         md.kc = kb->dev;
         md.vc = vb->dev;
+        if (!kb->kv_hist) kb->kv_hist = std::make_shared<std::vector<uint32_t>>();
+        md.kv_hist = kb->kv_hist;   // the cache's token history (context swap of the generation loops): shared by every plan over this buffer
         md.wtype = wtype_seen < 0 ? 0 : wtype_seen;
         if ((uint64_t)past + N > md.ctx) return false;
         return true;

@@ -75,8 +75,48 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
         for (int j = 0; j < KI; ++j) w[u][j] = ld_nt((const f4*)(p + loff[j]));
     }
     if (PRO == PRO_RMSNORM) {
+        // k_gemv_sa's norm (rmsnorm_prologue) for every activation row, the NC reductions side by side and ONE barrier for all of them (row by
+        // row cost a barrier and a dependent f64 reduction chain each: 8 of them in front of every norm launch of an eight-row tick); per row
+        // the same squares, the same f64 lane / wave / cross-wave order, the same two roundings per element -> the same bits
+        double ss[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) rmsnorm_prologue<KI, TH>(xr[c], act, gr, a.K, sred + c * NW);   // k_gemv_sa's norm, row by row (own scratch each)
+        for (int c = 0; c < NC; ++c) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                if (act[j]) {
+                    t += (double)__fmul_rn(xr[c][j].x, xr[c][j].x);
+                    t += (double)__fmul_rn(xr[c][j].y, xr[c][j].y);
+                    t += (double)__fmul_rn(xr[c][j].z, xr[c][j].z);
+                    t += (double)__fmul_rn(xr[c][j].w, xr[c][j].w);
+                }
+            }
+            ss[c] = t;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ss[c] = wave_sum_f64(ss[c]);
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sred[c * NW + wave] = ss[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) tot += sred[c * NW + w2];
+            const float scale = (float)(1.0 / sqrt(tot / (double)a.K + 1e-5));
+#pragma unroll
+            for (int j = 0; j < KI; ++j) {
+                if (act[j]) {
+                    const f4 g = gr[j];
+                    xr[c][j].x = __fmul_rn(g.x, __fmul_rn(xr[c][j].x, scale));
+                    xr[c][j].y = __fmul_rn(g.y, __fmul_rn(xr[c][j].y, scale));
+                    xr[c][j].z = __fmul_rn(g.z, __fmul_rn(xr[c][j].z, scale));
+                    xr[c][j].w = __fmul_rn(g.w, __fmul_rn(xr[c][j].w, scale));
+                }
+            }
+        }
     }
     for (uint32_t r = r0; r < r1; r += U) {
         float acc[U][NC];
@@ -115,14 +155,14 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
         }
     }
     __syncthreads();
-    // ---- epilogue: thread `fin` finishes weight row r0 + fin (or the pair r0 + fin, r0 + fin + 1) for every activation row, cross-wave sums
-    // in wave order (bit-reproducible, the order of gemv_finish)
-    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
-    if (r0 + fin >= r1) return;
-    const uint32_t v = r0 + fin;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if ((uint32_t)c >= a.n) break;
+    // ---- epilogue: work item (weight row or pair `it`, activation row c) -> thread, all items side by side (a thread per weight row looping over
+    // the activation rows left most of the workgroup idle behind up to eight silu / RoPE evaluations in a row); cross-wave sums in wave order
+    // (bit-reproducible, the order of gemv_finish)
+    constexpr uint32_t PER = (EPI == EPI_STORE || EPI == EPI_RESID) ? 1u : 2u;
+    const uint32_t nit = (r1 - r0 + PER - 1) / PER, nwork = nit * a.n;
+    for (uint32_t wk = (uint32_t)tid; wk < nwork; wk += TH) {
+        const uint32_t c = wk / nit, fin = (wk - c * nit) * PER;
+        const uint32_t v = r0 + fin;
         const float* p0 = red + ((size_t)fin * NC + c) * NW;
         float s0 = 0.f;
 #pragma unroll
@@ -140,7 +180,7 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
                 a.y[(size_t)c * a.ldy + (v >> 1)] = __fmul_rn(silu_ref(s0), s1);   // ml.go:2587-2589, 1877-1914 (llama.go:354-361)
             } else {   // EPI_QKV_ROPE: Rope mode 0 on Q / mode 1 on the new K row (ml.go:2253-2328), K, V appended to the row's cache (llama.go:274-278)
                 const uint32_t d = a.d;
-                const uint32_t pos = a.rows ? a.rows[c].pos : a.past + (uint32_t)c;
+                const uint32_t pos = a.rows ? a.rows[c].pos : a.past + c;
                 float* kcb = a.rows ? a.rows[c].kc + a.kv_off : a.k_cache;
                 float* vcb = a.rows ? a.rows[c].vc + a.kv_off : a.v_cache;
                 if (v < 2 * d) {

@@ -27,6 +27,7 @@ struct ModelDesc {
     int wtype = 0;                    // dtype of the weight matrices: 0 = f32, 7 = block-int8 (norms and embeddings stay f32)
     std::vector<LayerW> layers;       // indexed by absolute layer id
     float *kc = nullptr, *vc = nullptr;
+    std::shared_ptr<std::vector<uint32_t>> kv_hist;   // the K cache buffer's token history (Buffer::kv_hist); not part of same()
     bool same(const ModelDesc& o) const {
         return V == o.V && d == o.d && H == o.H && hd == o.hd && L == o.L && F == o.F && ctx == o.ctx && layer0 == o.layer0 && layer1 == o.layer1 &&
                cache_layer0 == o.cache_layer0 && wtype == o.wtype && tok_emb == o.tok_emb && norm == o.norm && output == o.output && kc == o.kc && vc == o.vc && layers == o.layers;
@@ -76,11 +77,11 @@ struct Plan {
     bool use_graph = true;
     // Context swap of the generation loops (pkg/server/server.go:160-172): the token evaluated at every position of this plan's KV cache, as far as
     // the host knows it (first stage; HIST_UNKNOWN elsewhere), and ModelParams.KeepCount (llama.go:47).  Evals with host token ids record
-    // themselves; the resident loops record what they produced when they synchronise.
+    // themselves (through whichever plan over this cache they ran); the resident loops record what they produced when they synchronise.
     static constexpr uint32_t HIST_UNKNOWN = 0xFFFFFFFFu;
-    std::vector<uint32_t> hist;
+    std::shared_ptr<std::vector<uint32_t>> hist;   // shared by every plan over the same KV cache (Buffer::kv_hist)
     uint32_t keep = 0;
-    void record(uint32_t pos, uint32_t tok) { if (pos < hist.size()) hist[pos] = tok; }
+    void record(uint32_t pos, uint32_t tok) { if (hist && pos < hist->size()) (*hist)[pos] = tok; }
 };
 
 // The re-fed run of a context swap (server.go:166-171) for a stream whose window is full: positions [0, past) hold hist[], `pending` is the

@@ -551,7 +551,7 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // 65..96 rows (round 3): five / six column tiles on the same half-length chunks (2 x (6 + 6) x 16 x 68 floats = 104 KB; 6 x 6 accumulator tiles =
 // 144 registers of the MFMA waves).  The tile GEMM's single row of 128-row tiles cost 17.6 ms at 65 rows against 10.2 ms at 64.
 static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 48, BATCH_ROWS_MAX = 64;
-static int stream_nct(uint32_t n) { return n > 96 ? 8 : (int)((n + 15) / 16); }
+static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
 
@@ -615,10 +615,12 @@ template <int MAXT, int NCT>
 static int launch_stream_dma_v(lh_ctx* ctx, const StreamArgs& a, const char* name, int v) {
     constexpr int N64 = dma_nimg_fit(MAXT, NCT, 64, 4), N128 = dma_nimg_fit(MAXT, NCT, 128, 2);
     static_assert(N64 >= 2, "two images of 64-column chunks always fit");
-    if constexpr (NCT > 6) {   // seven / eight column tiles: MFMA waves as 2 K-groups x 2 column halves, 64-column chunks
-        static_assert(NCT == 8 && dma_pipe_ok(MAXT, NCT / 2), "column split");
-        if (v == 0) return launch_stream_dma<MAXT, NCT, 64, N64, false, 2>(ctx, a, name);
-        return launch_stream_dma<MAXT, NCT, 64, N64, true, 2>(ctx, a, name);
+    if constexpr (NCT == 8) {   // eight column tiles: MFMA waves as 2 K-groups x 2 column halves, 64-column chunks
+        static_assert(dma_pipe_ok(MAXT, NCT / 2), "column split");
+        if (v == 1) return launch_stream_dma<MAXT, NCT, 64, N64, true, 2>(ctx, a, name);
+        return launch_stream_dma<MAXT, NCT, 64, N64, false, 2>(ctx, a, name);
+    } else if constexpr (NCT == 7) {   // seven (97..112 rows): the four K-groups still hold MAXT x 7 accumulator tiles (168 + 52 operand registers at six row tiles)
+        return launch_stream_dma<MAXT, NCT, 64, N64, false>(ctx, a, name);
     } else {
         if constexpr (N128 >= 2) if (v == 2) return launch_stream_dma<MAXT, NCT, 128, 2, false>(ctx, a, name);
         return launch_stream_dma<MAXT, NCT, 64, N64, false>(ctx, a, name);
@@ -627,7 +629,7 @@ static int launch_stream_dma_v(lh_ctx* ctx, const StreamArgs& a, const char* nam
 // per shape (7B launches, same box, tools/stream_mm_check mode 4): long chunks where a workgroup streams five or more row tiles next to two
 // column tiles (w1|w3 at 17..32 rows: 63.2 us against 67.2-68.4; memory-bound there, and a DMA instruction then moves 512 contiguous bytes
 // of a row); everywhere else the deeper ring of short chunks (wq|wk|wv at 32 rows 36.6 against 37.1, wo 19.1 against 25.6, w2 46.5 against 67.2)
-static int stream_dma_default_variant(int maxt, int nct) { return (nct == 2 && maxt >= 5) ? 2 : (nct > 6 ? 1 : 0); }
+static int stream_dma_default_variant(int maxt, int nct) { return (nct == 2 && maxt >= 5) ? 2 : 0; }   // (eight column tiles: the operand pipeline measured 2-5 % slower)
 // K-chunk: 128 columns; 256 for single-tile workgroups on long rows (w2: 37.5 -> 34.9 us).  Longer chunks (a whole 1 KB of ONE row per
 // load instruction, more bytes in flight) measured slower on the other 7B shapes, and a chunk-major copy of the weights (contiguous
 // runs per workgroup) gained 2-13 % at twice the footprint: profiles/r02c_stream_mm_check.txt.
@@ -657,7 +659,8 @@ static int launch_stream_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if constexpr (MAXT <= 6) {   // (8 x 5 / 8 x 6 accumulator tiles do not fit the registers: those launches take the tile GEMM)
         if (a.n <= 80) return launch_stream_nct<MAXT, 5>(ctx, a, name);
         if (a.n <= 96) return launch_stream_nct<MAXT, 6>(ctx, a, name);
-        return launch_stream_nct<MAXT, 8>(ctx, a, name);   // 97..128 rows (round 4): eight column tiles, fp32 weights only
+        if (a.n <= 112) return launch_stream_nct<MAXT, 7>(ctx, a, name);   // 97..128 rows (round 4): seven / eight column tiles, fp32 weights only
+        return launch_stream_nct<MAXT, 8>(ctx, a, name);
     }
     return ST_NA;
 }
@@ -959,7 +962,8 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
     rc = plan_ensure_rows(p, 1);
     if (rc) { plan_destroy(p); return rc; }
-    p->hist.assign(md.ctx, Plan::HIST_UNKNOWN);
+    p->hist = md.kv_hist ? md.kv_hist : std::make_shared<std::vector<uint32_t>>();
+    if (p->hist->size() < md.ctx) p->hist->resize(md.ctx, Plan::HIST_UNKNOWN);
     if (md.ctx > 256 && md.hd == 128) {   // long contexts: decode attention split over the keys (k_attention_split)
         const size_t nch = (md.ctx + ATT_TC - 1) / ATT_TC;
         e = hipMalloc((void**)&p->attn_part, (size_t)md.H * nch * (md.hd + 2) * 4);
@@ -988,7 +992,13 @@ void plan_destroy(Plan* p) {
 }
 
 Plan* plan_find_or_create(lh_ctx* ctx, const ModelDesc& md, int* rc) {
-    for (Plan* p : ctx->plans) if (p->md.same(md)) { *rc = 0; return p; }
+    for (Plan* p : ctx->plans)
+        if (p->md.same(md)) {
+            // same addresses, possibly a NEW cache buffer at a recycled address: the history is the buffer's, not the plan's
+            if (md.kv_hist && p->hist != md.kv_hist) { p->hist = md.kv_hist; if (p->hist->size() < md.ctx) p->hist->resize(md.ctx, Plan::HIST_UNKNOWN); }
+            *rc = 0;
+            return p;
+        }
     Plan* p = nullptr;
     *rc = plan_create(ctx, md, &p);
     if (*rc) return nullptr;
@@ -1147,7 +1157,8 @@ bool swap_refeed_tokens(const Plan* p, uint32_t past, uint32_t pending, std::vec
     const uint32_t n = (past - p->keep) / 2;
     if (n == 0) return true;
     for (uint32_t i = 0; i + 1 < n; ++i) {              // the n - 1 newest evaluated tokens ...
-        const uint32_t t = p->hist[past - (n - 1) + i];
+        const uint32_t idx = past - (n - 1) + i;
+        const uint32_t t = (p->hist && idx < p->hist->size()) ? (*p->hist)[idx] : Plan::HIST_UNKNOWN;
         if (t == Plan::HIST_UNKNOWN) return false;
         out->push_back(t);
     }
@@ -1636,6 +1647,14 @@ struct Batch {
     // the window check of every other Eval entry point (plan_eval: past + n <= ctx) is made here before a tick is enqueued
     std::vector<uint32_t> pos;
     bool pos_known = false;        // false until lh_batch_set / lh_batch_prompt placed the rows
+    // Context swap (server.go:160-172) of whole-model batches.  The ids live on the device (out_dev: row i's list, entry step0 + t written by
+    // tick t since the last batch_set); what the host needs at a swap it reads then: the token tick t evaluated is entry step0 + t - 1 (or
+    // tok0[i], the host value of the last batch_set, for entry -1).
+    std::vector<uint32_t> pos_set, tok0, pending;
+    bool tok0_known = false;
+    uint32_t step0 = 0, ticks = 0, drained = 0;   // ticks since the last batch_set / of them recorded in the pods' token histories
+    bool collecting = false;                      // lh_batch_decode: keep every id a row produces across the resets of the device lists
+    std::vector<std::vector<uint32_t>> gen;
     float* logits() const { return batched || B == 1 ? pods[0]->logits : logits_own; }
 };
 
@@ -1681,16 +1700,19 @@ static int batch_enqueue_tick(Batch* b, const float* x_in, float* x_out) {
 // One tick on the stream: the first one eagerly (it sets kernel attributes and makes the allocations a capture must not make), then a
 // captured graph, re-captured when an address it holds has changed.
 static int batch_tick_unchecked(Batch* b, const float* x_in, float* x_out);
+static int batch_swap(Batch* b);
 static int batch_tick(Batch* b, const float* x_in, float* x_out) {
     lh_ctx* ctx = b->ctx;
     const ModelDesc& m = b->pods[0]->md;
     // a tick evaluates row i at position pos[i]: RoPE table row, KV append and the attention's key range all index by it (Eval's
     // pastCount + N <= CtxSize, checked like plan_eval / lh_llama_stage do)
     if (!b->pos_known) LH_FAIL(ctx, LH_EINVAL, "lh_batch: tick before lh_batch_set / lh_batch_prompt placed the rows");
-    for (uint32_t i = 0; i < b->B; ++i)
-        if (b->pos[i] >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch: row %u at position %u has left the context window of %u", i, b->pos[i], m.ctx);
-    const int rc = batch_tick_unchecked(b, x_in, x_out);
-    if (rc == 0) for (uint32_t i = 0; i < b->B; ++i) b->pos[i] += 1;
+    bool full = false;
+    for (uint32_t i = 0; i < b->B; ++i) full = full || b->pos[i] >= m.ctx;
+    int rc;
+    if (full && (rc = batch_swap(b))) return rc;   // whole-model batches swap context like server.Do; a stage's batch fails here
+    rc = batch_tick_unchecked(b, x_in, x_out);
+    if (rc == 0) { for (uint32_t i = 0; i < b->B; ++i) b->pos[i] += 1; b->ticks += 1; }
     return rc;
 }
 static int batch_tick_unchecked(Batch* b, const float* x_in, float* x_out) {
@@ -1742,7 +1764,61 @@ static int batch_set(Batch* b, const uint32_t* tokens, const uint32_t* past, uin
     LH_HIP(ctx, hipGetLastError());
     b->pos.assign(past, past + b->B);
     b->pos_known = true;
+    b->pos_set = b->pos;
+    b->tok0_known = tokens != nullptr;
+    if (tokens) b->tok0.assign(tokens, tokens + b->B);
+    b->step0 = step0; b->ticks = 0; b->drained = 0;
     return 0;
+}
+
+// Waits for the stream and brings the host up to date with what the ticks since the last batch_set did: the token every tick evaluated goes
+// into its pod's history (Plan::hist), the ids produced into b->gen (lh_batch_decode), the rows' pending tokens into b->pending.
+static int batch_drain(Batch* b) {
+    lh_ctx* ctx = b->ctx;
+    const uint32_t B = b->B, n_out = b->step0 + b->ticks;
+    const ModelDesc& m = b->pods[0]->md;
+    if (!m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_batch: only the last stage knows the ids");
+    std::vector<uint32_t> out((size_t)B * std::max(n_out, 1u));
+    if (n_out) LH_HIP(ctx, hipMemcpy2DAsync(out.data(), (size_t)n_out * 4, b->out_dev, (size_t)b->out_cap * 4, (size_t)n_out * 4, B, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    b->pending.assign(B, Plan::HIST_UNKNOWN);
+    for (uint32_t i = 0; i < B; ++i) {
+        auto evaluated = [&](uint32_t t) -> uint32_t {   // the token tick t evaluated
+            if (b->step0 + t >= 1) return out[(size_t)i * n_out + b->step0 + t - 1];
+            return b->tok0_known ? b->tok0[i] : Plan::HIST_UNKNOWN;
+        };
+        for (uint32_t t = b->drained; t < b->ticks; ++t) {
+            b->pods[i]->record(b->pos_set[i] + t, evaluated(t));
+            if (b->collecting) b->gen[i].push_back(out[(size_t)i * n_out + b->step0 + t]);
+        }
+        b->pending[i] = evaluated(b->ticks);
+    }
+    b->drained = b->ticks;
+    return 0;
+}
+
+// The rows whose window is full swap context (server.go:160-172), each on its own plan and cache like its prompt ran: the run of
+// (position - keep) / 2 tokens is re-fed as ONE Eval at position keep, and the row's pending token then takes the next tick at the position
+// behind it - together exactly the reference's swap Eval (the pending token last in it), cut in two at its last row.
+static int batch_swap(Batch* b) {
+    lh_ctx* ctx = b->ctx;
+    const ModelDesc& m = b->pods[0]->md;
+    if (!m.first_stage() || !m.last_stage())
+        LH_FAIL(ctx, LH_EINVAL, "lh_batch: a row has left the context window of %u (the context swap of a layer shard is driven by the pipeline, not by a stage)", m.ctx);
+    int rc;
+    if ((rc = batch_drain(b))) return rc;
+    std::vector<uint32_t> newpos = b->pos, refeed;
+    for (uint32_t i = 0; i < b->B; ++i) {
+        if (b->pos[i] < m.ctx) continue;
+        Plan* p = b->pods[i];
+        if (p->keep >= m.ctx) LH_FAIL(ctx, LH_EINVAL, "context swap: KeepCount %u leaves no room in a window of %u", p->keep, m.ctx);
+        if (b->pending[i] == Plan::HIST_UNKNOWN || !swap_refeed_tokens(p, b->pos[i], b->pending[i], &refeed))
+            LH_FAIL(ctx, LH_EINVAL, "lh_batch: row %u has left the context window of %u and the tokens of its window are not known to the batch (run its prompt through lh_batch_prompt)", i, m.ctx);
+        if (!refeed.empty() && (rc = plan_eval(p, refeed.data(), nullptr, nullptr, (uint32_t)refeed.size(), p->keep, true))) return rc;
+        newpos[i] = p->keep + (uint32_t)refeed.size();
+    }
+    const std::vector<uint32_t> toks = b->pending;   // (batch_set overwrites b->tok0 from it)
+    return batch_set(b, toks.data(), newpos.data(), 0);
 }
 
 }  // namespace lh
@@ -1823,6 +1899,11 @@ int lh_llama_create(lh_ctx* ctx, const lh_llama_desc* desc, lh_llama** out) {
     if ((rc = need(desc->k_cache, kvn, "k_cache", &kc))) return rc;
     if ((rc = need(desc->v_cache, kvn, "v_cache", &vc))) return rc;
     md.kc = (float*)kc; md.vc = (float*)vc;
+    {   // the cache's token history travels with the buffer: shared with the graph path's plan over the same cache
+        Buffer* kb = find_buffer(ctx->ds, desc->k_cache);
+        if (!kb->kv_hist) kb->kv_hist = std::make_shared<std::vector<uint32_t>>();
+        md.kv_hist = kb->kv_hist;
+    }
     Plan* p = nullptr;
     if ((rc = plan_create(ctx, md, &p))) return rc;
     lh_llama* m = new lh_llama();
@@ -2153,14 +2234,16 @@ int lh_batch_decode(lh_batch* h, const uint32_t* first_tokens, const uint32_t* p
     const ModelDesc& m = b->pods[0]->md;
     LH_HIP(ctx, hipSetDevice(ctx->device));
     if (!m.first_stage() || !m.last_stage()) LH_FAIL(ctx, LH_EINVAL, "lh_batch_decode needs whole-model pods; use lh_batch_stage on a layer shard");
-    for (uint32_t i = 0; i < b->B; ++i)
-        if ((uint64_t)past[i] + n_steps > m.ctx) LH_FAIL(ctx, LH_EINVAL, "lh_batch_decode: row %u: past %u + %u steps exceed the context window of %u", i, past[i], n_steps, m.ctx);
     int rc;
     if ((rc = batch_set(b, first_tokens, past))) return rc;
-    for (uint32_t s = 0; s < n_steps; ++s)
-        if ((rc = batch_tick(b, nullptr, nullptr))) return rc;
+    b->collecting = true;
+    b->gen.assign(b->B, std::vector<uint32_t>());
+    for (uint32_t s = 0; s < n_steps && !rc; ++s) rc = batch_tick(b, nullptr, nullptr);   // (a row whose window is full swaps context first: batch_swap)
+    if (!rc) rc = batch_drain(b);
+    b->collecting = false;
+    if (rc) return rc;
     if (out_tokens)
-        LH_HIP(ctx, hipMemcpy2DAsync(out_tokens, (size_t)n_steps * 4, b->out_dev, (size_t)b->out_cap * 4, (size_t)n_steps * 4, b->B, hipMemcpyDeviceToHost, ctx->stream));
+        for (uint32_t i = 0; i < b->B; ++i) memcpy(out_tokens + (size_t)i * n_steps, b->gen[i].data(), (size_t)n_steps * 4);
     if (logits_last_host) LH_HIP(ctx, hipMemcpyAsync(logits_last_host, b->logits(), (size_t)b->B * m.V * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;

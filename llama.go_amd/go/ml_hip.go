@@ -45,7 +45,7 @@ import (
 type hipState struct {
 	ctx *C.lh_ctx
 	// persistent tensors registered through THIS context (a pod's KV caches): released with it
-	owned []*float32
+	owned []*Tensor
 }
 
 func hipHalt(ctx *C.lh_ctx) {
@@ -84,21 +84,36 @@ func ModelContextHIP(device int) *Context {
 	return modelCtx
 }
 
-// persistent[&Data[0]] = device buffer.  Pods run concurrently (server.go:88-101: one goroutine per job), so the map is
-// guarded: Go aborts the process on an unsynchronised concurrent map read + write.
+// persistent[tensor] = device buffer.  Keyed by the *Tensor (the model's weight tensors and a context's KV cache tensors are the very
+// objects the graph's MulMat / View1D nodes point to, llama.go:263-265, 274-275), NOT by &Data[0]: a pointer into the backing array
+// would keep all 27 GB of host weights reachable for the garbage collector for as long as the map lives, and the device copy is the only
+// one inference reads (include/llamahip.h: "no host pointer is retained").  ReleaseHostWeights drops the host copies.
+// Pods run concurrently (server.go:88-101: one goroutine per job), so the map is guarded: Go aborts the process on an unsynchronised
+// concurrent map read + write.
 var (
 	persistentMu sync.RWMutex
-	persistent   = map[*float32]C.lh_buf{}
+	persistent   = map[*Tensor]C.lh_buf{}
 )
 
 func lookupPersistent(t *Tensor) (C.lh_buf, bool) {
-	if len(t.Data) == 0 { // &t.Data[0] would panic on an empty slice
-		return 0, false
-	}
 	persistentMu.RLock()
-	buf, ok := persistent[&t.Data[0]]
+	buf, ok := persistent[t]
 	persistentMu.RUnlock()
 	return buf, ok
+}
+
+// ReleaseHostWeights: after RegisterPersistent the device holds the only copy inference needs; setting Data to nil lets the garbage
+// collector free the host copy (27 GB for 7B fp32).  Call once after LoadModel + registration (INTEGRATION.md §2); tensors that the host
+// still reads (none on the Eval path: logits come back through lh_node_read) must not be passed.
+func ReleaseHostWeights(tensors ...*Tensor) {
+	for _, t := range tensors {
+		if t == nil {
+			continue
+		}
+		if _, ok := lookupPersistent(t); ok {
+			t.Data = nil
+		}
+	}
 }
 
 // RegisterPersistent uploads t.Data to HBM under a stable key (the address of its backing array).  Tensors registered
@@ -108,33 +123,34 @@ func RegisterPersistent(ctx *Context, t *Tensor) {
 	if len(t.Data) == 0 {
 		return
 	}
-	key := &t.Data[0]
 	persistentMu.Lock()
 	defer persistentMu.Unlock()
-	if _, ok := persistent[key]; ok {
+	if _, ok := persistent[t]; ok {
 		return
 	}
 	var buf C.lh_buf
 	ne := [4]C.uint32_t{C.uint32_t(t.NE[0]), C.uint32_t(t.NE[1]), C.uint32_t(t.NE[2]), C.uint32_t(t.NE[3])}
-	rc := C.lh_tensor_register(ctx.hip.ctx, C.uint64_t(uintptr(unsafe.Pointer(key))), C.int(TYPE_F32), &ne[0], 1,
-		unsafe.Pointer(key), &buf) // the pointee holds no Go pointers: legal for the duration of the call
+	// library-side key: the tensor's address as a number (a uintptr holds nothing alive); the data pointer is used for the duration of
+	// the call only and its pointee holds no Go pointers (cgo rule)
+	rc := C.lh_tensor_register(ctx.hip.ctx, C.uint64_t(uintptr(unsafe.Pointer(t))), C.int(TYPE_F32), &ne[0], 1,
+		unsafe.Pointer(&t.Data[0]), &buf)
 	if rc != 0 {
 		hipHalt(ctx.hip.ctx)
 	}
-	persistent[key] = buf
+	persistent[t] = buf
 	if ctx != modelCtx {
-		ctx.hip.owned = append(ctx.hip.owned, key)
+		ctx.hip.owned = append(ctx.hip.owned, t)
 	}
 }
 
 // UnregisterPersistent frees the device copy of a tensor (a finished pod's KV cache).
 func UnregisterPersistent(ctx *Context, t *Tensor) {
-	if len(t.Data) != 0 {
-		unregisterKey(ctx, &t.Data[0])
+	if t != nil {
+		unregisterKey(ctx, t)
 	}
 }
 
-func unregisterKey(ctx *Context, key *float32) {
+func unregisterKey(ctx *Context, key *Tensor) {
 	persistentMu.Lock()
 	buf, ok := persistent[key]
 	delete(persistent, key)
@@ -334,7 +350,13 @@ func NewStageHIP(ctx *Context, w *ModelWeightsHIP, layer0, layer1, ctxSize uint3
 		layer1 = w.Layers
 	}
 	st := &StageHIP{ctx: ctx}
-	ne := [4]C.uint32_t{C.uint32_t(w.Embd * (layer1 - layer0) * ctxSize), 1, 1, 1}
+	// ml.Tensor.NE is uint32 (ml.go:187): the element count of a KV cache must fit it (C++ twin: llamago_NewBatch / make_stage halt likewise)
+	kvn := uint64(w.Embd) * uint64(layer1-layer0) * uint64(ctxSize)
+	if layer1 <= layer0 || kvn == 0 || kvn > 0xFFFFFFFF {
+		fmt.Printf("\n[HALT] NewStageHIP: KV cache of %d elements (embd %d x %d layers x ctx %d) outside uint32", kvn, w.Embd, layer1-layer0, ctxSize)
+		os.Exit(1)
+	}
+	ne := [4]C.uint32_t{C.uint32_t(kvn), 1, 1, 1}
 	if rc := C.lh_tensor_register(ctx.hip.ctx, 0, C.int(TYPE_F32), &ne[0], 1, nil, &st.k); rc != 0 {
 		hipHalt(ctx.hip.ctx)
 	}
@@ -389,7 +411,11 @@ type BatchHIP struct {
 
 func NewBatchHIP(ctx *Context, stages []*StageHIP) *BatchHIP {
 	n := len(stages)
-	hs := (*[64]*C.lh_llama)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	if n == 0 || n > 64 { // lh_batch_create would refuse it; the slice expression below must not panic first
+		fmt.Printf("\n[HALT] NewBatchHIP: %d pods outside 1..64", n)
+		os.Exit(1)
+	}
+	hs := (*[1 << 16]*C.lh_llama)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
 	defer C.free(unsafe.Pointer(&hs[0]))
 	for i, st := range stages {
 		hs[i] = st.h
@@ -404,6 +430,9 @@ func NewBatchHIP(ctx *Context, stages []*StageHIP) *BatchHIP {
 // cPrompts copies [][]uint32 into C memory (pointer table + rows); the returned func frees it.
 func cPrompts(prompts [][]uint32) (**C.uint32_t, *C.uint32_t, func()) {
 	n := len(prompts)
+	if n == 0 { // (SetSampler(nil prompts): nothing to hand over; &ptrs[0] below would panic)
+		return nil, nil, func() {}
+	}
 	ptrs := (*[1 << 16]*C.uint32_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
 	lens := (*[1 << 16]C.uint32_t)(C.malloc(C.size_t(4 * n)))[:n:n]
 	for i, pr := range prompts {
@@ -458,6 +487,14 @@ func (bt *BatchHIP) SetSampler(topK uint32, topP, temp, repeatPenalty float32, s
 	defer free()
 	if rc := C.lh_batch_set_sampler(bt.b, &sp, C.uint32_t(ringSize), pp, nn); rc != 0 {
 		hipHalt(bt.ctx.hip.ctx)
+	}
+}
+
+// SetKeepCount: ModelParams.KeepCount (llama.go:47) of every pod.  A Tick of a pod that stands at the end of its window swaps its context
+// as server.Do does (server.go:160-172) inside lh_batch_stage: the host loop needs no swap code of its own.
+func (bt *BatchHIP) SetKeepCount(keep uint32) {
+	for _, st := range bt.stages {
+		C.lh_llama_set_keep(st.h, C.uint32_t(keep))
 	}
 }
 

@@ -998,6 +998,9 @@ int llamago_BatchGreedyDecode(llama_batch* p, const uint32_t* const* prompts, co
         for (uint32_t s2 = 0; s2 + 1 < n_predict; s2++) out[(size_t)i * n_predict + 1 + s2] = rest[(size_t)i * (n_predict - 1) + s2];
     return 0;
 }
+void llamago_BatchSetKeepCount(llama_batch* p, uint32_t keep) {
+    if (p) for (lh_llama* m : p->pods) lh_llama_set_keep(m, keep);
+}
 int llamago_BatchPrompt(llama_batch* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t* ids_out) {
     if (!p || !prompts || !n_prompt || !ids_out) return halt_rc("llamago_BatchPrompt: bad arguments");
     lh_ctx* hip = p->mlctx->hip;

@@ -496,6 +496,11 @@ class Batch:
         ids = [list(out[i * n_predict:(i + 1) * n_predict]) for i in range(self.pods)]
         return (ids, lg) if want_logits else ids
 
+    def SetKeepCount(self, keep):
+        self.ml.lib.llamago_BatchSetKeepCount.restype = None
+        self.ml.lib.llamago_BatchSetKeepCount.argtypes = [VP, c_u32]
+        self.ml.lib.llamago_BatchSetKeepCount(self.h, keep)
+
     def Prompt(self, prompts):
         """BatchHIP.Prompt (go/ml_hip.go): every pod's prompt as one Eval; returns the id each prompt produced."""
         assert len(prompts) == self.pods

@@ -147,3 +147,48 @@ def test_resident_loop_without_the_windows_tokens_fails_cleanly(product):
         decode_greedy_resident(c, 5, 10, 12)      # positions 0..9 were never evaluated through this context
     c.free()
     m.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,int8,keep,lengths,seed", [("small", False, 0, [5, 1, 12, 3], 12), ("small", False, 4, [7, 2, 9, 4, 15, 1], 12), ("small", True, 0, [5, 1, 12], 13)])
+def test_pods_in_one_weight_pass_swap_context_per_row(product, oracle, shape, int8, keep, lengths, seed):
+    """lh_batch: rows reach the end of their windows at different ticks; each swaps on its own cache while the others go on, and every pod
+    decodes what it decodes alone on the checker (60 tokens through windows of 24)."""
+    from llama_go_amd.mlapi import Batch
+    ctx_size, n_predict = 24, 60
+    hp = make_hparams(**SHAPES[shape], ctx=ctx_size)
+    rng = np.random.default_rng(len(lengths) + keep)
+    prompts = [[int(t) for t in rng.integers(0, hp.vocabSize, n)] for n in lengths]
+    out, margin = _streams(oracle, hp, seed, prompts, n_predict, ctx_size, keep, int8)
+    if margin <= MARGIN:
+        pytest.fail(f"the checker's own top-2 margin is {margin:.2e}: pick another seed")
+    m = product.NewSyntheticModel(hp, seed)
+    if int8:
+        m.QuantizeQ8()
+    b = Batch(m, ctx_size, len(prompts))
+    b.SetKeepCount(keep)
+    ids = b.GreedyDecode(prompts, n_predict)
+    b.free()
+    m.free()
+    assert ids == [o[0] for o in out]
+
+
+@pytest.mark.gpu
+def test_unsharded_pipeline_swaps_context(product, oracle):
+    """The scheduler on one rank (lh_pipeline_run over lh_batch ticks): streams outlive their windows across run() calls."""
+    from llama_go_amd.mlapi import Pipeline
+    ctx_size, seed = 24, 13
+    hp = make_hparams(**SHAPES["small"], ctx=ctx_size)
+    rng = np.random.default_rng(77)
+    prompts = [[int(t) for t in rng.integers(0, hp.vocabSize, n)] for n in [6, 2, 11]]
+    out, margin = _streams(oracle, hp, seed, prompts, 50, ctx_size, 0)
+    if margin <= MARGIN:
+        pytest.fail(f"the checker's own top-2 margin is {margin:.2e}: pick another seed")
+    m = product.NewSyntheticModel(hp, seed)
+    pl = Pipeline(m, ctx_size, len(prompts), 0, 1)
+    pl.run(prompts, 19)
+    pl.run(None, 30)
+    got = [pl.tokens(i) for i in range(len(prompts))]
+    pl.free()
+    m.free()
+    assert got == [o[0] for o in out]

@@ -23,4 +23,4 @@ timeout 300 python tools/bench_ttft.py --ns 2,3,4,5,6,8,9,12,16,17,24,32,40,48,6
 LLAMAHIP_ROWS_MAX=4 LLAMAHIP_STREAM_V=-1 timeout 300 python tools/bench_ttft.py --ns 5,6,8,32,64,97,112,128 --reps 5 > $O/ttft_r3.json 2> $O/ttft_r3.err; echo "ttft round-3 paths rc=$?"; cat $O/ttft_r3.json
 timeout 300 python tools/bench_pods.py --pods 1,4,5,6,8,16,32,64 --steps 32 > $O/pods_default.json 2> $O/pods_default.err; echo "pods default rc=$?"; cat $O/pods_default.json
 LLAMAHIP_ROWS_MAX=4 timeout 300 python tools/bench_pods.py --pods 5,6,8 --steps 32 > $O/pods_rows4.json 2> $O/pods_rows4.err; echo "pods rows<=4 rc=$?"; cat $O/pods_rows4.json
-timeout 1200 python -m pytest tests/test_gpu_llama.py tests/test_gpu_batch.py -m gpu -x -q -k "7b_shape_slice or batched_decode_equals or ticks_ or batches_come or prefill_mfma_path or bitwise or odd_shapes or long_context or pipeline_groups" > $O/tests.log 2>&1; echo "tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/tests.log | tail -5
+timeout 1200 python -m pytest tests/test_gpu_llama.py tests/test_gpu_batch.py tests/test_context_swap.py -m gpu -q -k "7b_shape_slice or batched_decode_equals or ticks_ or batches_come or prefill_mfma_path or bitwise or odd_shapes or long_context or pipeline_groups or swap or windows_tokens or argument_errors" > $O/tests.log 2>&1; echo "tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $O/tests.log | tail -15

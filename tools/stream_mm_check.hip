@@ -92,6 +92,8 @@ template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const Strea
     if constexpr (NCT == 8) {   // eight column tiles: 2 K-groups x 2 column halves, 64-column chunks, pipelined
         if constexpr (KC == 64 && MAXT <= 6) { if (g_pipe) run_dma_img<MAXT, NCT, KC, NIMG, true, 2>(a, nCU); else run_dma_img<MAXT, NCT, KC, NIMG, false, 2>(a, nCU); }
         else printf("k_stream_dma: eight column tiles run 64-column chunks, up to six row tiles\n");
+    } else if constexpr (NCT == 7) {
+        if constexpr (KC == 64 && MAXT <= 6) run_dma_img<MAXT, NCT, KC, NIMG, false>(a, nCU);
     } else if constexpr (NCT >= 2) {
         constexpr bool POK = MAXT * NCT * 4 + 2 * (MAXT + NCT) * 4 <= 210;   // (plan.hip: dma_pipe_ok)
         if constexpr (POK) { if (g_pipe) { run_dma_img<MAXT, NCT, KC, NIMG, true>(a, nCU); return; } }
@@ -103,7 +105,7 @@ template <int MAXT, int NCT, int KC> static void run_dma(const StreamArgs& a, in
     if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
 }
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
-    if constexpr (NCT == 8) { run_dma<MAXT, NCT, 64>(a, nCU); return; }   // (mode 4 only: the other kernels hold MAXT x NCT tiles per wave)
+    if constexpr (NCT >= 7) { run_dma<MAXT, NCT, 64>(a, nCU); return; }   // (mode 4 only: the other kernels are built for up to six column tiles)
     else {
     if (g_dma) { if (g_kc == 64) run_dma<MAXT, NCT, 64>(a, nCU); else run_dma<MAXT, NCT, 128>(a, nCU); return; }
     if (g_v2) { if (g_kc >= 256) run2_kc<MAXT, NCT, 256>(a, nCU); else if (g_kc == 64) run2_kc<MAXT, NCT, 64>(a, nCU); else run2_kc<MAXT, NCT, 128>(a, nCU); return; }
@@ -153,7 +155,7 @@ int main(int argc, char** argv) {
     if (getenv("STREAM_WGPCU")) g_wgpcu = atoi(getenv("STREAM_WGPCU")) == 2 ? 2 : 1;
     const uint32_t T = M / 16, ngrp = (uint32_t)(nCU * g_wgpcu) / S, maxt = (T + ngrp - 1) / ngrp;
     printf("M %u K %u N %u: tiles %u, per workgroup <= %u\n", M, K, N, T, maxt);
-#define GO(MT) { if (g_dma && N > 96) run<(MT <= 6 ? MT : 6), 8>(a, nCU); else if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64 && N > 80 && MT <= 6) run<(MT <= 6 ? MT : 6), 6>(a, nCU); else if (g_v2 && g_kc == 64 && N > 64 && MT <= 6) run<(MT <= 6 ? MT : 6), 5>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
+#define GO(MT) { if (g_dma && N > 112) run<(MT <= 6 ? MT : 6), 8>(a, nCU); else if (g_dma && N > 96) run<(MT <= 6 ? MT : 6), 7>(a, nCU); else if (N <= 16) run<MT, 1>(a, nCU); else if (N <= 32) run<MT, 2>(a, nCU); else if (N <= 48 && g_v2) run<MT, 3>(a, nCU); else if (g_v2 && g_kc == 64 && N > 80 && MT <= 6) run<(MT <= 6 ? MT : 6), 6>(a, nCU); else if (g_v2 && g_kc == 64 && N > 64 && MT <= 6) run<(MT <= 6 ? MT : 6), 5>(a, nCU); else if (g_v2 && g_kc == 64) run<MT, 4>(a, nCU); else run<(MT <= 3 ? MT : 3), 4>(a, nCU); }
     if (maxt <= 1) GO(1) else if (maxt <= 2) GO(2) else if (maxt <= 3) GO(3) else if (maxt <= 4) GO(4) else if (maxt <= 6) GO(6) else GO(8)
     if (getenv("STREAM_CHECK_SKIP")) return 0;   // timing-only runs (the -DSTREAM_PROBE builds compute wrong sums on purpose)
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
