@@ -119,6 +119,7 @@ void llama_ReleaseContext(llama_context* lctx);                                 
  * copies the last row of logits to lctx.Logits.  Returns 0 (the reference always returns nil). */
 int llama_Eval(llama_context* lctx, llama_model* m, const uint32_t* tokens, uint32_t n, uint32_t pastCount);
 const float* llama_Logits(const llama_context* lctx); /* lctx.Logits, vocabSize floats */
+const float* llama_Embedding(llama_context* c);   /* lctx.Embedding (llama.go:88, 414-419): [embd] floats, NULL unless llamago_EnableEmbedding */
 ml_context* llama_MLContext(llama_context* lctx);
 /* Greedy decode as defined in SURVEY §8c: argmax (lowest index on ties) of Logits after each Eval,
  * loop as server.Do (server.go:153-217): prompt in one Eval, then N=1 steps.  out_tokens gets

@@ -48,6 +48,10 @@ int llamago_ProfileDecode(llama_context* c, uint32_t token, uint32_t past, uint3
 int llamago_Stage(llama_context* c, const uint32_t* tokens, const void* tokens_dev, const void* x_in_dev, void* x_out_dev, uint32_t n, uint32_t past,
                   void* logits_dev, void* argmax_dev);
 
+/* ModelParams.Embedding (llama.go:52, 88): from now on every llama_Eval also leaves row N-1 of `embeddings` (the final norm * weight rows,
+ * llama.go:381, 414-419) in lctx.Embedding; llama_Embedding (llamago.h) returns it ([embd] floats; NULL when not enabled).  On the GPU the fused plan
+ * never writes those rows out by itself: the Eval graph's node is flagged LH_T_OUTPUT. */
+void llamago_EnableEmbedding(llama_context* c);
 /* ModelParams.KeepCount (llama.go:47): the tokens a context swap keeps (server.go:166-167); 0 in the reference's own main.go.  The generation
  * loops (llama_GreedyDecode, llama_SampleDecode, llamago_DecodeGreedyResident) swap context at the window's end as server.Do does. */
 void llamago_SetKeepCount(llama_context* c, uint32_t keep);

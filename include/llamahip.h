@@ -98,7 +98,10 @@ typedef struct lh_tensor {
     const float* host;   /* owner leaf with buf == 0: host data uploaded for this call (token ids, op params); else NULL */
 } lh_tensor;
 
-enum { LH_T_OUTPUT = 1 /* host wants to read this node back (kept materialised by fused plans) */ };
+enum { LH_T_OUTPUT = 1 /* the host wants to read this node back with lh_node_read (in the reference every Tensor.Data is readable after
+                           GraphCompute).  Node-by-node execution materialises everything anyway.  A fused plan materialises the final node and,
+                           when flagged, llama.Eval's `embeddings` (the final norm rows, llama.go:381, 414-419); a graph with any other flagged
+                           intermediate is executed node by node instead */ };
 enum {
     LH_GRAPH_NO_FUSION = 1,        /* run every node 1:1 with the generic kernels (debug / op-level parity tests) */
     LH_GRAPH_LAST_ROW_LOGITS = 2   /* caller reads only row N-1 of the final MulMat (what llama.Eval does: it builds the

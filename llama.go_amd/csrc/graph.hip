@@ -40,6 +40,7 @@ struct Matcher {
     uint32_t N = 0, past = 0;
     int kc_owner = -1, vc_owner = -1;
     int tokens_leaf = -1;
+    int emb_node = -1;   // `embeddings` of llama.Eval (llama.go:381): the final norm * weight rows, source of the lm_head
     std::vector<uint32_t> tokens;
 
     // Every node the pattern walks over is marked; the match only holds if ALL nodes of the graph were claimed (extra outputs or
@@ -208,6 +209,11 @@ struct Matcher {
         if (!run_pattern()) return false;
         for (uint32_t i = n_leafs; i < total; ++i)
             if (!claimed[i]) return false;  // a node outside the Eval pattern: run the graph node by node
+        // LH_T_OUTPUT: the host wants to read this node back (in the reference every Tensor.Data is readable after GraphCompute, ml.go:1411-1528).
+        // A fused plan materialises the final node and `embeddings` (llama.go:381, read at llama.go:414-419); any other flagged intermediate
+        // never exists in it, so such a graph runs node by node.
+        for (uint32_t i = n_leafs; i + 1 < total; ++i)
+            if ((T[i].flags & LH_T_OUTPUT) && (int)i != emb_node) return false;
         return true;
     }
     bool run_pattern() {
@@ -222,6 +228,7 @@ struct Matcher {
         if (!(md.output = weight(wout, md.d, md.V, &md.s_output, true))) return false;
         int x;
         if (!norm_mul(s1(fin), &x, &md.norm)) return false;
+        emb_node = s1(fin);
         // count layers by walking the residual chain down to GetRows
         std::vector<int> outs;
         int cur = x;
@@ -435,6 +442,11 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
             int rc = 0;
             Plan* p = plan_find_or_create(ctx, m.md, &rc);
             if (p) rc = plan_eval(p, m.tokens.data(), nullptr, nullptr, m.N, m.past, (flags & LH_GRAPH_LAST_ROW_LOGITS) != 0);
+            if (!rc && m.emb_node >= 0 && (T[m.emb_node].flags & LH_T_OUTPUT)) {
+                float* emb = nullptr;
+                rc = plan_embeddings(p, m.N, &emb);   // the final norm * weight rows [N][embd] (the fused lm_head launches never write them out)
+                if (!rc) { ctx->last_ptr[m.emb_node] = emb; ctx->last_len[m.emb_node] = (uint64_t)m.N * m.md.d; }
+            }
             if (!rc) {
                 LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 ctx->last_ptr[total - 1] = p->logits;  // [N][V], the final node's layout (ne0 = V, ne1 = N)
@@ -504,7 +516,7 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
 int lh_node_read(lh_ctx* ctx, uint32_t index, uint64_t off, float* dst, uint64_t n) {
     if (!ctx || !dst) return LH_EINVAL;
     if (index >= ctx->last_ptr.size() || !ctx->last_ptr[index])
-        LH_FAIL(ctx, LH_EINVAL, "lh_node_read: tensor %u was not materialised by the last graph (fused plans keep only the final node; use LH_GRAPH_NO_FUSION)", index);
+        LH_FAIL(ctx, LH_EINVAL, "lh_node_read: tensor %u was not materialised by the last graph (a fused plan keeps the final node and the nodes flagged LH_T_OUTPUT; flag it, or use LH_GRAPH_NO_FUSION)", index);
     if (off > ctx->last_len[index] || n > ctx->last_len[index] - off) LH_FAIL(ctx, LH_EINVAL, "lh_node_read: range outside tensor %u", index);
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));

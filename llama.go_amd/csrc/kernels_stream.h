@@ -1041,6 +1041,162 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
     stream_epilogue<MAXT, NCT, CS>(a, smem_raw, (uint32_t)(NIMG * IMGF), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// k_stream_q8 — block-int8 weights (format of kernels_q8.h: int8 plane [M][K] + fp32 scale per 32 columns) on the LDS-DMA structure of
+// k_stream_dma, 3..48 token rows (BASELINE config 4: "dequant-in-LDS + fp32 MFMA").
+// Why a kernel of its own (round 3: 3.55x fewer bytes bought 0-9 % over fp32 at 8..48 rows): k_stream_mm2<.., true> dequantises in the LOADER waves -
+// per value one convert and one fma on the vector ALU of waves that only get issue slots in the gaps of the MFMA wave they share a SIMD with,
+// then a 4-byte LDS write per value - and its chunk is sized in columns, so it carries a quarter of the fp32 chunk's bytes behind the same
+// barrier.  Here the loader waves move the RAW bytes (`buffer_load_dwordx4 ... lds`: int8 rows, their scales, the activation rows; nothing
+// else in their loop) and the chunk is sized in BYTES: 256 (or 128) columns = 256 (128) B per weight row, the 64 (32)-column fp32 chunk's
+// footprint.  The MFMA waves dequantise on the operand-read side, where the matrix pipe leaves the vector ALU idle anyway: a lane's A operand
+// for four MFMAs is ONE dword of the image (4 quants), flipped to unsigned (xor 0x80808080), and  w = fma(d, float(u), -128 d)  - exact
+// before the fma's single rounding, so w IS fl32(d * q), the checker's dequantise-then-fp32 value (v_cvt_f32_ubyteN + v_fma_f32 per
+// value, 9 vector instructions per four MFMAs per row tile at one column tile).
+//   * image per chunk: weights [MAXT * 16 rows][KC bytes], granule = 16 quants = one k-block of a row, stored at position g ^ (row & (KC / 16 - 1))
+//     (source-side swizzle; the dword reads of a k-block are then 2-way conflicted at worst); scales [MAXT tiles][1 KB]: a tile's 16 rows x KC / 32
+//     floats in the first lanes' slots of one DMA instruction, the rest of its KB is padding the idle lanes write duplicates into; activations
+//     [NCT * 16 rows][KC floats] as in k_stream_dma.
+//   * the launch is bound by the matrix pipe from the first row on (4x the MACs per byte of fp32): per 256-column chunk and MFMA wave
+//     4 k-blocks x 4 MAXT NCT MFMAs; w1|w3 of 7B at <= 16 rows: 49 k clocks = 23.5 us at the 2.09 GHz the chip holds under this load.
+// Summation structure, epilogues, tile pairs, K-split pairs, batched rows: k_stream_dma's.  No folded norm.
+__host__ __device__ constexpr size_t stream_q8_image_bytes(int maxt, int nct, int kc) { return (size_t)maxt * 16 * kc + (size_t)maxt * 1024 + (size_t)nct * 16 * kc * 4; }
+
+template <int MAXT, int NCT, int KC, int NIMG>
+__global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
+    static_assert(KC == 128 || KC == 256, "chunk");
+    static_assert(NIMG >= 2 && NIMG <= 4, "ring");
+    constexpr int GRW = KC / 16;                // granules (= k-blocks) per weight row
+    constexpr int RPW = 64 / GRW;               // weight rows per DMA instruction: 4 / 8
+    constexpr int GRX = KC / 4;                 // granules per activation row: 64 / 32
+    constexpr int RPX = 64 / GRX;               // activation rows per DMA instruction: 1 / 2
+    constexpr int NWI = MAXT * 16 / RPW, NSI = MAXT, NXI = NCT * 16 / RPX, NI = NWI + NSI + NXI;
+    constexpr int NIW = (NI + 3) / 4;           // DMA instructions per loader wave and chunk (the last wave(s) repeat the final piece: uniform counts)
+    constexpr int WAITN = NIW * (NIMG - 2) < 64 ? NIW * (NIMG - 2) : 63;
+    constexpr uint32_t W_BYTES = MAXT * 16 * KC, S_BYTES = MAXT * 1024, X_BYTES = NCT * 16 * KC * 4, IMG_BYTES = W_BYTES + S_BYTES + X_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
+    const bool pairs = a.epi == ST_EPI_SILU_MUL;
+    const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
+    const uint32_t S = a.ksplit > 1 ? a.ksplit : 1u, bg = (uint32_t)blockIdx.x / S, ks = (uint32_t)blockIdx.x - bg * S, ng = (uint32_t)gridDim.x / S;
+    if (bg >= ng) return;
+    const uint32_t t0 = um * (uint32_t)(((uint64_t)bg * units) / ng), t1 = um * (uint32_t)(((uint64_t)(bg + 1) * units) / ng);
+    if (t1 <= t0) return;
+    const uint32_t nt = t1 - t0;
+    const uint32_t nch_all = a.K / KC, ch0 = (uint32_t)(((uint64_t)ks * nch_all) / S);
+    const uint32_t nch = (uint32_t)(((uint64_t)(ks + 1) * nch_all) / S) - ch0;
+    const uint32_t kbase = ch0 * KC;
+    if (nch == 0) return;
+    const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
+    constexpr int KB = KC / 64;                 // k-blocks per MFMA wave and chunk
+    f4m acc[MAXT][NCT];
+    if (wave < 4) {
+        // ---- loader waves: piece q = 4 j + wave of the chunk (weights, then the tiles' scales, then activations), one DMA instruction each
+        const char* base[NIW];
+        uint32_t voff[NIW], sstep[NIW], doff[NIW];
+#pragma unroll
+        for (int j = 0; j < NIW; ++j) {
+            uint32_t q = (uint32_t)j * 4 + (uint32_t)wave;
+            q = q < (uint32_t)NI ? q : (uint32_t)NI - 1;                   // surplus slots repeat the last piece (same bytes to the same place)
+            auto tile_base = [&](uint32_t ts, bool scales) -> const char* {   // first row of the tile in slot ts of this workgroup
+                ts = ts < nt ? ts : nt - 1;
+                const uint32_t v = t0 + ts;
+                uint32_t g, tile;
+                if (pairs) { g = v & 1u; tile = v >> 1; }
+                else { g = v / tiles_per_mat; tile = v - g * tiles_per_mat; }
+                if (scales) return (const char*)((g == 0 ? a.ws[0] : (g == 1 ? a.ws[1] : a.ws[2])) + (size_t)tile * 16 * (a.K / 32) + kbase / 32);
+                return (const char*)(g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2])) + (size_t)tile * 16 * a.K + kbase;
+            };
+            if (q < (uint32_t)NWI) {
+                const uint32_t rr = q * RPW + (uint32_t)lane / GRW, gd = (uint32_t)lane % GRW, gs = gd ^ (rr & (uint32_t)(GRW - 1));
+                base[j] = tile_base((q * RPW) >> 4, false);
+                voff[j] = (rr & 15u) * a.K + gs * 16u;
+                sstep[j] = KC;
+                doff[j] = q * 1024u;
+            } else if (q < (uint32_t)(NWI + NSI)) {
+                const uint32_t ts = q - NWI;
+                constexpr uint32_t LPR = KC / 128;                         // lanes (16-byte pieces) per row's scales: 2 / 1
+                const uint32_t l = (uint32_t)lane & (16u * LPR - 1u);      // the other lanes repeat these into the padding
+                base[j] = tile_base(ts, true);
+                voff[j] = ((l / LPR) * (a.K / 32) + (l % LPR) * 4u) * 4u;
+                sstep[j] = (KC / 32) * 4;
+                doff[j] = W_BYTES + ts * 1024u;
+            } else {
+                const uint32_t xq = q - NWI - NSI;
+                const uint32_t rr = xq * RPX + (uint32_t)lane / GRX, gd = (uint32_t)lane % GRX, gs = gd ^ (rr & 15u);
+                const uint32_t c = rr < a.n ? rr : a.n - 1;
+                base[j] = (const char*)(a.x + kbase);
+                voff[j] = (c * a.ldx + gs * 4u) * 4u;
+                sstep[j] = KC * 4;
+                doff[j] = W_BYTES + S_BYTES + xq * 1024u;
+            }
+        }
+        auto issue = [&](uint32_t ch) {
+            const uint32_t cc = ch < nch ? ch : nch - 1;
+            char* im = smem_raw + (size_t)(ch % NIMG) * IMG_BYTES;
+#pragma unroll
+            for (int j = 0; j < NIW; ++j) {
+                const __amdgpu_buffer_rsrc_t rs = stream_rsrc(base[j]);
+                __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(im + doff[j]);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, (int)voff[j], (int)(cc * sstep[j]), 0, 0);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NIMG - 1; ++c) issue((uint32_t)c);
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            wait_vm<WAITN>();
+            __builtin_amdgcn_s_barrier();
+            issue(ch + NIMG - 1);
+        }
+        wait_vm<0>();
+    } else {
+        // ---- MFMA waves: dequantise on the operand-read side
+        const int cw = wave - 4;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            const char* im = smem_raw + (size_t)(ch % NIMG) * IMG_BYTES;
+            barrier_lds_only();
+#pragma unroll
+            for (int h = 0; h < KB; ++h) {
+                const uint32_t kbc = (uint32_t)(KB * cw + h);               // k-block of the chunk
+                f4 bf[NCT];
+                unsigned int raw[MAXT];
+                float d[MAXT];
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) bf[c] = *(const f4*)(im + W_BYTES + S_BYTES + ((size_t)(c * 16 + r16) * GRX + ((kbc * 4 + slot) ^ r16)) * 16);
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    raw[t] = *(const unsigned int*)(im + (size_t)(t * 16 + r16) * KC + (kbc ^ (r16 & (uint32_t)(GRW - 1))) * 16 + slot * 4);
+                    d[t] = *(const float*)(im + W_BYTES + (size_t)t * 1024 + r16 * (KC / 32) * 4 + (kbc >> 1) * 4);
+                }
+                f4 af[MAXT];
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const unsigned int pk = raw[t] ^ 0x80808080u;
+                    const float nd = __fmul_rn(d[t], -128.0f);
+                    af[t].x = fmaf(d[t], (float)(pk & 255u), nd);
+                    af[t].y = fmaf(d[t], (float)((pk >> 8) & 255u), nd);
+                    af[t].z = fmaf(d[t], (float)((pk >> 16) & 255u), nd);
+                    af[t].w = fmaf(d[t], (float)(pk >> 24), nd);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                        for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[c][s], acc[t][c], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    stream_epilogue<MAXT, NCT>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
+}
+
 // Second half of a K-split launch: token row b of  y = resid + ((p_0 + p_1) + ...) + p_{S-1}  (fixed order: bit-reproducible; Add
 // ml.go:2515-2584), and - gamma != nullptr - the RMSNorm * weight of that row for the next matmul into h (ml.go:1753-1812, 1877-1914: fp32
 // squares, f64 sum, one fp32 scale, two roundings per element - k_rmsnorm_rows' arithmetic on a row that is in registers anyway, so the

@@ -44,6 +44,8 @@ struct Plan {
     uint64_t scratch_gen = 0;                 // counts re-allocations of the scratch below (graphs captured elsewhere - lh_batch - compare it)
     float *xa = nullptr, *xb = nullptr, *h = nullptr, *qraw = nullptr, *kraw = nullptr, *vraw = nullptr, *q = nullptr, *attn = nullptr;
     float *a1 = nullptr, *a3 = nullptr, *g = nullptr, *logits = nullptr;
+    float* emb = nullptr;                     // LH_T_OUTPUT on llama.Eval's `embeddings`: the final norm rows [emb_cap][d]
+    uint32_t emb_cap = 0;
     float* attn_part = nullptr;               // split-T decode attention partials [H][chunks][hd + 2] (plans with ctx > 256)
     float *scores = nullptr, *vt = nullptr;   // large-N prefill attention: S[H][N][Tp], V^T[H][hd][Tp]
     uint64_t scores_cap = 0, vt_cap = 0;
@@ -108,6 +110,8 @@ bool plan_batch_rows_ok(const Plan* p, uint32_t n);   // can n rows of different
 // enqueue the kernels of one decode step (N = 1), parameters from p->sp_dev
 int plan_enqueue_decode(Plan* p, const float* x_in_dev, float* x_out_dev, bool with_argmax_advance, lh_kernel_time* prof, uint32_t prof_cap, uint32_t* prof_n);
 int plan_decode_step(Plan* p, uint32_t token, uint32_t past);  // graph replay of one step; logits in p->logits
+// `embeddings` of the last Eval (llama.go:381): RMSNorm * norm weight of the n final residual rows, into a plan-owned buffer [n][embd]
+int plan_embeddings(Plan* p, uint32_t n, float** out);
 void destroy_plans(lh_ctx* ctx);
 
 // sample.hip

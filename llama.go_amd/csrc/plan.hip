@@ -221,6 +221,14 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
     const uint32_t K4 = a.K / 4, rows_wg = a.M / (uint32_t)ctx->ds->num_cu + 4;
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
     if (K4 <= 4 * 256 && rows_wg <= 256) {
+        if constexpr (NC == 8) {   // weight rows in flight per wave (probe: LLAMAHIP_ROWS_U; the 32 FMAs per load stand between a wave's load bursts)
+            static int u8 = -1;
+            if (u8 < 0) { const char* e = getenv("LLAMAHIP_ROWS_U"); u8 = e ? atoi(e) : 2; }
+            if ((K4 + 255) / 256 == 4) {
+                if (u8 == 3) return launch_gemv_rows<4, 3, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+                if (u8 == 4) return launch_gemv_rows<4, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
+            }
+        }
         switch ((K4 + 255) / 256) {
             case 1: return launch_gemv_rows<1, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
             case 2: return launch_gemv_rows<2, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
@@ -608,6 +616,38 @@ static int launch_stream_dma(lh_ctx* ctx, const StreamArgs& a, const char* name)
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
+// ---- k_stream_q8 (kernels_stream.h): block-int8 weights on the LDS-DMA structure, dequantised by the MFMA waves.  Chunk = 256 columns where
+// three images fit, else 128 (LLAMAHIP_Q8_KC overrides for A/B runs).
+constexpr int q8_nimg_fit(int maxt, int nct, int kc) {
+    const int n = (int)(160 * 1024 / stream_q8_image_bytes(maxt, nct, kc));
+    return n < 4 ? n : 4;
+}
+template <int MAXT, int NCT, int KC, int NIMG>
+static int launch_stream_q8(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    static_assert(NIMG >= 2, "ring");
+    static bool flags[16] = {};
+    auto kern = k_stream_q8<MAXT, NCT, KC, NIMG>;
+    const size_t lds = std::max<size_t>((size_t)NIMG * stream_q8_image_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
+    int rc = set_lds_once(ctx, kern, lds, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K / 32 * 36);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+template <int MAXT, int NCT>
+static int launch_stream_q8_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    static int kc_env = -1;
+    if (kc_env < 0) { const char* e = getenv("LLAMAHIP_Q8_KC"); kc_env = e ? atoi(e) : 0; }
+    constexpr int N256 = q8_nimg_fit(MAXT, NCT, 256), N128 = q8_nimg_fit(MAXT, NCT, 128);
+    static_assert(N128 >= 2, "two images of 128-column chunks fit every built shape");
+    if constexpr (N256 >= 2) {
+        if ((kc_env == 256 || (kc_env == 0 && N256 >= 3)) && a.K % 256 == 0) return launch_stream_q8<MAXT, NCT, 256, N256>(ctx, a, name);
+    }
+    return launch_stream_q8<MAXT, NCT, 128, N128>(ctx, a, name);
+}
 // variants: 0 = 64-column chunks, as many images as fit (<= 4); 2 = 128-column chunks, two images; 1 / 3 = the same with pipelined operands
 // (measured round 4, profiles/r04_stream_dma_variants.txt: the operand pipeline buys nothing on two to six column tiles - the LDS
 // latency behind a barrier is not what idles the matrix pipe - so only the eight-column-tile launches are built with it)
@@ -646,6 +686,9 @@ static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name)
     if constexpr (NCT >= 2) {
         const int ve = stream_dma_variant_env();
         if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
+    }
+    if constexpr (NCT <= 3) {   // block-int8, up to 48 rows: raw bytes by LDS-DMA, dequantised by the MFMA waves (no folded norm: the host runs the norm's own launch)
+        if (a.ws[0] && !a.gamma && !a.tiled && stream_dma_variant_env() != -1) return launch_stream_q8_kc<MAXT, NCT>(ctx, a, name);
     }
     if constexpr (NCT > 6) return ST_NA;   // (k_stream_mm2 holds MAXT x NCT accumulator tiles per wave: up to six column tiles)
     else return launch_stream_kc<MAXT, NCT>(ctx, a, name);
@@ -980,7 +1023,7 @@ void plan_destroy(Plan* p) {
     drop_graphs(p, ~0u);
     if (p->ss_dev) hipFree(p->ss_dev);
     if (p->ring_dev) hipFree(p->ring_dev);
-    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part, p->fa_part};
+    float* bufs[] = {p->xa, p->xb, p->h, p->qraw, p->kraw, p->vraw, p->q, p->attn, p->a1, p->a3, p->g, p->logits, p->scores, p->vt, p->part, p->fa_part, p->emb};
     for (float* b : bufs) if (b) hipFree(b);
     if (p->tokens_dev) hipFree(p->tokens_dev);
     if (p->sp_dev) hipFree(p->sp_dev);
@@ -1148,6 +1191,25 @@ static int upload_step_params(Plan* p, uint32_t slot, uint32_t token, uint32_t p
     lh_ctx* ctx = p->ctx;
     hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, ctx->stream, p->sp_dev + slot, token, past, step);
     LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+int plan_embeddings(Plan* p, uint32_t n, float** out) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    if (!m.last_stage() || n == 0 || n > p->n_cap) LH_FAIL(ctx, LH_EINVAL, "embeddings: the last Eval of this plan had no %u final rows", n);
+    if (n > p->emb_cap) {
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p->emb) LH_HIP(ctx, hipFree(p->emb));
+        p->emb = nullptr; p->emb_cap = 0;
+        LH_HIP(ctx, hipMalloc((void**)&p->emb, (size_t)n * m.d * 4));
+        p->emb_cap = n;
+    }
+    // every route of plan_eval leaves the residual rows behind the last layer in p->xa; RMSNorm (ml.go:1753-1812) then Mul by the norm weight
+    // (ml.go:1877-1914): k_rmsnorm_rows' arithmetic (fp32 squares, f64 sum, one fp32 scale, two roundings per element)
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xa, m.norm, p->emb, m.d);
+    LH_HIP(ctx, hipGetLastError());
+    *out = p->emb;
     return 0;
 }
 
@@ -1465,7 +1527,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         StreamArgs fq = {};
         fq.epi = ST_EPI_QKV_ROPE; fq.q_out = p->q; fq.k_cache = m.kc + slot; fq.v_cache = m.vc + slot; fq.rope = rope; fq.hd = m.hd; fq.past = past;
         fq.rows = rows; fq.kv_off = slot;
-        if (n <= stream_max_rows() && n <= 16 && (q8 || mfma)) {
+        const bool fold_norm = n <= 16 && (q8 ? stream_dma_variant_env() == -1 : mfma);   // (block-int8: k_stream_q8 moves raw bytes - the norm keeps its own launch)
+        if (n <= stream_max_rows() && fold_norm) {
             // short prompts: ONE launch for RMSNorm (folded: gamma at staging, the per-token scale in the epilogue) -> wq|wk|wv -> RoPE -> cache append
             // (folded up to 16 rows: -3..5 % per Eval; at 17..32 rows the extra staging work of the loader waves eats the saved launch)
             StreamArgs fa = fq;
@@ -1526,7 +1589,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const float* s13[2] = {L.s_w1, L.s_w3};
         float* y13[2] = {p->a1, p->a3};
         float* yg[2] = {p->g, nullptr};
-        if (n <= stream_max_rows() && n <= 16 && (q8 || mfma)) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
+        if (n <= stream_max_rows() && fold_norm) {   // short prompts: RMSNorm (folded) -> w1|w3 -> silu * mul in one launch
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
             fa.gamma = L.ffn_norm;

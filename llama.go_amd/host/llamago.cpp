@@ -70,6 +70,7 @@ struct ml_tensor {  // ml.Tensor ml.go:180-203
     ml_context* last_ctx = nullptr;
     uint64_t last_gen = 0;
     uint32_t last_index = 0;
+    bool want_output = false;  // the host reads this node's Data after GraphCompute (-> LH_T_OUTPUT)
     ml_tensor *gc_next = nullptr, *gc_prev = nullptr;  // per-thread list of constructor-made tensors (see ml_FreeGraph)
     bool gc_owned = false;
     // scratch marks of graph construction / flattening (valid when the generation matches): no hash containers on the Eval path
@@ -311,6 +312,7 @@ static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
         lh_tensor& o = T[i];
         memset(&o, 0, sizeof o);
         o.op = (uint8_t)t->op;
+        o.flags = t->want_output ? LH_T_OUTPUT : 0;
         o.dtype = (uint8_t)(t->type == ML_TYPE_I32 ? ML_TYPE_F32 : t->type);  // "I32" parameter tensors hold fp32 (ml.go:864-867)
         for (int k = 0; k < 4; ++k) { o.ne[k] = t->ne[k]; o.nb[k] = t->nb[k]; }
         o.src0 = t->src0 ? index_of(t->src0) : -1;
@@ -379,6 +381,7 @@ struct llama_context {  // llama.go:83-88
     llama_model* model;
     uint32_t ctxSize;
     uint32_t keepCount = 0;        // ModelParams.KeepCount llama.go:47
+    std::vector<float> embedding;  // lctx.Embedding (llama.go:88; allocated when ModelParams.Embedding is set, llama.go:414-419)
     lh_llama* resident = nullptr;  // plan handle for the device-resident loop / stages (created on demand)
     bool holds_model = false;
 };
@@ -743,6 +746,8 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
     do {
         ml_tensor* inpL = build_eval_graph(ctx0, model, lctx->K, lctx->V, ctxSize, tokens, N, pastCount, graph);
         if (!inpL) break;
+        ml_tensor* embeddings = inpL->src1;   // llama.go:381: the lm_head's input, norm * weight rows
+        if (!lctx->embedding.empty() && embeddings) embeddings->want_output = true;   // a fused plan then keeps it (LH_T_OUTPUT)
         const long t_build = us_since(tp0);
         const auto tp1 = std::chrono::steady_clock::now();
         {   // :389 — this caller reads only row N-1 of the result (:394-401) and says so
@@ -753,6 +758,9 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
         const long t_compute = us_since(tp1);
         const auto tp2 = std::chrono::steady_clock::now();
         if (lh_node_read(ctx0->hip, inpL->last_index, (uint64_t)vocabSize * (N - 1), lctx->logits.data(), vocabSize)) { g_err = lh_last_error(ctx0->hip); break; }
+        if (!lctx->embedding.empty()) {   // llama.go:414-419: row N-1 of `embeddings`
+            if (lh_node_read(ctx0->hip, embeddings->last_index, (uint64_t)model->hp.embdSize * (N - 1), lctx->embedding.data(), model->hp.embdSize)) { g_err = lh_last_error(ctx0->hip); break; }
+        }
         if (timing) fprintf(stderr, "[llamago] Eval N=%u: graph build %ld us, GraphCompute %ld us, logits read %ld us\n", N, t_build, t_compute, us_since(tp2));
         rc = 0;
     } while (0);
@@ -849,6 +857,9 @@ int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prom
     }
     return 0;
 }
+// ModelParams.Embedding (llama.go:52): lctx.Embedding is allocated and every Eval leaves row N-1 of `embeddings` in it (llama.go:414-419)
+void llamago_EnableEmbedding(llama_context* c) { if (c) c->embedding.assign(c->model->hp.embdSize, 0.f); }
+const float* llama_Embedding(llama_context* c) { return (c && !c->embedding.empty()) ? c->embedding.data() : nullptr; }
 void llamago_SetKeepCount(llama_context* c, uint32_t keep) {
     if (!c) return;
     c->keepCount = keep;

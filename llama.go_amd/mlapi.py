@@ -302,6 +302,18 @@ class Context:
             raise MLError(f"llama_GreedyDecode: {self.ml.last_error()}")
         return list(out), lg
 
+    def EnableEmbedding(self):
+        """ModelParams.Embedding (llama.go:52): every Eval also leaves row N-1 of `embeddings` in lctx.Embedding (llama.go:414-419)."""
+        self.ml.lib.llamago_EnableEmbedding.restype = None
+        self.ml.lib.llamago_EnableEmbedding.argtypes = [VP]
+        self.ml.lib.llamago_EnableEmbedding(self.h)
+
+    def Embedding(self):
+        self.ml.lib.llama_Embedding.restype = c_f32p
+        self.ml.lib.llama_Embedding.argtypes = [VP]
+        p = self.ml.lib.llama_Embedding(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.model.hp.embdSize,)).copy() if p else None
+
     def SetKeepCount(self, keep):
         """ModelParams.KeepCount (llama.go:47): what a context swap keeps (server.go:166-167)."""
         self.ml.lib.llamago_SetKeepCount.restype = None

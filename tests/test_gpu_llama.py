@@ -446,6 +446,35 @@ def test_committed_golden_vectors_on_the_gpu(product):
     m.free()
 
 
+@pytest.mark.parametrize("n_prompt", [1, 3, 8, 20, 70, 130])
+def test_embeddings_of_a_fused_eval_match_oracle(product, oracle, n_prompt):
+    """lctx.Embedding (llama.go:381, 414-419): row N-1 of the final norm * weight rows.  The fused plan's lm_head launches never write those
+    rows out; the Eval graph flags the node LH_T_OUTPUT and the plan materialises it - for every route an Eval takes (decode step, rows
+    kernel, stream kernels, tile GEMM), prompt and the decode steps behind it."""
+    hp = make_hparams(**SHAPES["small"], ctx=160)
+    rng = np.random.default_rng(n_prompt)
+    prompt = [int(t) for t in rng.integers(0, hp.vocabSize, n_prompt)]
+    got = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 7)
+        c = m.NewContext(160, 16, False)
+        c.EnableEmbedding()
+        lg = c.Eval(prompt, 0)
+        e0 = c.Embedding()
+        tok = int(np.argmax(lg))
+        lg1 = c.Eval([tok], n_prompt)
+        e1 = c.Embedding()
+        if name == "hip":
+            product.lib.llamago_LastGraphFused.restype = C.c_int
+            product.lib.llamago_LastGraphFused.argtypes = [C.c_void_p]
+            assert product.lib.llamago_LastGraphFused(product.lib.llama_MLContext(c.h)) == 1, "the flagged Eval graph must stay on the fused plan"
+        got[name] = (e0, e1, lg, lg1)
+        c.free()
+        m.free()
+    for k in range(4):
+        assert rel(got["hip"][k], got["orc"][k]) <= TOL, k
+
+
 def test_out_of_range_token_is_an_error_not_a_gpu_fault(product):
     """A token id >= vocab makes Go panic on the embedding slice (ml.go:1748); here it must come back as an error."""
     hp = make_hparams(**SHAPES["tiny"], ctx=8)
