@@ -246,6 +246,9 @@ int lh_comm_init(lh_ctx* ctx, int rank, int world, const uint8_t id[LH_COMM_ID_B
 typedef struct lh_comm_hooks {
     void* user;
     int (*exchange)(void* user, const void* send_host, uint64_t send_bytes, int send_peer, void* recv_host, uint64_t recv_bytes, int recv_peer);
+    /* optional (may be NULL): lh_comm_abort on this transport - make what the PEERS have pending against this rank fail instead of
+     * block (the counterpart of ncclCommAbort: e.g. send them a message of the wrong size, or close the connection) */
+    void (*abort)(void* user);
 } lh_comm_hooks;
 int lh_comm_init_hooks(lh_ctx* ctx, int rank, int world, const lh_comm_hooks* hooks, lh_comm** out);
 void lh_comm_destroy(lh_comm* comm);
@@ -299,6 +302,16 @@ int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint3
  * lh_llama_decode_sample with the same seed) instead of the argmax.  prompts must be given on rank 0 AND on the last rank (the
  * repeat penalty needs the ring there).  run_sample(NULL, NULL, K, sp, ring) continues sampled streams. */
 int lh_pipeline_run_sample(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, const lh_sample_params* sp, uint32_t ring_size);
+/* Where the time of a run goes on THIS rank (the N > 1 curve's diagnosis): with profiling on, every tick of the following runs is bracketed
+ * by HIP events on the compute stream - in front of the stage, behind it, behind the exchange - and the totals accumulate: stage_ms = the
+ * rank's own kernels, exchange_ms = from the end of its stage to the end of its send / receive (RCCL: includes waiting for the predecessor's
+ * data, i.e. pipeline bubbles show up here).  Three event records per tick (~ 5 us): not for the timed headline run. */
+typedef struct lh_pipeline_stats { uint32_t ticks; float stage_ms, exchange_ms; } lh_pipeline_stats;
+int lh_pipeline_profile(lh_pipeline* pl, int on);                      /* on: also clears the totals */
+int lh_pipeline_stats_read(lh_pipeline* pl, lh_pipeline_stats* out);
+/* Pre-flight of the ring: microseconds per grouped send + receive of `bytes` to the successor / from the predecessor (every rank calls it
+ * at the same time; 16 KB = one 7B residual row).  SURVEY 8e expects 10-20 us per hop over xGMI. */
+int lh_pipeline_hop_probe(lh_pipeline* pl, uint32_t bytes, uint32_t iters, float* us_per_hop);
 /* Token ids this rank knows for a stream since creation (rank 0: received from the last rank; last rank: produced). */
 int lh_pipeline_tokens(lh_pipeline* pl, uint32_t pod, uint32_t* out, uint32_t cap);
 

@@ -134,6 +134,12 @@ struct lh_pipeline {
     uint32_t d = 0, ctx_size = 0, vocab = 0;
     bool started = false;           // a prompt has been run: there is a token to continue from (the same on every rank)
     bool sampling = false;
+    // lh_pipeline_profile: HIP events around every stage and every exchange of a run (where a shortfall of the N > 1 curve comes from:
+    // the rank's own compute or the hops)
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;     // 3 per tick: before the stage, behind it, behind the exchange
+    uint32_t ev_used = 0;
+    lh_pipeline_stats stats = {};
 };
 
 extern "C" {
@@ -191,6 +197,7 @@ void lh_comm_destroy(lh_comm* cm) {
 int lh_comm_abort(lh_comm* cm) {
     if (!cm) return LH_EINVAL;
     if (cm->nccl && cm->r->CommAbort) { cm->r->CommAbort(cm->nccl); cm->nccl = nullptr; }
+    if (cm->use_hooks && cm->hooks.abort && !cm->aborted) cm->hooks.abort(cm->hooks.user);   // the transport's own way of failing the peers' pending receives
     cm->aborted = true;
     return LH_OK;
 }
@@ -337,6 +344,7 @@ void lh_pipeline_destroy(lh_pipeline* pl) {
     if (!pl) return;
     hipSetDevice(pl->ctx->device);
     hipStreamSynchronize(pl->ctx->stream);
+    for (hipEvent_t e : pl->ev) hipEventDestroy(e);
     for (Group& gr : pl->groups) {
         if (gr.batch) lh_batch_destroy(gr.batch);
         if (gr.x_in) hipFree(gr.x_in);
@@ -476,7 +484,26 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
         if (rs >= 0 && first && !last) return record(pl->groups[rs], lh_batch_tokens_dev(pl->groups[rs].batch));
         return 0;
     };
-    rc = run_ticks(r, R, G, units, stage, exchange);
+    // profiling: the same ticks with three events each on the compute stream (read back behind the run's final synchronisation)
+    pl->ev_used = 0;
+    auto mark = [&]() -> int {
+        if (pl->ev_used == pl->ev.size()) { hipEvent_t e; LH_HIP(ctx, hipEventCreate(&e)); pl->ev.push_back(e); }
+        LH_HIP(ctx, hipEventRecord(pl->ev[pl->ev_used++], ctx->stream));
+        return 0;
+    };
+    auto stage_p = [&](uint32_t g, uint32_t u) -> int {
+        int rc2;
+        if (pl->profiling && (rc2 = mark())) return rc2;
+        if ((rc2 = stage(g, u))) return rc2;
+        return pl->profiling ? mark() : 0;
+    };
+    auto exchange_p = [&](int32_t s, int32_t u, int32_t rs, int32_t ru) -> int {
+        int rc2;
+        if (pl->profiling && s < 0) { if ((rc2 = mark()) || (rc2 = mark())) return rc2; }   // a receive-only tick: an empty stage interval
+        if ((rc2 = exchange(s, u, rs, ru))) return rc2;
+        return pl->profiling ? mark() : 0;
+    };
+    rc = run_ticks(r, R, G, units, stage_p, exchange_p);
     if (rc) {
         // a rank that fails mid-run must not leave its peers waiting in a receive: tear the communicator down (RCCL: abort; the peers'
         // pending operations then fail instead of blocking).  The pipeline is unusable afterwards.
@@ -485,7 +512,56 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
     }
     if (prefill) pl->started = true;
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (pl->profiling) {
+        for (uint32_t i = 0; i + 2 < pl->ev_used; i += 3) {
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, pl->ev[i], pl->ev[i + 1]) == hipSuccess && hipEventElapsedTime(&b, pl->ev[i + 1], pl->ev[i + 2]) == hipSuccess) {
+                pl->stats.ticks += 1; pl->stats.stage_ms += a; pl->stats.exchange_ms += b;
+            }
+        }
+    }
     return LH_OK;
+}
+
+int lh_pipeline_profile(lh_pipeline* pl, int on) {
+    if (!pl) return LH_EINVAL;
+    pl->profiling = on != 0;
+    if (on) pl->stats = lh_pipeline_stats{};
+    return LH_OK;
+}
+int lh_pipeline_stats_read(lh_pipeline* pl, lh_pipeline_stats* out) {
+    if (!pl || !out) return LH_EINVAL;
+    *out = pl->stats;
+    return LH_OK;
+}
+// `iters` ring shifts of `bytes` (every rank sends to its successor and receives from its predecessor in one grouped call, as a tick's
+// exchange does), timed with HIP events on the compute stream: microseconds per shift.  World of one: a self send/recv.
+int lh_pipeline_hop_probe(lh_pipeline* pl, uint32_t bytes, uint32_t iters, float* us_per_hop) {
+    if (!pl || !us_per_hop || !bytes || !iters) return LH_EINVAL;
+    lh_ctx* ctx = pl->ctx;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (!pl->comm) { *us_per_hop = 0.f; return LH_OK; }
+    void *sb = nullptr, *rb = nullptr;
+    LH_HIP(ctx, hipMalloc(&sb, bytes));
+    LH_HIP(ctx, hipMalloc(&rb, bytes));
+    LH_HIP(ctx, hipMemsetAsync(sb, 0, bytes, ctx->stream));
+    const int R = pl->world, r = pl->rank;
+    int rc = 0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (uint32_t i = 0; i < 8 && !rc; ++i) rc = lh_comm_exchange(pl->comm, sb, bytes, (r + 1) % R, rb, bytes, (r + R - 1) % R);   // warm-up: connections, buffers
+    if (!rc) {
+        hipEventRecord(e0, ctx->stream);
+        for (uint32_t i = 0; i < iters && !rc; ++i) rc = lh_comm_exchange(pl->comm, sb, bytes, (r + 1) % R, rb, bytes, (r + R - 1) % R);
+        hipEventRecord(e1, ctx->stream);
+    }
+    hipStreamSynchronize(ctx->stream);
+    float ms = 0.f;
+    if (!rc) hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(sb); hipFree(rb);
+    *us_per_hop = ms * 1e3f / (float)iters;
+    return rc;
 }
 
 int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps) {

@@ -1150,47 +1150,79 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
             __builtin_amdgcn_s_barrier();
             issue(ch + NIMG - 1);
         }
+        __builtin_amdgcn_s_barrier();           // the MFMA waves' barrier in front of their last k-block (their pipeline looks one k-block ahead)
         wait_vm<0>();
     } else {
-        // ---- MFMA waves: dequantise on the operand-read side
+        // ---- MFMA waves: dequantise on the operand-read side.  Software pipeline over the k-blocks of a chunk: while k-block h multiplies, the
+        // raw quants and scales of k-block h + 1 (requested in front of it) are converted - sched_group_barrier pins the interleave, a few
+        // vector instructions behind every MFMA; left to itself the compiler converts a whole k-block and only then starts its MFMAs, and the
+        // matrix pipe idles through every conversion (measured: 51 us instead of 31 for w1|w3 of 7B at <= 16 rows).
         const int cw = wave - 4;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
+        f4 af[2][MAXT], bf[2][NCT];
+        unsigned int raw[MAXT];
+        float d[MAXT];
+        auto load_ops = [&](const char* im, int h, f4 (&b)[NCT]) {
+            const uint32_t kbc = (uint32_t)(KB * cw + h);               // k-block of the chunk
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) b[c] = *(const f4*)(im + W_BYTES + S_BYTES + ((size_t)(c * 16 + r16) * GRX + ((kbc * 4 + slot) ^ r16)) * 16);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                raw[t] = *(const unsigned int*)(im + (size_t)(t * 16 + r16) * KC + (kbc ^ (r16 & (uint32_t)(GRW - 1))) * 16 + slot * 4);
+                d[t] = *(const float*)(im + W_BYTES + (size_t)t * 1024 + r16 * (KC / 32) * 4 + (kbc >> 1) * 4);
+            }
+        };
+        auto dequant = [&](f4 (&a4)[MAXT]) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const unsigned int pk = raw[t] ^ 0x80808080u;
+                const float nd = __fmul_rn(d[t], -128.0f);
+                a4[t].x = fmaf(d[t], (float)(pk & 255u), nd);
+                a4[t].y = fmaf(d[t], (float)((pk >> 8) & 255u), nd);
+                a4[t].z = fmaf(d[t], (float)((pk >> 16) & 255u), nd);
+                a4[t].w = fmaf(d[t], (float)(pk >> 24), nd);
+            }
+        };
+        auto mfmas = [&](const f4 (&a4)[MAXT], const f4 (&b)[NCT]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][s], b[c][s], acc[t][c], 0, 0, 0);
+        };
+        constexpr int NM = 4 * MAXT * NCT, NV = 10 * MAXT, VPM = (NV + NM - 1) / NM;   // MFMAs of a k-block, vector instructions of one conversion, of them behind each MFMA
+        static_assert(KB % 2 == 0, "the two operand sets alternate by k-block parity across chunks");
+        // The pipeline runs ACROSS chunks: the step behind the last k-block of chunk ch is the first of chunk ch + 1, so barrier ch + 1 stands
+        // in front of that k-block's MFMAs (its operands are in registers by then: the image of chunk ch is not read any more).
+        barrier_lds_only();                     // barrier 0
+        load_ops(smem_raw, 0, bf[0]);
+        dequant(af[0]);
         for (uint32_t ch = 0; ch < nch; ++ch) {
             const char* im = smem_raw + (size_t)(ch % NIMG) * IMG_BYTES;
-            barrier_lds_only();
 #pragma unroll
             for (int h = 0; h < KB; ++h) {
-                const uint32_t kbc = (uint32_t)(KB * cw + h);               // k-block of the chunk
-                f4 bf[NCT];
-                unsigned int raw[MAXT];
-                float d[MAXT];
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) bf[c] = *(const f4*)(im + W_BYTES + S_BYTES + ((size_t)(c * 16 + r16) * GRX + ((kbc * 4 + slot) ^ r16)) * 16);
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    raw[t] = *(const unsigned int*)(im + (size_t)(t * 16 + r16) * KC + (kbc ^ (r16 & (uint32_t)(GRW - 1))) * 16 + slot * 4);
-                    d[t] = *(const float*)(im + W_BYTES + (size_t)t * 1024 + r16 * (KC / 32) * 4 + (kbc >> 1) * 4);
+                // straight-line, no condition on the chunk index (a branch splits the block and the interleave with it): behind the LAST chunk
+                // the step reads and converts whatever the ring's next image holds (the loader's clamped tail request) - never multiplied
+                __builtin_amdgcn_sched_barrier(0);
+                if (h + 1 < KB) load_ops(im, h + 1, bf[(h + 1) & 1]);
+                else {
+                    barrier_lds_only();         // barrier ch + 1: the next chunk is in its image (and the loader may refill chunk ch's)
+                    load_ops(smem_raw + (size_t)((ch + 1) % NIMG) * IMG_BYTES, 0, bf[0]);
                 }
-                f4 af[MAXT];
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(af[h & 1], bf[h & 1]);
+                dequant(af[(h + 1) & 1]);
 #pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    const unsigned int pk = raw[t] ^ 0x80808080u;
-                    const float nd = __fmul_rn(d[t], -128.0f);
-                    af[t].x = fmaf(d[t], (float)(pk & 255u), nd);
-                    af[t].y = fmaf(d[t], (float)((pk >> 8) & 255u), nd);
-                    af[t].z = fmaf(d[t], (float)((pk >> 16) & 255u), nd);
-                    af[t].w = fmaf(d[t], (float)(pk >> 24), nd);
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-                        for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][s], bf[c][s], acc[t][c], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();

@@ -1106,6 +1106,20 @@ int llamago_PipelineRun(llama_pipeline* p, const uint32_t* const* prompts, const
     if (lh_pipeline_run(p->pl, prompts, n_prompt, steps)) return halt_rc(lh_last_error(p->mlctx->hip));
     return 0;
 }
+int llamago_PipelineProfile(llama_pipeline* p, int on) { return p ? lh_pipeline_profile(p->pl, on) : 1; }
+int llamago_PipelineStats(llama_pipeline* p, uint32_t* ticks, float* stage_ms, float* exchange_ms) {
+    lh_pipeline_stats st;
+    if (!p || lh_pipeline_stats_read(p->pl, &st)) return 1;
+    if (ticks) *ticks = st.ticks;
+    if (stage_ms) *stage_ms = st.stage_ms;
+    if (exchange_ms) *exchange_ms = st.exchange_ms;
+    return 0;
+}
+int llamago_PipelineHopProbe(llama_pipeline* p, uint32_t bytes, uint32_t iters, float* us_per_hop) {
+    if (!p) return 1;
+    if (lh_pipeline_hop_probe(p->pl, bytes, iters, us_per_hop)) return halt_rc(lh_last_error(p->mlctx->hip));
+    return 0;
+}
 int llamago_PipelineTokens(llama_pipeline* p, uint32_t pod, uint32_t* out, uint32_t cap) {
     const int n = lh_pipeline_tokens(p->pl, pod, out, cap);
     if (n < 0) g_err = lh_last_error(p->mlctx->hip);

@@ -465,6 +465,28 @@ class Pipeline:
         if rc:
             raise MLError(f"llamago_PipelineRun: {self.ml.last_error()}")
 
+    def profile(self, on=True):
+        """lh_pipeline_profile: HIP events around every stage and exchange of the following runs (clears the totals)."""
+        self.ml.lib.llamago_PipelineProfile.argtypes = [VP, C.c_int]
+        if self.ml.lib.llamago_PipelineProfile(self.h, 1 if on else 0):
+            raise MLError("llamago_PipelineProfile failed")
+
+    def stats(self):
+        """Totals since profile(True): dict(ticks, stage_ms, exchange_ms) of THIS rank."""
+        t, a, b = c_u32(0), C.c_float(0), C.c_float(0)
+        self.ml.lib.llamago_PipelineStats.argtypes = [VP, c_u32p, c_f32p, c_f32p]
+        if self.ml.lib.llamago_PipelineStats(self.h, C.byref(t), C.byref(a), C.byref(b)):
+            raise MLError("llamago_PipelineStats failed")
+        return dict(ticks=int(t.value), stage_ms=float(a.value), exchange_ms=float(b.value))
+
+    def hop_probe(self, nbytes=16384, iters=1000):
+        """Microseconds per ring shift of nbytes (every rank at the same time)."""
+        us = C.c_float(0)
+        self.ml.lib.llamago_PipelineHopProbe.argtypes = [VP, c_u32, c_u32, c_f32p]
+        if self.ml.lib.llamago_PipelineHopProbe(self.h, nbytes, iters, C.byref(us)):
+            raise MLError(f"llamago_PipelineHopProbe: {self.ml.last_error()}")
+        return float(us.value)
+
     def tokens(self, pod):
         cap = 1 << 16
         out = (c_u32 * cap)()

@@ -51,9 +51,12 @@ class _PipelineHooks(C.Structure):
 COMM_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_int)
 
 
+COMM_ABORT_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
 class CommHooks(C.Structure):
     """lh_comm_hooks."""
-    _fields_ = [("user", C.c_void_p), ("exchange", COMM_EXCHANGE_FN)]
+    _fields_ = [("user", C.c_void_p), ("exchange", COMM_EXCHANGE_FN), ("abort", COMM_ABORT_FN)]
 
 
 _lib = None
@@ -145,5 +148,15 @@ def gloo_comm_hooks(dist):
             print(f"gloo transport failed: {e!r}", file=sys.stderr, flush=True)
             return -1
 
-    hooks = CommHooks(None, COMM_EXCHANGE_FN(_exchange))
+    def _abort(_user):
+        # lh_comm_abort: the successor is (or will be) waiting for this rank's rows - a one-byte message where it expects more makes its
+        # receive fail (gloo: message size mismatch) instead of block; its own abort then passes the failure on round the ring
+        try:
+            world, rank = dist.get_world_size(), dist.get_rank()
+            if world > 1:
+                dist.isend(torch.zeros(1, dtype=torch.uint8), (rank + 1) % world)
+        except BaseException:
+            pass
+
+    hooks = CommHooks(None, COMM_EXCHANGE_FN(_exchange), COMM_ABORT_FN(_abort))
     return hooks

@@ -25,7 +25,16 @@ l0, l1 = layer_range(rank, world, hp.layersCount)
 m = prod.NewSyntheticModel(hp, 17, l0, l1)
 pl = Pipeline(m, ctx, len(prompts), rank, world, hooks=gloo_comm_hooks(dist))
 smp = dict(topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=777)
-if sample:
+if sample == 2:
+    # failure path: rank 0 sees a bad prompt and aborts the communicator; every other rank must FAIL its run (the transport's abort hook
+    # poisons its pending receive) instead of waiting forever.  Every rank reports what happened to it on stderr-free stdout lines.
+    try:
+        pl.run(prompts, steps)
+        print(json.dumps({"rank": rank, "failed": False}), flush=True)
+    except Exception as e:
+        print(json.dumps({"rank": rank, "failed": True, "error": str(e)[:200]}), flush=True)
+    os._exit(0)
+elif sample:
     pl.run_sample(prompts, steps, **smp)
     pl.run_sample(None, 2, **smp)
 else:

@@ -109,6 +109,29 @@ def test_pipeline_two_ranks_share_one_gpu_greedy_and_sampled(product, sample):
     m.free()
 
 
+def test_a_failing_rank_takes_its_peers_down_instead_of_leaving_them_waiting(product):
+    """Rank 0 is handed a token id outside the vocabulary: it refuses the run and aborts the communicator (lh_comm_abort).  On the
+    host-staged transport that is the hooks' abort callback (a poison message); rank 1, which is waiting for rank 0's rows, must fail its
+    run within seconds - with RCCL it is ncclCommAbort that does this."""
+    from llama_go_amd.mlapi import SHAPES
+    prompts = [[1, 2, 3], [4, SHAPES["small"]["vocab"] + 5]]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "pipeline_worker.py"), "small", "40", "3", "2", json.dumps(prompts)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)   # (a hang would hit the 120 s gloo timeout at best)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.strip().startswith("{") and '"rank"' in l]
+    by_rank = {d["rank"]: d for d in lines}
+    assert set(by_rank) == {0, 1}, (r.stdout[-1500:], r.stderr[-3000:])
+    assert by_rank[0]["failed"] and "vocabulary" in by_rank[0]["error"]
+    assert by_rank[1]["failed"], by_rank[1]
+
+
 def test_rccl_transport_world_of_one(product, oracle):
     """lh_comm_unique_id / lh_comm_init / lh_comm_exchange on real RCCL with the one GPU of the box: a world of one rank sends the
     produced token id to itself (grouped ncclSend + ncclRecv on the context's stream).  Streams must equal the checker's greedy ids."""
@@ -150,8 +173,8 @@ def test_pipeline_argument_errors(product):
         pl.run(None, 2)                    # nothing to continue from
     with pytest.raises(MLError):
         pl.run([[1, 2], [9999]], 1)        # token id outside the vocabulary
-    with pytest.raises(MLError):
-        pl.run([[1, 2], [3]], 40)          # leaves the context window
+    pl.run([[1, 2], [3]], 40)              # past the window of 32: an unsharded pipeline swaps context like server.Do (tests/test_context_swap.py)
+    assert len(pl.tokens(0)) == 41 and len(pl.tokens(1)) == 41
     pl.run([[1, 2], [3]], 2)
     assert len(pl.tokens(0)) == 3 and len(pl.tokens(1)) == 3
     pl.free()
