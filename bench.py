@@ -338,7 +338,9 @@ def main():
             try:
                 from llama_go_amd.mlapi import Pipeline
                 pb = {}
-                for P in (4, 8, 16, 32):
+                wb_tick, kv_row = bytes_per_token(d, L, F, V, P0 + W + (K + 1) / 2.0)
+                macs_row = L * (4 * d * d + 3 * d * F) + V * d   # weight MACs of one stream's token
+                for P in (4, 8, 16, 32, 64):
                     plb = Pipeline(model, ctx_size, P, 0, 1)
                     plb.run([PROMPT] * P, max(W, 1))
                     torch.cuda.synchronize()
@@ -350,10 +352,17 @@ def main():
                     plb.free()
                     solo = [first] + toks   # the single stream's ids from the same prompt (timed region above)
                     n_c = min(len(solo), len(ids_b[0]))
-                    pb[str(P)] = {"tokens_per_s": round(P * K / d_b, 1), "ms_per_tick": round(d_b / K * 1e3, 4),
+                    tick = d_b / K
+                    # a tick reads the weights once + every row's KV; its matmuls are P rows deep: both rooflines, the binding one named
+                    f_hbm = (wb_tick + P * kv_row) / tick / (HBM_PEAK_GBPS * 1e9)
+                    f_mfma = 2.0 * P * macs_row / tick / 157.3e12
+                    pb[str(P)] = {"tokens_per_s": round(P * K / d_b, 1), "ms_per_tick": round(tick * 1e3, 4),
+                                  "frac_of_hbm_roofline": round(f_hbm, 4), "frac_of_fp32_mfma_peak": round(f_mfma, 4), "bound": "hbm" if f_hbm >= f_mfma else "mfma",
                                   "ids_match_single_stream": all(t[:n_c] == solo[:n_c] for t in ids_b)}
                 result["pods_batched"] = dict(pb, note="P independent greedy streams on ONE GPU, one pass over the weights per tick for all of them "
-                                                       "(rows = pods: k_gemv_rows up to 4, stream-GEMM kernels beyond; per-row KV cache and position); aggregate tokens/s")
+                                                       "(rows = pods: the decode stream itself up to 8 rows, the MFMA stream kernels beyond; per-row KV cache and position); "
+                                                       "aggregate tokens/s; fractions against 8 TB/s and the 157.3 TFLOP/s fp32 matrix peak (the chip holds ~2.09 GHz under this load, "
+                                                       "i.e. ~137 TFLOP/s: profiles/r04_stream_eight_tiles_clock.txt)")
             except Exception as e:  # a side measurement must never take the headline line down
                 result["pods_batched"] = {"error": str(e)}
         ctx.free()
@@ -436,6 +445,33 @@ def main():
                 result["int8_decode"]["roofline"] = {"bound": "hbm", "kernel": dq_k["name"], "achieved": round(dq_k["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                      "frac": round(dq_k["gbps"] / HBM_PEAK_GBPS, 4), "bytes_per_launch": dq_k["bytes_per_launch"], "avg_us": round(dq_k["avg_us"], 2)}
                 result["int8_decode"]["kernels"] = {k["name"]: {"avg_us": round(k["avg_us"], 2), "GBps": round(k["gbps"], 1)} for k in pq}
+                # the int8 pods of one GPU in one weight pass (k_gemv_q8_rows up to 4 rows, k_stream_q8 beyond: raw bytes by LDS-DMA, dequantised by the
+                # MFMA waves) and the 8-token prompt, beside their fp32 twins above
+                try:
+                    from llama_go_amd.mlapi import Pipeline
+                    pq8 = {}
+                    for P in (4, 8, 16, 32):
+                        plq = Pipeline(mt, ctx_size, P, 0, 1)
+                        plq.run([PROMPT] * P, max(W, 1))
+                        torch.cuda.synchronize()
+                        t_b = time.perf_counter()
+                        plq.run(None, K)
+                        torch.cuda.synchronize()
+                        d_b = time.perf_counter() - t_b
+                        idq = [plq.tokens(i) for i in range(P)]
+                        plq.free()
+                        pq8[str(P)] = {"tokens_per_s": round(P * K / d_b, 1), "ms_per_tick": round(d_b / K * 1e3, 4), "all_streams_equal": all(t == idq[0] for t in idq)}
+                    result["int8_decode"]["pods_batched"] = pq8
+                    cq.Eval(PROMPT, 0)
+                    tq8 = []
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t_p = time.perf_counter()
+                        cq.Eval(PROMPT, 0)
+                        tq8.append(time.perf_counter() - t_p)
+                    result["int8_decode"]["prompt_8_tokens_ms"] = round(min(tq8) * 1e3, 3)
+                except Exception as e:
+                    result["int8_decode"]["pods_batched"] = {"error": str(e)}
                 # the ids of ALL timed steps + the last logits against the dequantise-then-fp32 checker on the full model (scalar Go order)
                 lgq = None
                 if not args.no_cpu_baseline:

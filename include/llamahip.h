@@ -282,7 +282,7 @@ typedef struct lh_pipeline lh_pipeline;
 /* pods[i]: this rank's stage of stream i (lh_llama_create with the rank's [layer0, layer1) and the stream's own KV
  * cache), all on `ctx` (one stream orders compute and p2p).  comm may be NULL when the model is not sharded.
  * The streams are dealt into G = min(pods, world) groups (more when a group would exceed the rows one weight pass takes: 64 fp32,
- * 48 block-int8); a group is an lh_batch - its streams advance together in ONE pass over the rank's weights - and the schedule
+ * 64 block-int8 too since round 4); a group is an lh_batch - its streams advance together in ONE pass over the rank's weights - and the schedule
  * above runs over groups instead of single streams.  pods = 4 world: every tick evaluates 4 rows.  max_rows_per_tick (grouped
  * variant; 0 = as many as fit) bounds the rows of a group: 1 puts every stream into its own tick (one weight pass per stream). */
 int lh_pipeline_create(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods, uint32_t n_pods, lh_pipeline** out);

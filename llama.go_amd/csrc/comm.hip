@@ -304,8 +304,9 @@ int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods
         pl->pods.push_back(m);
     }
     pl->past.assign(n_pods, 0);
-    // rows per tick: as many as the P-row kernels take (64 fp32 / 48 block-int8) unless the caller asks for fewer; 1 = every stream on its own
-    const uint32_t cap = wtype == 7 ? 48u : 64u;
+    // rows per tick: as many as the P-row kernels take (64) unless the caller asks for fewer; 1 = every stream on its own
+    const uint32_t cap = 64u;   // (block-int8: 48 until round 4's k_stream_q8)
+    (void)wtype;
     const uint32_t mr = max_rows ? std::min(max_rows, cap) : cap;
     const uint32_t G = group_count(n_pods, (uint32_t)world, mr);
     pl->groups.resize(G);

@@ -1175,18 +1175,53 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
                 d[t] = *(const float*)(im + W_BYTES + (size_t)t * 1024 + r16 * (KC / 32) * 4 + (kbc >> 1) * 4);
             }
         };
+#ifndef Q8_ABL
+#define Q8_ABL 0   // tools/stream_mm_check timing-only builds: 1 = no conversion (the raw dword's bits as the operand), 2 = no MFMAs, 4 = no operand reads after the first
+#endif
         auto dequant = [&](f4 (&a4)[MAXT]) {
+            if constexpr ((Q8_ABL & 1) != 0) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) { const float fv = __builtin_bit_cast(float, raw[t]); a4[t] = f4{fv, d[t], fv, d[t]}; }
+                return;
+            }
+#ifndef Q8_CVT
+#define Q8_CVT 1   // 0: unsigned convert + fma (k_stream_mm2's form), 1: sign-extending convert (SDWA byte select) + multiply, 2: byte permute into 2^23 + u, subtract, fma
+#endif
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                const unsigned int pk = raw[t] ^ 0x80808080u;
-                const float nd = __fmul_rn(d[t], -128.0f);
-                a4[t].x = fmaf(d[t], (float)(pk & 255u), nd);
-                a4[t].y = fmaf(d[t], (float)((pk >> 8) & 255u), nd);
-                a4[t].z = fmaf(d[t], (float)((pk >> 16) & 255u), nd);
-                a4[t].w = fmaf(d[t], (float)(pk >> 24), nd);
+                if constexpr (Q8_CVT == 1) {
+                    // (float)q is exact, d * (float)q rounds once: fl32(d * q), the checker's dequantised weight; 2 vector instructions per value
+                    const int dq = (int)raw[t];
+                    a4[t].x = __fmul_rn(d[t], (float)(int)(signed char)(dq));
+                    a4[t].y = __fmul_rn(d[t], (float)(int)(signed char)(dq >> 8));
+                    a4[t].z = __fmul_rn(d[t], (float)(int)(signed char)(dq >> 16));
+                    a4[t].w = __fmul_rn(d[t], (float)(dq >> 24));
+                } else if constexpr (Q8_CVT == 2) {
+                    // 0x4B000000 | u = 2^23 + u as a float (one byte permute), minus 2^23 + 128 = q exactly, then the one rounding multiply
+                    const unsigned int pk = raw[t] ^ 0x80808080u;
+                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c00u)) - 8388736.0f;
+                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c01u)) - 8388736.0f;
+                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c02u)) - 8388736.0f;
+                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c03u)) - 8388736.0f;
+                    a4[t].x = __fmul_rn(d[t], q0); a4[t].y = __fmul_rn(d[t], q1); a4[t].z = __fmul_rn(d[t], q2); a4[t].w = __fmul_rn(d[t], q3);
+                } else {
+                    const unsigned int pk = raw[t] ^ 0x80808080u;
+                    const float nd = __fmul_rn(d[t], -128.0f);
+                    a4[t].x = fmaf(d[t], (float)(pk & 255u), nd);
+                    a4[t].y = fmaf(d[t], (float)((pk >> 8) & 255u), nd);
+                    a4[t].z = fmaf(d[t], (float)((pk >> 16) & 255u), nd);
+                    a4[t].w = fmaf(d[t], (float)(pk >> 24), nd);
+                }
             }
         };
         auto mfmas = [&](const f4 (&a4)[MAXT], const f4 (&b)[NCT]) {
+            if constexpr ((Q8_ABL & 2) != 0) {   // keep the operands alive, multiply nothing
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) asm volatile("" :: "v"(a4[t].x), "v"(a4[t].y), "v"(a4[t].z), "v"(a4[t].w));
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) asm volatile("" :: "v"(b[c].x), "v"(b[c].y), "v"(b[c].z), "v"(b[c].w));
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -1194,7 +1229,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
 #pragma unroll
                     for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][s], b[c][s], acc[t][c], 0, 0, 0);
         };
-        constexpr int NM = 4 * MAXT * NCT, NV = 10 * MAXT, VPM = (NV + NM - 1) / NM;   // MFMAs of a k-block, vector instructions of one conversion, of them behind each MFMA
+        constexpr int NM = 4 * MAXT * NCT, NV = (Q8_CVT == 1 ? 8 : Q8_CVT == 2 ? 13 : 10) * MAXT, VPM = (NV + NM - 1) / NM;   // MFMAs of a k-block, vector instructions of one conversion, of them behind each MFMA
         static_assert(KB % 2 == 0, "the two operand sets alternate by k-block parity across chunks");
         // The pipeline runs ACROSS chunks: the step behind the last k-block of chunk ch is the first of chunk ch + 1, so barrier ch + 1 stands
         // in front of that k-block's MFMAs (its operands are in registers by then: the image of chunk ch is not read any more).

@@ -221,14 +221,8 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
     const uint32_t K4 = a.K / 4, rows_wg = a.M / (uint32_t)ctx->ds->num_cu + 4;
     const uint64_t bytes = (uint64_t)a.M * a.K * 4;
     if (K4 <= 4 * 256 && rows_wg <= 256) {
-        if constexpr (NC == 8) {   // weight rows in flight per wave (probe: LLAMAHIP_ROWS_U; the 32 FMAs per load stand between a wave's load bursts)
-            static int u8 = -1;
-            if (u8 < 0) { const char* e = getenv("LLAMAHIP_ROWS_U"); u8 = e ? atoi(e) : 2; }
-            if ((K4 + 255) / 256 == 4) {
-                if (u8 == 3) return launch_gemv_rows<4, 3, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
-                if (u8 == 4) return launch_gemv_rows<4, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
-            }
-        }
+        // (eight activation rows: three / four weight rows in flight per wave measured slower than two - 5.17 / 5.40 against 4.99 ms per 8-pod tick,
+        // profiles/r04_rows_kernel_u.txt)
         switch ((K4 + 255) / 256) {
             case 1: return launch_gemv_rows<1, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
             case 2: return launch_gemv_rows<2, 4, 256, NC, PRO, EPI, MAP>(ctx, a, name, bytes);
@@ -558,7 +552,7 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // the tile GEMM): 49..64 rows run half-length chunks (KC = 64: 2 x (6 + 4) x 16 x 68 floats = 87 KB), fp32 weights only.
 // 65..96 rows (round 3): five / six column tiles on the same half-length chunks (2 x (6 + 6) x 16 x 68 floats = 104 KB; 6 x 6 accumulator tiles =
 // 144 registers of the MFMA waves).  The tile GEMM's single row of 128-row tiles cost 17.6 ms at 65 rows against 10.2 ms at 64.
-static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 48, BATCH_ROWS_MAX = 64;
+static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 64, BATCH_ROWS_MAX = 64;
 static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
@@ -687,7 +681,7 @@ static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name)
         const int ve = stream_dma_variant_env();
         if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
     }
-    if constexpr (NCT <= 3) {   // block-int8, up to 48 rows: raw bytes by LDS-DMA, dequantised by the MFMA waves (no folded norm: the host runs the norm's own launch)
+    if constexpr (NCT <= 3 || (NCT == 4 && MAXT <= 6)) {   // block-int8, up to 64 rows (eight row tiles: 48; their 8 x 4 tiles + two operand sets would spill): raw bytes by LDS-DMA, dequantised by the MFMA waves (no folded norm: the host runs the norm's own launch)
         if (a.ws[0] && !a.gamma && !a.tiled && stream_dma_variant_env() != -1) return launch_stream_q8_kc<MAXT, NCT>(ctx, a, name);
     }
     if constexpr (NCT > 6) return ST_NA;   // (k_stream_mm2 holds MAXT x NCT accumulator tiles per wave: up to six column tiles)

@@ -109,11 +109,11 @@ template <int MAXT, int NCT, int KC, int NIMG> static void run_q8_img(const Stre
     } else printf("k_stream_q8<%d,%d,%d>: images do not fit\n", MAXT, NCT, KC);
 }
 template <int MAXT, int NCT> static void run_q8(const StreamArgs& a, int nCU) {
-    if constexpr (NCT <= 3) {
+    if constexpr (NCT <= 3 || (NCT == 4 && MAXT <= 6)) {
         constexpr int cap = 4;
         constexpr int N256 = (int)std::min<size_t>(cap, 160 * 1024 / stream_q8_image_bytes(MAXT, NCT, 256)), N128 = (int)std::min<size_t>(cap, 160 * 1024 / stream_q8_image_bytes(MAXT, NCT, 128));
         if (g_kc == 256) run_q8_img<MAXT, NCT, 256, N256>(a, nCU); else run_q8_img<MAXT, NCT, 128, N128>(a, nCU);
-    } else printf("k_stream_q8: up to three column tiles\n");
+    } else printf("k_stream_q8: up to four column tiles (three with eight row tiles)\n");
 }
 template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const StreamArgs& a, int nCU) {
     if constexpr (NCT == 8) {   // eight column tiles: 2 K-groups x 2 column halves, 64-column chunks, pipelined
