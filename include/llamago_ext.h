@@ -87,6 +87,7 @@ uint32_t llamago_PipelineGroups(llama_pipeline* p);
 int llamago_PipelineRun(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps);             /* lh_pipeline_run */
 int llamago_PipelineRunSample(llama_pipeline* p, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, uint32_t topK, float topP, float temp,
                               float repeatPenalty, uint64_t seed, uint32_t ringSize);                                            /* lh_pipeline_run_sample */
+int llamago_PipelineSetKeepCount(llama_pipeline* p, uint32_t keep);                                               /* lh_pipeline_set_keep (same value on every rank) */
 int llamago_PipelineProfile(llama_pipeline* p, int on);                                                          /* lh_pipeline_profile */
 int llamago_PipelineStats(llama_pipeline* p, uint32_t* ticks, float* stage_ms, float* exchange_ms);             /* lh_pipeline_stats_read */
 int llamago_PipelineHopProbe(llama_pipeline* p, uint32_t bytes, uint32_t iters, float* us_per_hop);             /* lh_pipeline_hop_probe */

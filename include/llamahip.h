@@ -302,6 +302,11 @@ int lh_pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const uint3
  * lh_llama_decode_sample with the same seed) instead of the argmax.  prompts must be given on rank 0 AND on the last rank (the
  * repeat penalty needs the ring there).  run_sample(NULL, NULL, K, sp, ring) continues sampled streams. */
 int lh_pipeline_run_sample(lh_pipeline* pl, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t steps, const lh_sample_params* sp, uint32_t ring_size);
+/* ModelParams.KeepCount (llama.go:47) of every stream; call it with the same value on every rank.  Past the window the streams swap context
+ * like server.Do (server.go:160-172): an unsharded pipeline inside its batches' ticks, a sharded one in the unit where a stream stands at the
+ * window's end - its re-fed run ((ctx - keep) / 2 tokens, the pending one last) is evaluated as one Eval at position keep by every rank in turn,
+ * its residual rows travelling in front of that tick's rows in the same exchange.  Rank 0 knows the tokens (its prompts + the ids it received). */
+int lh_pipeline_set_keep(lh_pipeline* pl, uint32_t keep);
 /* Where the time of a run goes on THIS rank (the N > 1 curve's diagnosis): with profiling on, every tick of the following runs is bracketed
  * by HIP events on the compute stream - in front of the stage, behind it, behind the exchange - and the totals accumulate: stage_ms = the
  * rank's own kernels, exchange_ms = from the end of its stage to the end of its send / receive (RCCL: includes waiting for the predecessor's

@@ -136,6 +136,10 @@ struct lh_pipeline {
     bool sampling = false;
     // lh_pipeline_profile: HIP events around every stage and every exchange of a run (where a shortfall of the N > 1 curve comes from:
     // the rank's own compute or the hops)
+    // context swap across ranks (server.go:160-172): KeepCount (the same on every rank) and, on rank 0, every stream's prompt - together with the
+    // ids it received (Group::hist) the contents of the reference's lastNTokens ring, oldest first
+    uint32_t keep = 0;
+    std::vector<std::vector<uint32_t>> prompt_host;
     bool profiling = false;
     std::vector<hipEvent_t> ev;     // 3 per tick: before the stage, behind it, behind the exchange
     uint32_t ev_used = 0;
@@ -388,10 +392,10 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
         const uint32_t np = prefill ? n_prompt[p] : 0;
         if (prefill && !np) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u has an empty prompt", p);
         if (np > pl->ctx_size) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u: a prompt of %u tokens exceeds the context window of %u", p, np, pl->ctx_size);
-        // an unsharded pipeline swaps context at the window's end like server.Do (server.go:160-172; lh_batch does it per row); across ranks
-        // the re-fed run would have to travel through the stages like a prompt: not built - the run is refused before anything starts
-        if (R > 1 && (uint64_t)(prefill ? 0 : pl->past[p]) + np + steps > pl->ctx_size)
-            LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u would leave the context window of %u (the context swap is built for unsharded pipelines only)", p, pl->ctx_size);
+        // past the window every stream swaps context like server.Do (server.go:160-172): an unsharded pipeline inside its lh_batch ticks, a sharded
+        // one in the unit where a stream stands at the window's end - the re-fed run travels through the stages in front of that unit's tick
+        if (pl->keep >= pl->ctx_size && (uint64_t)(prefill ? 0 : pl->past[p]) + np + steps > pl->ctx_size)
+            LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u would leave the context window of %u and KeepCount %u leaves no room to swap", p, pl->ctx_size, pl->keep);
     }
     // what only ONE rank can see (the prompts live on rank 0, and on the last rank of a sampled run): that rank tears the communicator
     // down before it returns, so the others' first receive fails instead of waiting for it
@@ -428,6 +432,21 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
         }
     }
     if (prefill) { pl->sampling = smp != nullptr; std::fill(pl->past.begin(), pl->past.end(), 0u); }
+    if (prefill && first && R > 1) {
+        pl->prompt_host.assign(P, std::vector<uint32_t>());
+        for (uint32_t p = 0; p < P; ++p) pl->prompt_host[p].assign(prompts[p], prompts[p] + n_prompt[p]);
+    }
+    // A decode unit of a SHARDED pipeline in which streams of the group stand at the window's end is a swap unit: every such stream's re-fed run
+    // ((ctx - keep) / 2 tokens, the pending one last) is evaluated as one Eval at position keep on every rank in turn - its residual rows travel
+    // in FRONT of the tick's rows in the same exchange - and the tick then takes the pending token behind it.  Every rank derives the same swap
+    // set from its mirror of the positions; only rank 0 needs the tokens.
+    const uint32_t swap_n = pl->keep < pl->ctx_size ? (pl->ctx_size - pl->keep) / 2 : 0;
+    auto swap_rows = [&](uint32_t g) -> uint32_t {   // rows of the re-fed runs of group g's next decode unit, from the positions as they are NOW
+        uint32_t t = 0;
+        if (R > 1) for (uint32_t p : pl->groups[g].pods) if (pl->past[p] >= pl->ctx_size) t += swap_n;
+        return t;
+    };
+    std::vector<uint32_t> unit_rows(G, 0);           // rows the group's CURRENT unit sends / receives (set by its stage, or by recv_rows on a rank that only receives)
     auto rows_of = [&](uint32_t g, uint32_t u) -> uint32_t {
         const Group& gr = pl->groups[g];
         if (!(prefill && u == 0)) return (uint32_t)gr.pods.size();
@@ -457,9 +476,42 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
             std::vector<const uint32_t*> pr;
             std::vector<uint32_t> np;
             for (uint32_t p : gr.pods) { pr.push_back(first ? prompts[p] : nullptr); np.push_back(n_prompt[p]); pl->past[p] = n_prompt[p]; }
+            unit_rows[g] = rows_of(g, u);
             rc2 = lh_batch_prompt(gr.batch, first ? pr.data() : nullptr, np.data(), first ? nullptr : gr.x_in, last ? nullptr : gr.x_out);
         } else {
-            rc2 = lh_batch_stage(gr.batch, first ? nullptr : gr.x_in, last ? nullptr : gr.x_out, nullptr, nullptr);
+            const uint32_t B = (uint32_t)gr.pods.size(), extra = swap_rows(g);
+            unit_rows[g] = B + extra;
+            if (extra) {
+                if ((rc2 = group_ensure_rows(pl, gr, B + extra))) return rc2;
+                // rank 0: the ring of every swapping stream = its prompt + the ids received so far (Group::hist: [unit][row]); the pending id is the newest
+                std::vector<uint32_t> ids;
+                if (first) {
+                    ids.resize((size_t)gr.n_hist * B);
+                    LH_HIP(ctx, hipMemcpyAsync(ids.data(), gr.hist, ids.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+                    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                std::vector<uint32_t> newpos(B), refeed;
+                uint32_t off = 0;
+                for (uint32_t i = 0; i < B; ++i) {
+                    const uint32_t p = gr.pods[i];
+                    newpos[i] = pl->past[p];
+                    if (pl->past[p] < pl->ctx_size) continue;
+                    if (first) {
+                        std::vector<uint32_t> ring = pl->prompt_host[p];
+                        for (uint32_t k = 0; k < gr.n_hist; ++k) ring.push_back(ids[(size_t)k * B + i]);
+                        if (ring.size() < swap_n) LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_run: stream %u: the window's tokens are not known on rank 0", p);
+                        refeed.assign(ring.end() - swap_n, ring.end());
+                    }
+                    if (swap_n && (rc2 = lh_llama_stage(pl->pods[p], first ? refeed.data() : nullptr, nullptr, first ? nullptr : gr.x_in + (size_t)off * pl->d,
+                                                        last ? nullptr : gr.x_out + (size_t)off * pl->d, swap_n, pl->keep, nullptr, nullptr)))
+                        return rc2;
+                    off += swap_n;
+                    newpos[i] = pl->keep + swap_n;
+                    pl->past[p] = newpos[i];
+                }
+                if ((rc2 = lh_batch_set(gr.batch, nullptr, newpos.data()))) return rc2;   // token ids stay what the last exchange delivered
+            }
+            rc2 = lh_batch_stage(gr.batch, first ? nullptr : gr.x_in + (size_t)extra * pl->d, last ? nullptr : gr.x_out + (size_t)extra * pl->d, nullptr, nullptr);
             for (uint32_t p : gr.pods) pl->past[p] += 1;
         }
         if (rc2) return rc2;
@@ -473,12 +525,18 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
         if (s >= 0) {
             Group& gr = pl->groups[s];
             if (last) { sb = lh_batch_ids_dev(gr.batch); sbytes = gr.pods.size() * 4; }
-            else { sb = gr.x_out; sbytes = (uint64_t)rows_of((uint32_t)s, (uint32_t)u) * pl->d * 4; }
+            else { sb = gr.x_out; sbytes = (uint64_t)unit_rows[s] * pl->d * 4; }
         }
         if (rs >= 0) {
             Group& gr = pl->groups[rs];
             if (first) { rb = lh_batch_tokens_dev(gr.batch); rbytes = gr.pods.size() * 4; }
-            else { rb = gr.x_in; rbytes = (uint64_t)rows_of((uint32_t)rs, (uint32_t)ru) * pl->d * 4; }
+            else {
+                // what the predecessor sends for unit ru of group rs: this rank has not run that unit yet, so its position mirror says what the unit is
+                const uint32_t rows = (prefill && ru == 0) ? rows_of((uint32_t)rs, 0) : (uint32_t)gr.pods.size() + swap_rows((uint32_t)rs);
+                int rc3 = group_ensure_rows(pl, gr, rows);
+                if (rc3) return rc3;
+                rb = gr.x_in; rbytes = (uint64_t)rows * pl->d * 4;
+            }
         }
         int rc2 = lh_comm_exchange(pl->comm, sb, sbytes, (int)((r + 1) % R), rb, rbytes, (int)((r + R - 1) % R));
         if (rc2) return rc2;
@@ -524,6 +582,12 @@ static int pipeline_run(lh_pipeline* pl, const uint32_t* const* prompts, const u
     return LH_OK;
 }
 
+int lh_pipeline_set_keep(lh_pipeline* pl, uint32_t keep) {
+    if (!pl) return LH_EINVAL;
+    pl->keep = keep;
+    for (lh_llama* m : pl->pods) lh_llama_set_keep(m, keep);
+    return LH_OK;
+}
 int lh_pipeline_profile(lh_pipeline* pl, int on) {
     if (!pl) return LH_EINVAL;
     pl->profiling = on != 0;

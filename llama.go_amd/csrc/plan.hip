@@ -678,6 +678,8 @@ static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) 
 template <int MAXT, int NCT>
 static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     if constexpr (NCT >= 2) {
+        // (one column tile, 9..16 rows, stays on k_stream_mm2 with the norm folded into the launch: on the LDS-DMA kernel with the norm's own launch
+        // in front it measured 6.12-6.14 ms per Eval against 5.63-5.68, 16 pods 5.91 against 5.81 ms per tick - profiles/r04_stream_one_column_tile_probe.txt)
         const int ve = stream_dma_variant_env();
         if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
     }

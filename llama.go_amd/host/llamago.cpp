@@ -1106,6 +1106,7 @@ int llamago_PipelineRun(llama_pipeline* p, const uint32_t* const* prompts, const
     if (lh_pipeline_run(p->pl, prompts, n_prompt, steps)) return halt_rc(lh_last_error(p->mlctx->hip));
     return 0;
 }
+int llamago_PipelineSetKeepCount(llama_pipeline* p, uint32_t keep) { return p ? lh_pipeline_set_keep(p->pl, keep) : 1; }
 int llamago_PipelineProfile(llama_pipeline* p, int on) { return p ? lh_pipeline_profile(p->pl, on) : 1; }
 int llamago_PipelineStats(llama_pipeline* p, uint32_t* ticks, float* stage_ms, float* exchange_ms) {
     lh_pipeline_stats st;

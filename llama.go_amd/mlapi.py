@@ -465,6 +465,12 @@ class Pipeline:
         if rc:
             raise MLError(f"llamago_PipelineRun: {self.ml.last_error()}")
 
+    def SetKeepCount(self, keep):
+        """ModelParams.KeepCount of every stream (lh_pipeline_set_keep; the same value on every rank)."""
+        self.ml.lib.llamago_PipelineSetKeepCount.argtypes = [VP, c_u32]
+        if self.ml.lib.llamago_PipelineSetKeepCount(self.h, keep):
+            raise MLError("llamago_PipelineSetKeepCount failed")
+
     def profile(self, on=True):
         """lh_pipeline_profile: HIP events around every stage and exchange of the following runs (clears the totals)."""
         self.ml.lib.llamago_PipelineProfile.argtypes = [VP, C.c_int]

@@ -12,6 +12,8 @@ import torch  # noqa: E402,F401  (one HIP runtime per process: torch's)
 import torch.distributed as dist  # noqa: E402
 
 shape, ctx, steps, sample, prompts = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), json.loads(sys.argv[5])
+keep = int(sys.argv[6]) if len(sys.argv) > 6 else None   # given: the streams outlive their windows (context swap with this KeepCount), second run of `more` steps
+more = int(sys.argv[7]) if len(sys.argv) > 7 else 2
 os.environ["LLAMAGO_DEVICE"] = "0"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
@@ -25,6 +27,8 @@ l0, l1 = layer_range(rank, world, hp.layersCount)
 m = prod.NewSyntheticModel(hp, 17, l0, l1)
 pl = Pipeline(m, ctx, len(prompts), rank, world, hooks=gloo_comm_hooks(dist))
 smp = dict(topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=777)
+if keep is not None:
+    pl.SetKeepCount(keep)
 if sample == 2:
     # failure path: rank 0 sees a bad prompt and aborts the communicator; every other rank must FAIL its run (the transport's abort hook
     # poisons its pending receive) instead of waiting forever.  Every rank reports what happened to it on stderr-free stdout lines.
@@ -36,10 +40,10 @@ if sample == 2:
     os._exit(0)
 elif sample:
     pl.run_sample(prompts, steps, **smp)
-    pl.run_sample(None, 2, **smp)
+    pl.run_sample(None, more, **smp)
 else:
     pl.run(prompts, steps)
-    pl.run(None, 2)
+    pl.run(None, more)
 if rank == 0:
     print(json.dumps({"ids": [pl.tokens(i) for i in range(len(prompts))], "groups": pl.groups}), flush=True)
 pl.free()

@@ -192,3 +192,47 @@ def test_unsharded_pipeline_swaps_context(product, oracle):
     pl.free()
     m.free()
     assert got == [o[0] for o in out]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,keep,sample", [(2, 0, 0), (3, 3, 0), (2, 0, 1)])
+def test_sharded_pipeline_swaps_context_across_ranks(product, world, keep, sample):
+    """Two / three ranks (layer blocks) on ONE GPU (host-staged p2p), streams of different prompt lengths in two groups, 50 ids through windows of
+    24: in the unit where a stream stands at the window's end its re-fed run travels through every stage in front of the tick's rows.  Every stream
+    must decode exactly what the single-process loops decode for it (those are checked against the checker above)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ctx_size, seed = 24, 17
+    hp = make_hparams(**SHAPES["small"], ctx=ctx_size)
+    rng = np.random.default_rng({(2, 0): 520, (3, 3): 33}[(world, keep)])   # prompt seeds whose checker runs keep a top-2 margin > 5e-4 over all 250 steps
+    prompts = [[int(t) for t in rng.integers(0, hp.vocabSize, n)] for n in (5, 1, 9, 3, 2)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "pipeline_worker.py"), "small", str(ctx_size), "19", str(sample), json.dumps(prompts), str(keep), "30"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-6000:])
+    got = None
+    for line in reversed(r.stdout.splitlines()):
+        if line.strip().startswith("{") and '"ids"' in line:
+            got = json.loads(line)
+            break
+    assert got is not None, r.stdout[-2000:]
+    m = product.NewSyntheticModel(hp, seed)
+    smp = dict(topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=777)
+    for i, pr in enumerate(prompts):
+        c = m.NewContext(ctx_size, 1)
+        c.SetKeepCount(keep)
+        want = c.SampleDecode(pr, 50, **smp) if sample else c.GreedyDecode(pr, 50, want_logits=False)[0]
+        c.free()
+        assert got["ids"][i] == list(want), (i, got["ids"][i], want)
+    m.free()
