@@ -37,11 +37,6 @@ struct GemvArgs {
     uint32_t hd;            // head dim (= rope dims)
     uint32_t d;             // embd
     const StepParams* sp;   // past
-    // EPI_QKV_ROPE with the attention of the token folded into the launch (qkv_attn_tail): per-head arrival counters [H] (zero between
-    // launches), the merged-heads output [d] and fl32(1/sqrt(hd)); attn_cnt == nullptr: the attention is its own launch
-    uint32_t* attn_cnt;
-    float* attn_out;
-    float attn_scale;
 };
 
 template <int KI, int TH>
@@ -160,9 +155,6 @@ __device__ __forceinline__ const char* gemv_row_base(const char* w0, const char*
     return ((v & 1u) ? w1 : w0) + (uint64_t)(v >> 1) * row_bytes;
 }
 
-template <int TH_>
-__device__ __forceinline__ void qkv_attn_tail(const GemvArgs& a, uint32_t r0, uint32_t r1, uint32_t past, char* smem);   // below, next to k_attention
-
 template <int KI, int U, int TH, int PRO, int EPI, int MAP>
 __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -233,7 +225,6 @@ __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
     }
     __syncthreads();
     gemv_finish<EPI, NW>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
-    if (EPI == EPI_QKV_ROPE && a.attn_cnt) qkv_attn_tail<TH>(a, r0, r1, past_pre, smem_raw);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -584,189 +575,6 @@ __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, con
             o = fmaf(base[(size_t)s * (hd + 2) + c], w, o);
         }
         a.out[(size_t)j * a.d + h * hd + c] = __fmul_rn(o, inv);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Decode attention WITHOUT a launch (round 4).  The wq|wk|wv launch owns the 3*hd rows of head h (its q, the new k and the new v)
-// in a handful of workgroups; each workgroup publishes what it stored (release fence), adds its row count to the head's counter, and the
-// workgroup whose add completes the count computes the head (acquire fence, then exactly k_attention's arithmetic).  Nobody waits for
-// anybody: a workgroup that is not last simply ends.  attn_head_tail reproduces k_attention (1024 threads: 32 key groups, 8 key phases
-// in the PV step, 16 waves in the long-row reductions) with TH_ threads by giving every thread 1024 / TH_ of those roles and keeping each
-// role's summation order, so the result is bit-identical to the separate launch (and to the batched ticks, which keep it).
-// hd = 128 only (the plan decides).
-// ---------------------------------------------------------------------------------------------------
-template <int TH_>
-__device__ __forceinline__ void attn_head_tail(const float* q_all, const float* kc, const float* vc, float* out, uint32_t d, uint32_t h, uint32_t T,
-                                               float scale, char* smem) {
-    constexpr int HD = 128, NG = TH_ / 32, NWV = TH_ / 64, PPT = ATT_TH / TH_, PHASES = ATT_TH / HD, VWAVES = ATT_TH / 64;
-    static_assert(TH_ % HD == 0 && ATT_TH % TH_ == 0, "attn_head_tail: workgroup size");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t Tp = (T + 63) & ~63u;
-    float* sc = (float*)smem;         // [Tp] scaled scores
-    float* pr = sc + Tp;              // [Tp] un-normalised probabilities
-    float* scratch = pr + Tp;         // [ATT_TH] PV partials / reduction scratch
-    const float* q = q_all + h * HD;
-    const float* Kc = kc + h * HD;
-    const float* Vc = vc + h * HD;
-    const uint32_t c = tid % HD, tr = tid / HD;   // this thread plays key phases tr * PPT .. + PPT - 1 of column c
-    constexpr int VP = 8;
-    float vpre[PPT][VP];
-#pragma unroll
-    for (int s = 0; s < PPT; ++s)
-#pragma unroll
-        for (int i = 0; i < VP; ++i) {
-            const uint32_t t = tr * PPT + s + (uint32_t)i * PHASES;
-            vpre[s][i] = t < T ? Vc[(size_t)t * d + c] : 0.f;
-        }
-    {   // scores: one key per 32-lane group, 128 keys requested per round
-        const int g = tid >> 5, gl = tid & 31;
-        constexpr int UN = 128 / NG;
-        const f4 qv = *(const f4*)(q + gl * 4);
-        for (uint32_t t0 = g; t0 < T; t0 += NG * UN) {
-            f4 kv[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const uint32_t t = t0 + u * NG;
-                kv[u] = *(const f4*)(Kc + (size_t)(t < T ? t : 0) * d + gl * 4);
-            }
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const uint32_t t = t0 + u * NG;
-                float s = fmaf(kv[u].x, qv.x, 0.f);
-                s = fmaf(kv[u].y, qv.y, s); s = fmaf(kv[u].z, qv.z, s); s = fmaf(kv[u].w, qv.w, s);
-                s = half_wave_sum(s);
-                if (gl == 0 && t < T) sc[t] = __fmul_rn(s, scale);
-            }
-        }
-    }
-    __syncthreads();
-    float inv;
-    if (T <= 128) {   // every wave evaluates the row redundantly (k_attention's short-row path)
-        float m = -INFINITY;
-        for (uint32_t t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
-        m = wave_max(m);
-        float psum = 0.f;
-        for (uint32_t t = lane; t < T; t += 64) {
-            const float p = (float)exp((double)__fsub_rn(sc[t], m));
-            pr[t] = p;
-            psum += p;
-        }
-        psum = wave_sum(psum);
-        inv = __fdiv_rn(1.0f, psum);
-    } else {          // k_attention's long-row path: thread v of 1024 takes keys v, v + 1024, ..; wave sums added in wave order
-        float mv[PPT];
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            float m = -INFINITY;
-            for (uint32_t t = tid + r * TH_; t < T; t += ATT_TH) m = fmaxf(m, sc[t]);
-            mv[r] = wave_max(m);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < PPT; ++r) scratch[wave + r * NWV] = mv[r];
-        }
-        __syncthreads();
-        float m = scratch[0];
-#pragma unroll
-        for (int w = 1; w < VWAVES; ++w) m = fmaxf(m, scratch[w]);
-        __syncthreads();
-        float ps[PPT];
-#pragma unroll
-        for (int r = 0; r < PPT; ++r) {
-            float psum = 0.f;
-            for (uint32_t t = tid + r * TH_; t < T; t += ATT_TH) {
-                const float p = (float)exp((double)__fsub_rn(sc[t], m));
-                pr[t] = p;
-                psum += p;
-            }
-            ps[r] = wave_sum(psum);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < PPT; ++r) scratch[wave + r * NWV] = ps[r];
-        }
-        __syncthreads();
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < VWAVES; ++w) tot += scratch[w];
-        inv = __fdiv_rn(1.0f, tot);
-        __syncthreads();
-    }
-    float acc[PPT];
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        acc[s] = 0.f;
-#pragma unroll
-        for (int i = 0; i < VP; ++i) {
-            const uint32_t t = tr * PPT + s + (uint32_t)i * PHASES;
-            if (t < T) acc[s] = fmaf(vpre[s][i], __fmul_rn(pr[t], inv), acc[s]);
-        }
-    }
-    for (uint32_t base = VP * PHASES; base < T; base += VP * PHASES) {   // keys beyond the first 64: the same batches of VP per phase
-        float vv[PPT][VP];
-#pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int i = 0; i < VP; ++i) {
-                const uint32_t t = base + tr * PPT + s + (uint32_t)i * PHASES;
-                vv[s][i] = Vc[(size_t)(t < T ? t : 0) * d + c];
-            }
-#pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int i = 0; i < VP; ++i) {
-                const uint32_t t = base + tr * PPT + s + (uint32_t)i * PHASES;
-                if (t < T) acc[s] = fmaf(vv[s][i], __fmul_rn(pr[t], inv), acc[s]);
-            }
-    }
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) scratch[(tr * PPT + s) * HD + c] = acc[s];
-    __syncthreads();
-    if (tid < HD) {
-        float o = scratch[tid];
-#pragma unroll
-        for (int p2 = 1; p2 < PHASES; ++p2) o += scratch[tid + p2 * HD];
-        out[h * HD + tid] = o;
-    }
-}
-
-constexpr int QKV_TAIL_SEGS = 8;   // (matrix, head) runs a workgroup's block of virtual rows can touch
-
-template <int TH_>
-__device__ __forceinline__ void qkv_attn_tail(const GemvArgs& a, uint32_t r0, uint32_t r1, uint32_t past, char* smem) {
-    const int tid = threadIdx.x;
-    const uint32_t d = a.d, hd = a.hd;
-    __threadfence();     // release: the q / k / v values this thread stored are visible device-wide before the count below
-    __syncthreads();
-    uint32_t* done = (uint32_t*)smem;   // [QKV_TAIL_SEGS]: head completed by this workgroup's add, or ~0
-    if (tid < QKV_TAIL_SEGS) {
-        // segment `tid` of [r0, r1): cut at every multiple of hd (matrix boundaries are multiples of hd)
-        const uint32_t v0 = tid == 0 ? r0 : (r0 / hd + (uint32_t)tid) * hd;
-        uint32_t v1 = (r0 / hd + (uint32_t)tid + 1) * hd;
-        if (v1 > r1) v1 = r1;
-        uint32_t res = ~0u;
-        if (v0 < r1) {
-            const uint32_t h = (v0 % d) / hd, cnt = v1 - v0;
-            const uint32_t old = __hip_atomic_fetch_add(a.attn_cnt + h, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + cnt == 3 * hd) {
-                __hip_atomic_store(a.attn_cnt + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next touched by the next launch
-                res = h;
-            }
-        }
-        done[tid] = res;
-    }
-    __syncthreads();
-    uint32_t heads[QKV_TAIL_SEGS];
-#pragma unroll
-    for (int i = 0; i < QKV_TAIL_SEGS; ++i) heads[i] = done[i];
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < QKV_TAIL_SEGS; ++i) {
-        if (heads[i] == ~0u) continue;     // uniform over the workgroup
-        __threadfence();                   // acquire: the other workgroups' stores of this head
-        attn_head_tail<TH_>(a.q_out, a.k_cache, a.v_cache, a.attn_out, d, heads[i], past + 1, a.attn_scale, smem);
-        __syncthreads();
     }
 }
 

@@ -191,7 +191,6 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     }
     __syncthreads();
     gemv_finish<EPI, NWR>(a, red, r0, r1, fin, resid_pre, cs_pre, past_pre);
-    if (EPI == EPI_QKV_ROPE && a.attn_cnt) qkv_attn_tail<TH>(a, r0, r1, past_pre, smem_raw);
 }
 
 }  // namespace lh

@@ -63,7 +63,6 @@ struct Plan {
     uint32_t* out_tokens_dev = nullptr;
     uint32_t out_cap = 0;
     uint32_t* argmax_dev = nullptr;
-    uint32_t* attn_cnt = nullptr;             // per-head arrival counters of the attention folded into the wq|wk|wv launch (zero between launches)
     // captured decode graphs: one Eval(N=1) (embed .. logits); the same + argmax + advance (resident greedy loop) as 1 step and as
     // GRAPH_MULTI consecutive steps per launch; the same + device sampler + advance (resident sampling loop), 1 and GRAPH_MULTI steps.
     // Several steps per graph launch keep the GPU fed when the host is slow to submit (a loaded host measured 207 instead of 230 tok/s

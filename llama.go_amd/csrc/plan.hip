@@ -998,8 +998,6 @@ int plan_create(lh_ctx* ctx, const ModelDesc& md, Plan** out) {
     hipError_t e = hipMalloc((void**)&p->sp_dev, sizeof(StepParams) * SP_SLOTS);
     if (e == hipSuccess) e = hipHostMalloc((void**)&p->sp_host, sizeof(StepParams) * SP_SLOTS, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&p->argmax_dev, 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->attn_cnt, (size_t)md.H * 4);
-    if (e == hipSuccess) e = hipMemset(p->attn_cnt, 0, (size_t)md.H * 4);
     if (e != hipSuccess) { set_error(ctx, "plan_create: %s", hipGetErrorString(e)); plan_destroy(p); return LH_ENOMEM; }
     rc = plan_ensure_rows(p, 1);
     if (rc) { plan_destroy(p); return rc; }
@@ -1028,7 +1026,6 @@ void plan_destroy(Plan* p) {
     if (p->sp_host) hipHostFree(p->sp_host);
     if (p->out_tokens_dev) hipFree(p->out_tokens_dev);
     if (p->argmax_dev) hipFree(p->argmax_dev);
-    if (p->attn_cnt) hipFree(p->attn_cnt);
     if (p->attn_part) hipFree(p->attn_part);
     delete p;
 }
@@ -1053,16 +1050,7 @@ void destroy_plans(lh_ctx* ctx) {
     ctx->plans.clear();
 }
 
-// Decode attention inside the wq|wk|wv launch (qkv_attn_tail, kernels_llama.h): heads of 128, single-pass attention (ctx <= 256), and a
-// workgroup's block of virtual rows within the segments the tail enumerates.  LLAMAHIP_FUSED_ATTN=0/1 overrides (A/B).
-static bool fused_attention(const Plan* p) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("LLAMAHIP_FUSED_ATTN"); v = e ? atoi(e) : 0; }
-    const ModelDesc& m = p->md;
-    return v == 1 && m.hd == 128 && !p->attn_part && p->attn_cnt && (3 * m.d / (uint32_t)p->ctx->ds->num_cu + 2) / 128 + 2 <= (uint32_t)QKV_TAIL_SEGS;
-}
-
-// ---- decode step (N = 1): 5 kernels per layer (4 with the attention folded into the first) ---------------------
+// ---- decode step (N = 1): 5 kernels per layer --------------------------------------------------------
 // advance: 0 = logits only, 1 = greedy argmax + loop bookkeeping, 2 = device sampler + loop bookkeeping
 static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, float* x_out, int argmax_advance, uint32_t* argmax_out,
                           const uint32_t* tokens_dev = nullptr, uint32_t logits_row = 0) {
@@ -1084,7 +1072,6 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
     float* xa = p->xa;
     float* xb = p->xb;
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));  // llama.go:306
-    const bool fused = fused_attention(p);
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * m.d;
@@ -1093,10 +1080,9 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
             a.w[0] = L.wq; a.w[1] = L.wk; a.w[2] = L.wv; a.ws[0] = L.s_wq; a.ws[1] = L.s_wk; a.ws[2] = L.s_wv; a.rows_per_mat = m.d; a.M = 3 * m.d; a.K = m.d;
             a.x = x; a.gamma = L.attn_norm; a.q_out = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot;
             a.rope = rope; a.hd = m.hd; a.d = m.d; a.sp = sp;
-            if (fused) { a.attn_cnt = p->attn_cnt; a.attn_out = p->attn; a.attn_scale = scale; }
             if ((rc = gemv<PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK>(ctx, a, "gemv_qkv_rope", m.wtype))) return rc;
         }
-        if (!fused) {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
+        {   // scores, scale, mask, softmax, PV, head merge   (llama.go:300-333)
             AttnArgs a = {};
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = m.d; a.hd = m.hd; a.n = 1; a.scale = scale; a.sp = sp;
             if (p->attn_part) { if ((rc = launch_attention_split(p, a, p->attn_part))) return rc; }
