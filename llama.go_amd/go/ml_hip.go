@@ -566,6 +566,46 @@ func (p *PipelineHIP) Run(prompts [][]uint32, steps int) {
 	}
 }
 
+// SetKeepCount: ModelParams.KeepCount (llama.go:47) of every stream; every rank calls it with the same value before the prompts.  A stream
+// that stands at the end of its window is swapped inside Run as server.Do does (server.go:160-172), on all ranks in the same tick.
+func (p *PipelineHIP) SetKeepCount(keep uint32) {
+	if rc := C.lh_pipeline_set_keep(p.pl, C.uint32_t(keep)); rc != 0 {
+		hipHalt(p.ctx.hip.ctx)
+	}
+}
+
+// Profile / Stats: where the time of the following Runs goes on THIS rank - its own kernels per tick (ms) and from the end of its stage to the
+// end of its send / receive (us; includes waiting for the predecessor).  Profile(true) also clears the totals.  Not for a timed run.
+func (p *PipelineHIP) Profile(on bool) {
+	v := C.int(0)
+	if on {
+		v = 1
+	}
+	if rc := C.lh_pipeline_profile(p.pl, v); rc != 0 {
+		hipHalt(p.ctx.hip.ctx)
+	}
+}
+
+func (p *PipelineHIP) Stats() (ticks uint32, stageMsPerTick, exchangeUsPerTick float32) {
+	var st C.lh_pipeline_stats
+	if rc := C.lh_pipeline_stats_read(p.pl, &st); rc != 0 {
+		hipHalt(p.ctx.hip.ctx)
+	}
+	if st.ticks == 0 {
+		return 0, 0, 0
+	}
+	return uint32(st.ticks), float32(st.stage_ms) / float32(st.ticks), float32(st.exchange_ms) * 1000 / float32(st.ticks)
+}
+
+// HopProbe: microseconds per grouped send + receive of `rows` residual rows round the ring (every rank calls it at the same time).
+func (p *PipelineHIP) HopProbe(rows, embd uint32, iters int) float32 {
+	var us C.float
+	if rc := C.lh_pipeline_hop_probe(p.pl, C.uint32_t(rows*embd*4), C.uint32_t(iters), &us); rc != 0 {
+		hipHalt(p.ctx.hip.ctx)
+	}
+	return float32(us)
+}
+
 // Tokens: ids of a stream known to this rank (rank 0: everything generated so far).
 func (p *PipelineHIP) Tokens(pod int) []uint32 {
 	n := int(C.lh_pipeline_tokens(p.pl, C.uint32_t(pod), nil, 0))
