@@ -242,7 +242,9 @@ static int gemv_rows_nc(lh_ctx* ctx, const GemvRowsArgs& a, const char* name) {
     }
     }
 }
-// block-int8 twin (k_gemv_q8_rows): the launch shape of gemv_q8's 256-thread workgroups (one or three 16-quant chunks per thread)
+// block-int8 twin (k_gemv_q8_rows): the launch shape of gemv_q8's 256-thread workgroups (one or three 16-quant chunks per thread).  (512 threads =
+// two row groups per workgroup, two waves per SIMD: measured, nothing - 4 pods 1417 / 1333 against 1393 / 1439 tok/s, 2 pods 939 against 893;
+// the kernel issues instructions 73 % of its wave cycles, it does not wait: profiles/r04_q8_rows_threads_pmc.txt)
 template <int KI, int U, int NC, int PRO, int EPI, int MAP>
 static int launch_gemv_q8_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, uint64_t bytes) {
     static bool flags[16] = {};
