@@ -102,6 +102,9 @@ def spawn_ranks(n):
     return max(abs(rc) for rc in rcs)
 
 
+_OUT = None   # the real stdout once main() has pointed fd 1 at stderr
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,6 +121,13 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+
+    # stdout carries ONE JSON line.  Native libraries write there too ("[Gloo] Rank 0 is connected to 2 peer ranks" in front of the line of a three-rank
+    # run: gloo's C++ side): fd 1 goes to stderr for the rest of the run, the line goes to the real stdout kept here
+    global _OUT
+    sys.stdout.flush()
+    _OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     ncpu_early = usable_cores()   # BEFORE an OpenMP runtime pins this thread (OMP_PROC_BIND below): the affinity mask then shows one core
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # before any OpenMP runtime loads (CPU baseline threads)
@@ -512,7 +522,7 @@ def main():
 
         def fail(stage, e):   # a failing rank says so and leaves: the launcher (or spawn_ranks) takes the others down
             msg = {"error": f"rank {rank}: {stage}: {e}", "n_gpus": world}
-            print(json.dumps(msg), file=sys.stderr if rank else sys.stdout, flush=True)
+            print(json.dumps(msg), file=sys.stderr if rank else _OUT, flush=True)
             os._exit(1)
 
         try:
@@ -645,7 +655,7 @@ def main():
     }
     line.update(result)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=_OUT, flush=True)
     if world > 1:
         dist.barrier()   # every rank is through its last exchange before any of them tears the control group down
         dist.destroy_process_group()
@@ -659,6 +669,6 @@ if __name__ == "__main__":
     except BaseException as e:   # whatever a rank dies of, it says so on one JSON line and exits non-zero: nobody waits for it
         import traceback
         traceback.print_exc()
-        print(json.dumps({"error": f"rank {os.environ.get('RANK', '0')}: {e!r}", "n_gpus": int(os.environ.get("WORLD_SIZE", "1"))}), flush=True)
+        print(json.dumps({"error": f"rank {os.environ.get('RANK', '0')}: {e!r}", "n_gpus": int(os.environ.get("WORLD_SIZE", "1"))}), file=_OUT or sys.stdout, flush=True)
         sys.stdout.flush()
         os._exit(1)

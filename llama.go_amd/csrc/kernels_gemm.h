@@ -54,6 +54,9 @@ struct GemmArgs {
     float* v_cache;
     const double2* rope;
     uint32_t hd;
+#ifdef GEMM_CLOCK
+    unsigned long long* clk;   // tools/gemm_probe.hip -DGEMM_CLOCK: shader clocks and 100 MHz ticks one workgroup spent in k_gemm_glds
+#endif
 };
 enum { GEMM_EPI_STORE = 0, GEMM_EPI_SILU_MUL = 1, GEMM_EPI_QKV_ROPE = 2 };
 
@@ -264,6 +267,9 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     // share a weight panel meet in one L2.
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+#ifdef GEMM_CLOCK
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (uint32_t wv = v0; wv < work; wv += G) {
     const uint32_t ks = wv % splits, wi = wv / splits;  // K range fastest: the pieces of one tile run side by side
     const uint32_t be = wi / total, bid = wi % total;
@@ -395,6 +401,9 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     if (a.epi != GEMM_EPI_STORE) gemm_store_fused<TN, TM>(a, acc, g, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
     else gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, ldy);
   }
+#ifdef GEMM_CLOCK
+    if (a.clk && blockIdx.x == G / 2 && tid == 0) { a.clk[0] = __builtin_amdgcn_s_memtime() - clk_c0; a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
+#endif
 }
 
 // Second pass of split-K: Y_g[n][m] = (R_g[n][m] +) sum over ks, in ks order, of part[g][ks][n][m].

@@ -38,6 +38,18 @@ static void run_glds(const char* name, uint32_t N, uint32_t M, uint32_t K, uint3
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
+#ifdef GEMM_CLOCK
+    {   // one more launch with the clock stamps of the middle workgroup (-DGEMM_CLOCK): what the shader clock is while this GEMM runs
+        unsigned long long* clk; hipMalloc(&clk, 16); hipMemset(clk, 0, 16);
+        a.clk = clk;
+        for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, a);
+        hipDeviceSynchronize();
+        unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+        printf("    shader clock while it runs: %.3f GHz (%llu clocks in %.1f us) -> fp32 matrix peak at this clock %.1f TFLOP/s\n", (double)h[0] / ((double)h[1] * 10.0), h[0],
+               (double)h[1] * 0.01, 157.3 * (double)h[0] / ((double)h[1] * 10.0) / 2.4);
+        a.clk = nullptr; hipFree(clk);
+    }
+#endif
     const double fl = 2.0 * N * M * K * groups;
     printf("GLDS(abl %d) %-10s <%d,%d,%d,%d> tile %3dx%3d tiles %5u (%.2f/CU)  %8.1f us  %6.1f TFLOP/s  %.1f %%\n", GEMM_ABL, name, WN, WM, TN, TM, BN, BM, tiles, tiles / 256.0, ms * 1e3,
            fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
@@ -130,6 +142,15 @@ static void run(const char* name, uint32_t N, uint32_t M, uint32_t K, uint32_t g
            ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100);
 }
 
+// pseudo-random operands in [-1, 1): the clock the chip holds under matrix load depends on what the multipliers toggle (all-zero operands run cooler)
+__global__ void k_fill_rand(float* p, size_t n, uint32_t seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = (float)((int)(h >> 8) - (1 << 23)) / (float)(1 << 23);
+    }
+}
+
 int main() {
 #if GEMM_ABL == 0
     if (check(300, 500, 256) | check(128, 160, 64) | check(33, 1000, 96)) return 1;
@@ -139,8 +160,14 @@ int main() {
     hipMalloc(&x, (size_t)N * F * 4);
     hipMalloc(&w, (size_t)3 * F * d * 4);
     hipMalloc(&y, (size_t)3 * N * F * 4);
+#ifdef GEMM_CLOCK
+    hipLaunchKernelGGL(k_fill_rand, dim3(4096), dim3(256), 0, 0, x, (size_t)N * F, 1u);
+    hipLaunchKernelGGL(k_fill_rand, dim3(4096), dim3(256), 0, 0, w, (size_t)3 * F * d, 2u);
+    hipDeviceSynchronize();
+#else
     hipMemset(x, 0, (size_t)N * F * 4);
     hipMemset(w, 0, (size_t)3 * F * d * 4);
+#endif
     run<4, 1, 1, 5>("qkv", N, d, d, 3, x, w, y);
     run<4, 1, 1, 5>("wo", N, d, d, 1, x, w, y);
     run<2, 2, 2, 2>("w1w3", N, F, d, 2, x, w, y);
