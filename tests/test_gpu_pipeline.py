@@ -24,13 +24,21 @@ def last_json(text):
     raise AssertionError("no JSON line in output:\n" + text[-2000:])
 
 
+def only_json(text):
+    """bench.py's contract: rank 0 prints ONE JSON line on stdout and nothing else (native libraries that print there - gloo's
+    "[Gloo] Rank 0 is connected ..." - are kept off it)."""
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    assert len(lines) == 1, "stdout must be exactly one line:\n" + text[-2000:]
+    return json.loads(lines[0])
+
+
 def test_two_rank_pipeline_reproduces_single_process_tokens(product):
     args = ["--shape", "small", "--steps", "6", "--warmup", "1", "--no-cpu-baseline"]
     env = dict(os.environ)
     env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    one = last_json(r1.stdout)
+    one = only_json(r1.stdout)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -40,7 +48,7 @@ def test_two_rank_pipeline_reproduces_single_process_tokens(product):
                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
                         cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
-    two = last_json(r2.stdout)
+    two = only_json(r2.stdout)
     assert two["n_gpus"] == 2 and two["config"]["streams"] == 8   # default: 4 streams per rank in flight
     assert two["tokens_stream0"] == one["tokens_stream0"], (one["tokens_stream0"], two["tokens_stream0"])
     assert len(one["tokens_stream0"]) == 6
@@ -58,7 +66,7 @@ def _bench(args, env, nranks, launcher):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks)] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    return last_json(r.stdout)
+    return only_json(r.stdout)
 
 
 def test_single_stream_and_self_spawned_ranks(product):
