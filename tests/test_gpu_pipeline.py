@@ -151,7 +151,15 @@ def test_rccl_transport_world_of_one(product, oracle):
     assert len(cid) == 128 and any(cid)
     pl = Pipeline(m, 48, len(prompts), 0, 1, comm_id=cid)
     pl.run(prompts, 3)
+    # the diagnosis calls of the N > 1 bench line on a real RCCL communicator: ring shifts (here: grouped send / receive to self) and the
+    # per-tick stage / exchange events
+    hop = pl.hop_probe(4096 * 4, 50)
+    assert 0.0 < hop < 1e5, hop
+    pl.profile(True)
     pl.run(None, 4)
+    st = pl.stats()
+    assert st["ticks"] >= 4 and st["stage_ms"] > 0.0 and st["exchange_ms"] >= 0.0, st
+    pl.profile(False)
     got = [pl.tokens(i) for i in range(len(prompts))]
     pl.free()
     # the same streams without any communicator (direct device copy of the id)
