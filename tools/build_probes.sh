@@ -7,4 +7,5 @@ done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/valu_mfma_probe tools/valu_mfma_probe.hip || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result -o tools/mfma_clock_probe tools/mfma_clock_probe.hip || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-unused-result -Illama.go_amd/csrc -Iinclude -DGEMM_CLOCK -o tools/gemm_probe_clock tools/gemm_probe.hip || exit 1
+for p in pk_fma_probe sync_latency_probe; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-unused-result -o tools/$p tools/$p.hip || exit 1; done
 ls -la tools/stream_mm_check*
