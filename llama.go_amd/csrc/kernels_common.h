@@ -6,6 +6,7 @@
 namespace lh {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 // Device-resident per-step parameters of a decode graph: kernels read `past`/`token` from here so a

@@ -23,7 +23,6 @@ namespace lh {
 
 __device__ __forceinline__ u4 ld_nt_u4(const u4* p) { return __builtin_nontemporal_load(p); }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 // 16 int8 x 16 fp32: two independent accumulator PAIRS so the FMAs can issue as v_pk_fma_f32 (2 FMAs per instruction)
 __device__ __forceinline__ float dot16_q8(const u4 q, const f4 (&x)[4]) {

@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
                 return;
             }
 #ifndef Q8_CVT
-#define Q8_CVT 1   // 0: unsigned convert + fma (k_stream_mm2's form), 1: sign-extending convert (SDWA byte select) + multiply, 2: byte permute into 2^23 + u, subtract, fma
+#define Q8_CVT 3   // 0: unsigned convert + fma (k_stream_mm2's form), 1: sign-extending convert (SDWA byte select) + multiply, 2: byte permute into 2^23 + u, subtract, fma, 3: form 1 with packed multiplies
 #endif
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
@@ -1196,6 +1196,13 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
                     a4[t].y = __fmul_rn(d[t], (float)(int)(signed char)(dq >> 8));
                     a4[t].z = __fmul_rn(d[t], (float)(int)(signed char)(dq >> 16));
                     a4[t].w = __fmul_rn(d[t], (float)(dq >> 24));
+                } else if constexpr (Q8_CVT == 3) {
+                    // the same values with the four multiplies as two v_pk_mul_f32 (scale broadcast to both halves; IEEE multiply per half: the same bits)
+                    const int dq = (int)raw[t];
+                    const f2 dd = f2{d[t], d[t]};
+                    const f2 lo = f2{(float)(int)(signed char)(dq), (float)(int)(signed char)(dq >> 8)} * dd;
+                    const f2 hi = f2{(float)(int)(signed char)(dq >> 16), (float)(dq >> 24)} * dd;
+                    a4[t] = f4{lo.x, lo.y, hi.x, hi.y};
                 } else if constexpr (Q8_CVT == 2) {
                     // 0x4B000000 | u = 2^23 + u as a float (one byte permute), minus 2^23 + 128 = q exactly, then the one rounding multiply
                     const unsigned int pk = raw[t] ^ 0x80808080u;
@@ -1229,7 +1236,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
 #pragma unroll
                     for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][s], b[c][s], acc[t][c], 0, 0, 0);
         };
-        constexpr int NM = 4 * MAXT * NCT, NV = (Q8_CVT == 1 ? 8 : Q8_CVT == 2 ? 13 : 10) * MAXT, VPM = (NV + NM - 1) / NM;   // MFMAs of a k-block, vector instructions of one conversion, of them behind each MFMA
+        constexpr int NM = 4 * MAXT * NCT, NV = (Q8_CVT == 1 ? 8 : Q8_CVT == 2 ? 13 : Q8_CVT == 3 ? 6 : 10) * MAXT, VPM = (NV + NM - 1) / NM;   // MFMAs of a k-block, vector instructions of one conversion, of them behind each MFMA
         static_assert(KB % 2 == 0, "the two operand sets alternate by k-block parity across chunks");
         // The pipeline runs ACROSS chunks: the step behind the last k-block of chunk ch is the first of chunk ch + 1, so barrier ch + 1 stands
         // in front of that k-block's MFMAs (its operands are in registers by then: the image of chunk ch is not read any more).
