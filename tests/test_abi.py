@@ -54,6 +54,64 @@ def test_headers_and_exports_agree_in_both_directions(built):
     assert bound <= go_decl, sorted(bound - go_decl)
 
 
+def _split_args(text):
+    """top-level comma split of an argument list (nested parentheses / brackets / braces stay together)"""
+    out, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _call_args(src, start):
+    """the text between the parentheses of the call whose '(' is at src[start]"""
+    depth, i = 0, start
+    while True:
+        if src[i] == "(":
+            depth += 1
+        elif src[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return src[start + 1:i]
+        i += 1
+
+
+def test_go_shim_calls_only_declared_functions_with_the_declared_arity():
+    """The cgo shim cannot be compiled here (no Go toolchain): at least every C.lh_* it calls must be a function llamahip.h declares, called with
+    the number of arguments the prototype has, and every C.lh_* / C.LH_* type or constant it names must exist in the header."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "llamahip.h")).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(lh_[A-Za-z0-9_]+)\s*\(", hdr):
+        args = _call_args(hdr, m.end() - 1).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_split_args(args))
+    go = open(os.path.join(ROOT, "llama.go_amd", "go", "ml_hip.go")).read()
+    go = re.sub(r"//[^\n]*", "", go)
+    go_code = go.split('import "C"', 1)[1]          # below the cgo preamble
+    calls = 0
+    for m in re.finditer(r"\bC\.(lh_[A-Za-z0-9_]+)\s*\(", go_code):
+        name = m.group(1)
+        if name not in protos:
+            # a conversion to a C type, e.g. C.lh_buf(x): the type must exist
+            assert re.search(r"\b" + name + r"\b", hdr), f"ml_hip.go uses C.{name}, which llamahip.h does not know"
+            continue
+        args = _call_args(go_code, m.end() - 1).strip()
+        n = 0 if not args else len(_split_args(args))
+        assert n == protos[name], f"ml_hip.go calls C.{name} with {n} arguments, llamahip.h declares {protos[name]}"
+        calls += 1
+    assert calls >= 30, calls
+    for name in set(re.findall(r"\bC\.((?:lh|LH)_[A-Za-z0-9_]+)\b", go_code)):
+        assert re.search(r"\b" + name + r"\b", hdr), f"ml_hip.go names C.{name}, which llamahip.h does not declare"
+
+
 def test_host_library_and_oracle_export_the_mirror_api(built):
     import llama_go_amd as pkg
     C.CDLL(pkg.LIBLLAMAHIP, mode=C.RTLD_GLOBAL)
