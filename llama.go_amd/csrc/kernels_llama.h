@@ -337,7 +337,18 @@ struct AttnArgs {
     // layer's slot); k_cache, v_cache, sp and past_host are then unused
     const BatchRow* rows;
     uint64_t kv_off;
+    // block-int8 on the bf16 pipe (k_stream_q8b): the merged heads ALSO as three bf16 planes (out = hi + mid + lo exactly), row j at
+    // out_s3 + p * out_plane + j * d - the activation format of the wo launch behind it
+    uint16_t* out_s3;
+    uint64_t out_plane;
 };
+__device__ __forceinline__ void attn_store_split3(const AttnArgs& a, size_t idx, float o) {
+    const uint32_t h = __builtin_bit_cast(uint32_t, o) & 0xffff0000u;
+    const float r1 = __fsub_rn(o, __builtin_bit_cast(float, h));
+    const uint32_t m = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    const float r2 = __fsub_rn(r1, __builtin_bit_cast(float, m));
+    a.out_s3[idx] = (uint16_t)(h >> 16); a.out_s3[idx + a.out_plane] = (uint16_t)(m >> 16); a.out_s3[idx + 2 * a.out_plane] = (uint16_t)(__builtin_bit_cast(uint32_t, r2) >> 16);
+}
 
 constexpr int ATT_TH = 1024;
 
@@ -470,6 +481,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
         float o = scratch[tid];
         for (uint32_t p2 = 1; p2 < phases; ++p2) o += scratch[tid + p2 * hd];
         a.out[(size_t)j * d + h * hd + tid] = o;
+        if (a.out_s3) attn_store_split3(a, (size_t)j * d + h * hd + tid, o);
     }
 }
 
@@ -574,7 +586,9 @@ __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, con
             const float w = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
             o = fmaf(base[(size_t)s * (hd + 2) + c], w, o);
         }
-        a.out[(size_t)j * a.d + h * hd + c] = __fmul_rn(o, inv);
+        const float ov = __fmul_rn(o, inv);
+        a.out[(size_t)j * a.d + h * hd + c] = ov;
+        if (a.out_s3) attn_store_split3(a, (size_t)j * a.d + h * hd + c, ov);
     }
 }
 

@@ -34,7 +34,7 @@ struct StreamArgs {
     const float* ws[3];  // block-int8 models (k_stream_mm2<.., true>): w[] are the int8 planes [M][K], ws[] the fp32 scales [M][K / 32]
     const float* x;      // activations [n][K], row c at x + c * ldx
     uint32_t groups, M, K, n, ldx, ldy;
-#ifdef STREAM_TRACE
+#if defined(STREAM_TRACE) || defined(Q8B_TRACE)
     unsigned long long* trace;   // tools/stream_mm_check: [4 waves][8] shader-clock totals of workgroup 0's loop phases
 #endif
     // fused epilogues of k_stream_mm2 (the launches llama.Eval makes, llama.go:255-297 and :346-361)
@@ -63,6 +63,15 @@ struct StreamArgs {
     uint64_t ysplit;     // floats between the partial outputs
     uint32_t tiled;      // the matrices are stored chunk-major: [K / KC][M / 16][16][KC] (stream_tile_layout): a workgroup's rows of one
                          // K-chunk are ONE contiguous run, and so are all workgroups' together
+    // k_stream_q8b (kernels_stream_q8b.h): the activations as three bf16 planes (x = hi + mid + lo exactly), plane p row c at
+    // xs + p * xs_plane + c * ldxs (elements of 2 bytes); x above is then unused.  ys != nullptr: the epilogue ALSO writes its fp32 result
+    // split the same way (the next launch's activations: silu*mul -> w2), row c at ys + p * ys_plane + c * ldys
+    const uint16_t* xs;
+    uint64_t xs_plane;
+    uint32_t ldxs;
+    uint16_t* ys;
+    uint64_t ys_plane;
+    uint32_t ldys;
 };
 
 enum { ST_EPI_STORE = 0, ST_EPI_SILU_MUL = 1, ST_EPI_QKV_ROPE = 2 };   // plain (+ residual) | y[0] = silu(w[0] x) * (w[1] x) | RoPE + cache append
@@ -292,6 +301,24 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
     }
 }
 
+// x = hi + mid + lo exactly, each piece a bf16 (its 16 bits returned): the activation format of k_stream_q8b (kernels_stream_q8b.h)
+__device__ __forceinline__ void split3(float x, uint32_t* hi, uint32_t* mid, uint32_t* lo) {
+    const uint32_t h = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+    const float r1 = __fsub_rn(x, __builtin_bit_cast(float, h));          // exact: the low 16 bits of x's significand
+    const uint32_t m = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    const float r2 = __fsub_rn(r1, __builtin_bit_cast(float, m));         // exact: <= 8 significant bits
+    *hi = h >> 16; *mid = m >> 16; *lo = __builtin_bit_cast(uint32_t, r2) >> 16;
+}
+// four consecutive features `row..row + 3` of token row `col` into the three output planes (StreamArgs::ys)
+__device__ __forceinline__ void stream_store_split3(const StreamArgs& a, uint32_t col, uint32_t row, f4 v) {
+    uint32_t h[4], m[4], l[4];
+    split3(v.x, &h[0], &m[0], &l[0]); split3(v.y, &h[1], &m[1], &l[1]); split3(v.z, &h[2], &m[2], &l[2]); split3(v.w, &h[3], &m[3], &l[3]);
+    uint16_t* o = a.ys + (size_t)col * a.ldys + row;
+    *(uint2*)(o) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+    *(uint2*)(o + a.ys_plane) = uint2{m[0] | (m[1] << 16), m[2] | (m[3] << 16)};
+    *(uint2*)(o + 2 * a.ys_plane) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Epilogue of the wave-specialised kernels (k_stream_mm2, k_stream_dma): the partial tiles of the four MFMA waves (waves 4..7, each holding
 // the sums over its share of every chunk's k-blocks) meet in LDS, thread (column, row quad) adds them in wave order (bit-reproducible) and
@@ -300,7 +327,10 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
 // a folded RMSNorm (k_stream_mm2) or nullptr; acc_of(t, c) = this wave's partial tile.  CS = 2 (k_stream_dma, seven / eight column tiles):
 // the MFMA waves are dealt as 2 K-groups x 2 column halves, MFMA wave w holds the sums of K-group w >> 1 for column tiles
 // (w & 1) NCT / 2 + c; two partials per tile meet instead of four.
-template <int MAXT, int NCT, int CS = 1, typename AccFn>
+// TR (k_stream_q8b): the MFMA was issued transposed - a lane's four results are tokens 4 slot + i of ONE weight row (lane & 15).
+// NB > 0 (k_stream_q8b, sixteen equal waves): wave w holds the sums over quant block w % NB of every chunk for the tiles t with
+// t % (16 / NB) == w / NB; NB partials per tile meet.
+template <int MAXT, int NCT, int CS = 1, bool TR = false, int NB = 0, typename AccFn>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_raw, uint32_t lds_floats, const float* scales, uint32_t t0, uint32_t nt, uint32_t ks,
                                                 uint32_t tiles_per_mat, AccFn&& acc_of) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -311,14 +341,16 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         if (pairs) { *g = v & 1u; *tile = v >> 1; }
         else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
     };
-    constexpr int NC = NCT * 16, NKG = 4 / CS, NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
+    constexpr int NC = NCT * 16, NKG = NB > 0 ? NB : 4 / CS, NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
+    constexpr int TGX = NB > 0 ? 16 / NB : 1;
     static_assert(CS == 1 || (CS == 2 && NCT % 2 == 0), "column split");
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = (uint32_t)NKG * NC * 16;
     const uint32_t batch = (lds_floats / TILE_FLOATS) & ~1u;   // even: a pair never straddles two batches
     const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
     const float nscale = (scales && col < (uint32_t)NC) ? scales[col] : 1.0f;
-    const uint32_t kg = CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4), cbase = CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u;
+    const uint32_t kg = NB > 0 ? (uint32_t)wave % (uint32_t)NKG : (CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4)), cbase = CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u;
+    const uint32_t tgw = NB > 0 ? (uint32_t)wave / (uint32_t)NKG : 0u;
     auto tile_sum = [&](uint32_t slot_in_batch) {
         const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
         f4 s = *(const f4*)p;
@@ -331,13 +363,17 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         return s;
     };
     for (uint32_t tb = 0; tb < nt; tb += batch) {
-        if (wave >= 4) {
+        if (NB > 0 || wave >= 4) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) {
+                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt && (NB == 0 || (uint32_t)(t % TGX) == tgw)) {
 #pragma unroll
                     for (int c = 0; c < NCW; ++c) {
                         const f4m v = acc_of(t, c);
+                        if constexpr (TR) {
+                            float* pp = part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)kg * NC + (cbase + c) * 16 + slot * 4) * 16 + r16;
+                            pp[0] = v[0]; pp[16] = v[1]; pp[32] = v[2]; pp[48] = v[3];
+                        } else
                         *(f4m*)(part + (size_t)(t - tb) * TILE_FLOATS + ((size_t)kg * NC + (cbase + c) * 16 + r16) * 16 + slot * 4) = v;
                     }
                 }
@@ -352,7 +388,8 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
                     f4 o;   // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
                     o.x = __fmul_rn(silu_ref(s1.x), s3.x); o.y = __fmul_rn(silu_ref(s1.y), s3.y);
                     o.z = __fmul_rn(silu_ref(s1.z), s3.z); o.w = __fmul_rn(silu_ref(s1.w), s3.w);
-                    *(f4*)(a.y[0] + (size_t)col * a.ldy + row) = o;
+                    if (a.y[0]) *(f4*)(a.y[0] + (size_t)col * a.ldy + row) = o;
+                    if (a.ys) stream_store_split3(a, col, row, o);
                 }
             } else {
                 for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
@@ -382,6 +419,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
                             s.x = __fadd_rn(s.x, rv.x); s.y = __fadd_rn(s.y, rv.y); s.z = __fadd_rn(s.z, rv.z); s.w = __fadd_rn(s.w, rv.w);   // Add ml.go:2515-2584
                         }
                         *(f4*)(yp + o) = s;
+                        if (a.ys && g == 0) stream_store_split3(a, col, row, s);
                     }
                 }
             }
@@ -1281,8 +1319,10 @@ struct StreamReduceArgs {
     const float* resid;  // [n][ldy] or nullptr
     float* y;            // [n][ldy]
     const float* gamma;  // [d] or nullptr: no norm output
-    float* h;            // [n][d] normalised rows
+    float* h;            // [n][d] normalised rows (or nullptr)
     uint32_t S, d, ldy;
+    uint16_t* hs;        // block-int8 on the bf16 pipe (k_stream_q8b): the normalised rows as three bf16 planes, row b at hs + p * hs_plane + b * d
+    uint64_t hs_plane;
 };
 __global__ __launch_bounds__(256) void k_stream_reduce_norm(const StreamReduceArgs a) {
     __shared__ double sred[4];
@@ -1337,7 +1377,15 @@ __global__ __launch_bounds__(256) void k_stream_reduce_norm(const StreamReduceAr
             f4 o;
             o.x = __fmul_rn(g[j].x, __fmul_rn(v[j].x, scale)); o.y = __fmul_rn(g[j].y, __fmul_rn(v[j].y, scale));
             o.z = __fmul_rn(g[j].z, __fmul_rn(v[j].z, scale)); o.w = __fmul_rn(g[j].w, __fmul_rn(v[j].w, scale));
-            ((f4*)hr)[i] = o;
+            if (a.h) ((f4*)hr)[i] = o;
+            if (a.hs) {
+                uint32_t hh[4], mm[4], ll[4];
+                split3(o.x, &hh[0], &mm[0], &ll[0]); split3(o.y, &hh[1], &mm[1], &ll[1]); split3(o.z, &hh[2], &mm[2], &ll[2]); split3(o.w, &hh[3], &mm[3], &ll[3]);
+                uint16_t* op = a.hs + (size_t)blockIdx.x * a.d + (size_t)i * 4;
+                *(uint2*)(op) = uint2{hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16)};
+                *(uint2*)(op + a.hs_plane) = uint2{mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16)};
+                *(uint2*)(op + 2 * a.hs_plane) = uint2{ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16)};
+            }
         }
     }
 }

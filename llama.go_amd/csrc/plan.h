@@ -44,6 +44,8 @@ struct Plan {
     uint64_t scratch_gen = 0;                 // counts re-allocations of the scratch below (graphs captured elsewhere - lh_batch - compare it)
     float *xa = nullptr, *xb = nullptr, *h = nullptr, *qraw = nullptr, *kraw = nullptr, *vraw = nullptr, *q = nullptr, *attn = nullptr;
     float *a1 = nullptr, *a3 = nullptr, *g = nullptr, *logits = nullptr;
+    uint16_t* s3 = nullptr;                   // block-int8 plans: the activations of the int8 matmuls as three bf16 planes each (kernels_stream_q8b.h):
+                                              // [3][n_cap][d] normalised rows, [3][n_cap][d] merged attention heads, [3][n_cap][F] gated rows
     float* emb = nullptr;                     // LH_T_OUTPUT on llama.Eval's `embeddings`: the final norm rows [emb_cap][d]
     uint32_t emb_cap = 0;
     float* attn_part = nullptr;               // split-T decode attention partials [H][chunks][hd + 2] (plans with ctx > 256)

@@ -9,6 +9,7 @@
 #include "kernels_attn.h"
 #include "kernels_sample.h"
 #include "kernels_stream.h"
+#include "kernels_stream_q8b.h"
 #include "kernels_rows.h"
 #include <math.h>
 #include <string.h>
@@ -777,6 +778,111 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
     return 0;
 }
 
+// ---- k_stream_q8b (kernels_stream_q8b.h, round 5): block-int8 weights on the bf16 matrix pipe, activations as three bf16 planes (exact split).
+// Chunk length per shape: 256 columns; 512 where a workgroup holds at most three row tiles next to one column tile (wq|wk|wv: half as many
+// barriers; standalone on 7B 20.2-22.2 us against 23.5); 128 from three column tiles on and where K is not a multiple of 256.
+constexpr int q8b_nimg_fit(int maxt, int xr, int kc) {
+    const int n = (int)(160 * 1024 / stream_q8b_image_bytes(maxt, xr, kc));
+    return n < 4 ? n : 4;
+}
+template <int MAXT, int NCT, int KC, int XR>
+static int launch_stream_q8b(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    constexpr int NIMG = q8b_nimg_fit(MAXT, XR, KC);
+    if constexpr (NIMG < 2) return ST_NA;
+    else {
+        static bool flags[16] = {};
+        auto kern = k_stream_q8b<MAXT, NCT, KC, NIMG, XR>;
+        const size_t lds = std::max<size_t>((size_t)NIMG * stream_q8b_image_bytes(MAXT, XR, KC), 82 * 1024);   // one workgroup per CU
+        int rc = set_lds_once(ctx, kern, lds, flags);
+        if (rc) return rc;
+        if (g_prepare_only) return 0;
+        const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
+        ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K / 32 * 36);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Q8B_TH), lds, ctx->stream, a);
+        LH_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+}
+template <int MAXT, int NCT, int XR>
+static int launch_stream_q8b_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    const uint32_t S = a.ksplit > 1 ? a.ksplit : 1u;
+    if constexpr (NCT == 1 && MAXT <= 3 && q8b_nimg_fit(MAXT, XR, 512) >= 2) { if (a.K % 512 == 0 && a.K / 512 >= S) return launch_stream_q8b<MAXT, NCT, 512, XR>(ctx, a, name); }
+    if constexpr (NCT <= 2 && q8b_nimg_fit(MAXT, XR, 256) >= 2) { if (a.K % 256 == 0 && a.K / 256 >= S) return launch_stream_q8b<MAXT, NCT, 256, XR>(ctx, a, name); }
+    if (a.K / 128 < S) return ST_NA;
+    return launch_stream_q8b<MAXT, NCT, 128, XR>(ctx, a, name);
+}
+template <int MAXT>
+static int launch_stream_q8b_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    if (a.n <= 8) return launch_stream_q8b_kc<MAXT, 1, 8>(ctx, a, name);
+    if (a.n <= 16) return launch_stream_q8b_kc<MAXT, 1, 16>(ctx, a, name);
+    if (a.n <= 32) return launch_stream_q8b_kc<MAXT, 2, 32>(ctx, a, name);
+    if (a.n <= 48) return launch_stream_q8b_kc<MAXT, 3, 48>(ctx, a, name);
+    if (a.n <= 64) return launch_stream_q8b_kc<MAXT, 4, 64>(ctx, a, name);
+    return ST_NA;
+}
+static int launch_stream_q8b_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name, uint32_t maxt) {
+    switch (maxt) {
+        case 1: return launch_stream_q8b_n<1>(ctx, a, name);
+        case 2: return launch_stream_q8b_n<2>(ctx, a, name);
+        case 3: return launch_stream_q8b_n<3>(ctx, a, name);
+        case 4: return launch_stream_q8b_n<4>(ctx, a, name);
+        case 5: case 6: return launch_stream_q8b_n<6>(ctx, a, name);
+        case 7: case 8: return launch_stream_q8b_n<8>(ctx, a, name);
+        default: return ST_NA;
+    }
+}
+// groups (<= 3) int8 matrices of equal shape times the same activation planes in ONE launch; fused: the epilogue (RoPE + cache append | silu * mul)
+static int gemm_q8b_group(lh_ctx* ctx, const uint16_t* xs, uint64_t xs_plane, uint32_t ldxs, uint32_t groups, const float* const* wq, const float* const* wsc, float* const* y,
+                          const float* const* r, uint32_t M, uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr) {
+    if (n == 0 || n > STREAM_ROWS_Q8 || groups > 3 || M % 16 || K % 128 || ldxs % 8 || ldy % 4 || ((uintptr_t)xs & 15) || (xs_plane * 2) % 16) return ST_NA;
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
+    const uint32_t maxt = (fused && fused->epi == ST_EPI_SILU_MUL) ? 2 * ((M / 16 + ncu - 1) / ncu) : (T + ncu - 1) / ncu;
+    if (maxt > 8) return ST_NA;
+    if (fused && fused->epi == ST_EPI_QKV_ROPE && (fused->hd % 4 || M % fused->hd)) return ST_NA;
+    StreamArgs a = {};
+    if (fused) a = *fused;
+    a.xs = xs; a.xs_plane = xs_plane; a.ldxs = ldxs; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldy = ldy;
+    for (uint32_t g = 0; g < groups; ++g) {
+        a.w[g] = wq[g]; a.ws[g] = wsc[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr;
+        if (((uintptr_t)wq[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || ((uintptr_t)a.ws[g] & 15)) return ST_NA;
+    }
+    return launch_stream_q8b_maxt(ctx, a, name, maxt);
+}
+// One matrix as groups of S workgroups that split the contraction (a workgroup then holds S times the rows for a 1 / S of K: the single-tile
+// matrices wo and w2 read S times less of X out of L2 and run S times fewer, longer chunk loops), k_stream_reduce_norm adds the S partials +
+// the residual in fixed order and writes the RMSNorm * gamma rows of the NEXT matmul as planes (and as fp32 rows when h is given) - it
+// stands where that norm's launch stood.  Standalone, 7B (profiles/r05_q8b_probe.txt): wo at 8 / 32 rows 11.5 / 14.5 us in fours against
+// 12.5 / - unsplit, w2 17.5 / 26.2 against 20.3 / 39.6.
+static int gemm_q8b_split(lh_ctx* ctx, const float* wq, const float* wsc, const uint16_t* xs, uint64_t xs_plane, uint32_t ldxs, uint32_t M, uint32_t K, uint32_t n,
+                          const float* resid, float* y, const float* gamma, float* h, uint16_t* hs, uint64_t hs_plane, const char* name) {
+    if (n == 0 || n > STREAM_ROWS_Q8 || M % 16 || M > 8192 || M % 4 || K % 128 || ldxs % 8 || ((uintptr_t)xs & 15) || (xs_plane * 2) % 16) return ST_NA;
+    if ((((uintptr_t)wq | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h | (uintptr_t)hs | (uintptr_t)wsc) & 15)) return ST_NA;
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, nchunks = K / (K % 256 == 0 ? 256u : 128u);
+    uint32_t S = 4;
+    while (S > 1 && (nchunks < 2 * S || ncu / S == 0)) S >>= 1;
+    const uint32_t ngrp = ncu / S, maxt = (M / 16 + ngrp - 1) / ngrp;
+    if (maxt > 8) return ST_NA;
+    const uint64_t need = (uint64_t)S * n * M;
+    if (need > ctx->splitk_floats) {
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
+        ctx->splitk = nullptr; ctx->splitk_floats = 0; ctx->splitk_gen++;
+        LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
+        ctx->splitk_floats = need;
+    }
+    StreamArgs a = {};
+    a.xs = xs; a.xs_plane = xs_plane; a.ldxs = ldxs; a.groups = 1; a.M = M; a.K = K; a.n = n; a.ldy = M; a.w[0] = wq; a.ws[0] = wsc; a.y[0] = ctx->splitk;
+    a.ksplit = S; a.ysplit = (uint64_t)n * M;
+    const int rs = launch_stream_q8b_maxt(ctx, a, name, maxt);
+    if (rs) return rs;
+    if (g_prepare_only) return 0;
+    StreamReduceArgs r = {};
+    r.part = ctx->splitk; r.stride = a.ysplit; r.resid = resid; r.y = y; r.gamma = gamma; r.h = h; r.S = S; r.d = M; r.ldy = M; r.hs = hs; r.hs_plane = hs_plane;
+    { TraceScope ts_(ctx->stream, "stream_reduce_norm"); hipLaunchKernelGGL(k_stream_reduce_norm, dim3(n), dim3(256), 0, ctx->stream, r); }
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // fused != nullptr: GEMM_EPI_SILU_MUL (w = {w1, w3}, y[0] = gated output [n][M]) or GEMM_EPI_QKV_ROPE (w = {wq, wk, wv}; outputs in *fused) in
 // the epilogue of the LDS-DMA tile GEMM; returns ST_NA when the launch cannot take it (short prompt, split-K, register-staged kernel) and
 // the caller runs the plain GEMM + the separate pass.
@@ -977,6 +1083,11 @@ int plan_ensure_rows(Plan* p, uint32_t n) {
     if (n > 1) { rc |= re(&p->qraw, nd); rc |= re(&p->kraw, nd); rc |= re(&p->vraw, nd); rc |= re(&p->a1, nf); rc |= re(&p->a3, nf); }
     if (m.last_stage()) rc |= re(&p->logits, (size_t)n * m.V);
     if (rc) return LH_EHIP;
+    if (m.wtype == 7 && n > 1) {
+        if (p->s3) LH_HIP(ctx, hipFree(p->s3));
+        p->s3 = nullptr;
+        LH_HIP(ctx, hipMalloc((void**)&p->s3, (size_t)3 * n * (2 * (size_t)m.d + m.F) * 2));
+    }
     if (p->tokens_dev) LH_HIP(ctx, hipFree(p->tokens_dev));
     LH_HIP(ctx, hipMalloc((void**)&p->tokens_dev, (size_t)n * 4));
     p->n_cap = n;
@@ -1029,6 +1140,7 @@ void plan_destroy(Plan* p) {
     if (p->out_tokens_dev) hipFree(p->out_tokens_dev);
     if (p->argmax_dev) hipFree(p->argmax_dev);
     if (p->attn_part) hipFree(p->attn_part);
+    if (p->s3) hipFree(p->s3);
     delete p;
 }
 
@@ -1311,6 +1423,88 @@ bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     return m.d % GBK == 0 && m.F % GBK == 0;
 }
 
+// Block-int8, 5..64 rows (a prompt's tokens or the pods of a tick): the layers on k_stream_q8b.  Per layer 7 launches:
+//   [RMSNorm -> planes] (first layer only; afterwards the w2 reduce pass of the layer before writes them)
+//   wq|wk|wv + RoPE + cache append | attention (merged heads -> planes) | wo as K-split fours | reduce + residual + RMSNorm -> planes |
+//   w1|w3 + silu * mul -> planes | w2 as K-split fours | reduce + residual + the NEXT norm -> planes
+// (llama.go:255-366).  Returns ST_NA before anything is enqueued when a launch of the model has no instantiation (the caller's older route
+// then takes the Eval).
+static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only, const BatchCtx* bc) {
+    lh_ctx* ctx = p->ctx;
+    const ModelDesc& m = p->md;
+    const uint32_t d = m.d, F = m.F, ncu = (uint32_t)ctx->ds->num_cu;
+    if (d > 8192 || d % 128 || F % 128 || (3 * d / 16 + ncu - 1) / ncu > 8 || 2 * ((F / 16 + ncu - 1) / ncu) > 8 || (d / 16 + ncu / 4 - 1) / (ncu / 4) > 8 || ncu < 4) return ST_NA;
+    if (m.last_stage() && (m.V % 16 || (m.V / 16 + ncu - 1) / ncu > 8)) return ST_NA;
+    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+        const LayerW& L = m.layers[il];
+        const float* sc[] = {L.s_wq, L.s_wk, L.s_wv, L.s_wo, L.s_w1, L.s_w2, L.s_w3};
+        for (const float* q : sc) if (!q || ((uintptr_t)q & 15)) return ST_NA;
+    }
+    const BatchRow* rows = bc ? bc->rows : nullptr;
+    const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
+    const uint64_t pd = (uint64_t)p->n_cap * d, pf = (uint64_t)p->n_cap * F;   // plane strides (elements)
+    uint16_t* hs = p->s3;
+    uint16_t* as = hs + 3 * pd;
+    uint16_t* gs = as + 3 * pd;
+    int rc;
+#define Q8B_TRY(expr, what) do { if ((rc = (expr))) { if (rc == ST_NA) LH_FAIL(ctx, LH_ESHAPE, "block-int8 Eval of %u rows: no launch for %s (embd %u, ff %u)", n, what, d, F); return rc; } } while (0)
+    bool h_ready = false;
+    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
+        const LayerW& L = m.layers[il];
+        const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
+        if (!h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_s3"); if (!g_prepare_only) hipLaunchKernelGGL(k_rmsnorm_rows_s3, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, (float*)nullptr, hs, pd, d); }
+        {   // wq|wk|wv -> RoPE(Q, new K rows) -> K, V appended   (llama.go:263-297)
+            const float* wqkv[3] = {L.wq, L.wk, L.wv};
+            const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
+            StreamArgs fq = {};
+            fq.epi = ST_EPI_QKV_ROPE; fq.q_out = p->q; fq.k_cache = m.kc + slot; fq.v_cache = m.vc + slot; fq.rope = p->rope; fq.hd = m.hd; fq.past = past;
+            fq.rows = rows; fq.kv_off = slot;
+            Q8B_TRY(gemm_q8b_group(ctx, hs, pd, d, 3, wqkv, sqkv, nullptr, nullptr, d, d, n, d, "q8b_wqkv_rope", &fq), "wq|wk|wv");
+        }
+        if (rows) {   // rows of different streams: one query each, against its own cache up to its own position
+            AttnArgs a = {};
+            a.q = p->q; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.rows = rows; a.kv_off = slot; a.out_s3 = as; a.out_plane = pd;
+            if (bc->attn_part) { if ((rc = launch_attention_split(p, a, bc->attn_part))) return rc; }
+            else if ((rc = launch_attention(ctx, a, m.ctx))) return rc;
+        } else if (n >= 32 && m.hd == FA_HD) {   // a prompt: single pass, online softmax; its rows are split by a pass of their own
+            if ((rc = attention_flash(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
+            Split3Args sa = {p->attn, as, pd, d, d, d};
+            if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); hipLaunchKernelGGL(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
+        } else {
+            AttnArgs a = {};
+            a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
+            a.out_s3 = as; a.out_plane = pd;
+            if ((rc = launch_attention(ctx, a, past + n))) return rc;
+        }
+        // wo + residual + RMSNorm * ffn_norm -> planes   (llama.go:336-351)
+        Q8B_TRY(gemm_q8b_split(ctx, L.wo, L.s_wo, as, pd, d, d, d, n, x, p->xb, L.ffn_norm, nullptr, hs, pd, "q8b_wo_ksplit"), "wo");
+        {   // w1|w3 -> silu(w1 h) * (w3 h) -> planes   (llama.go:354-361)
+            const float* w13[2] = {L.w1, L.w3};
+            const float* s13[2] = {L.s_w1, L.s_w3};
+            StreamArgs fa = {};
+            fa.epi = ST_EPI_SILU_MUL; fa.ys = gs; fa.ys_plane = pf; fa.ldys = F;
+            Q8B_TRY(gemm_q8b_group(ctx, hs, pd, d, 2, w13, s13, nullptr, nullptr, F, d, n, F, "q8b_w1w3_silu", &fa), "w1|w3");
+        }
+        {   // w2 + residual (+ the next layer's first norm, or the final norm, on the reduce pass)   (llama.go:363-372)
+            const bool last = il + 1 == m.layer1;
+            float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
+            const float* next_gamma = !last ? m.layers[il + 1].attn_norm : (m.last_stage() ? m.norm : nullptr);
+            Q8B_TRY(gemm_q8b_split(ctx, L.w2, L.s_w2, gs, pf, F, d, F, n, p->xb, y, next_gamma, (last && m.last_stage()) ? p->h : nullptr, next_gamma ? hs : nullptr, pd, "q8b_w2_ksplit"), "w2");
+            h_ready = next_gamma != nullptr;
+        }
+        x = p->xa;
+        LH_HIP(ctx, hipGetLastError());
+    }
+    if (m.last_stage()) {   // lm_head on the rows the caller reads (llama.go:374-384, 394-401); hs / p->h hold RMSNorm * norm of every row
+        const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
+        const float* wv = m.output; const float* sv = m.s_output; float* yv = p->logits + (size_t)r0 * m.V;
+        Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)r0 * d, pd, d, 1, &wv, &sv, &yv, nullptr, m.V, d, nr, m.V, "q8b_lmhead"), "lm_head");
+    }
+    LH_HIP(ctx, hipGetLastError());
+#undef Q8B_TRY
+    return 0;
+}
+
 int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only, const BatchCtx* bc) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
@@ -1508,6 +1702,10 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     }
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
     const uint32_t d = m.d, F = m.F;
+    if (q8_stream && p->s3) {
+        const int rs = eval_q8b_layers(p, x, x_out_dev, n, past, last_row_only, bc);
+        if (rs != ST_NA) return rs;
+    }
     bool h_ready = false;   // p->h already holds this layer's RMSNorm * attn_norm rows (written by the previous layer's w2 reduce pass)
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
