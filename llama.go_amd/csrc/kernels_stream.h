@@ -347,7 +347,10 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = (uint32_t)NKG * NC * 16;
     const uint32_t batch = (lds_floats / TILE_FLOATS) & ~1u;   // even: a pair never straddles two batches
-    const uint32_t col = (uint32_t)tid >> 2, quad = (uint32_t)tid & 3;
+    // second phase: thread (column, row quad) of thread group `egrp` adds the partials of the tiles egrp, egrp + negrp, ... (tile pairs under
+    // silu * mul) - every 4 NC threads of the workgroup take tiles of their own (round 5: one group did all of them while up to fifteen waves idled)
+    const uint32_t egrp = (uint32_t)tid / (4u * NC), negrp = (uint32_t)blockDim.x / (4u * NC), etid = (uint32_t)tid - egrp * (4u * NC);
+    const uint32_t col = etid >> 2, quad = etid & 3;
     const float nscale = (scales && col < (uint32_t)NC) ? scales[col] : 1.0f;
     const uint32_t kg = NB > 0 ? (uint32_t)wave % (uint32_t)NKG : (CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4)), cbase = CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u;
     const uint32_t tgw = NB > 0 ? (uint32_t)wave / (uint32_t)NKG : 0u;
@@ -380,9 +383,9 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
             }
         }
         __syncthreads();
-        if (tid < 4 * NC && col < a.n) {
+        if (egrp < negrp && col < a.n) {
             if (a.epi == ST_EPI_SILU_MUL) {
-                for (uint32_t t = tb; t + 1 < tb + batch && t + 1 < nt; t += 2) {   // (w1 tile, w3 tile) of the same rows
+                for (uint32_t t = tb + 2 * egrp; t + 1 < tb + batch && t + 1 < nt; t += 2 * negrp) {   // (w1 tile, w3 tile) of the same rows
                     const f4 s1 = tile_sum(t - tb), s3 = tile_sum(t + 1 - tb);
                     const uint32_t row = ((t0 + t) >> 1) * 16 + quad * 4;
                     f4 o;   // Silu(w1 h) then Mul(., w3 h): ml.go:2587-2589, 1877-1914 (llama.go:354-361)
@@ -392,7 +395,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
                     if (a.ys) stream_store_split3(a, col, row, o);
                 }
             } else {
-                for (uint32_t t = tb; t < tb + batch && t < nt; ++t) {
+                for (uint32_t t = tb + egrp; t < tb + batch && t < nt; t += negrp) {
                     f4 s = tile_sum(t - tb);
                     uint32_t g, tile;
                     tile_of(t0 + t, &g, &tile);

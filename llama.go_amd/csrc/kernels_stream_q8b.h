@@ -33,7 +33,9 @@
 //   image per chunk of KC columns:
 //     weights  [MAXT * 16 rows][KC bytes]; 16-byte granule g of row r at position g ^ swz(r) (source-side swizzle: the ds_read_b64 of a
 //              quant block - 16 rows x 2 slots per lane group - touches all 64 banks once)
-//     scales   [MAXT tiles][1 KB]: a tile's 16 rows x KC / 32 floats in the first lanes' slots of one DMA instruction
+//     scales   [MAXT tiles][16 rows][KC / 32] floats, no padding: one DMA instruction per tile with only the first 4 KC / 32 lanes active (EXEC
+//              masked around it: an LDS-DMA writes 16 bytes per ACTIVE lane).  (4-byte DMAs that gather the scales transposed - conflict-free
+//              reads - measured slower: twice the instructions, w2 at 8 rows 16.9 -> 19.3 us, profiles/r05_q8b_probe.txt)
 //     x planes [3][XR rows][KC bf16]; granule g of row r at g ^ (r & 15) (g ^ 2 r with XR = 8); XR = 8 (up to eight token rows) or NCT * 16
 // (Measured and dropped, profiles/r05_q8b_probe.txt: the converting waves fetching their activation pieces and scales straight from global
 // memory into registers, one chunk ahead, with a weights-only ring of up to eight images - w1|w3 of 7B at 8 rows 36.0 us against 27.5:
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows_s3(const float* __restrict
     }
 }
 
-__host__ __device__ constexpr size_t stream_q8b_image_bytes(int maxt, int xr, int kc) { return (size_t)maxt * 16 * kc + (size_t)maxt * 1024 + (size_t)3 * xr * kc * 2; }
+__host__ __device__ constexpr size_t stream_q8b_image_bytes(int maxt, int xr, int kc) { return (size_t)maxt * 16 * kc + (size_t)maxt * (kc / 32) * 64 + (size_t)3 * xr * kc * 2; }
 constexpr int stream_q8b_xr(int nct, uint32_t n) { return (nct == 1 && n <= 8) ? 8 : nct * 16; }
 
 #ifndef Q8B_ABL
@@ -129,7 +131,7 @@ constexpr int Q8B_TH = 1024;
 template <int MAXT, int NCT, int KC, int NIMG, int XR>
 __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
     static_assert(KC == 128 || KC == 256 || KC == 512, "chunk");
-    static_assert(NIMG >= 2 && NIMG <= 4, "ring");
+    static_assert(NIMG >= 2 && NIMG <= 4, "ring");   // (the product launches up to three)
     static_assert(XR == NCT * 16 || (NCT == 1 && XR == 8), "staged activation rows");
     constexpr int NWV = Q8B_TH / 64;            // waves
     constexpr int NB = KC / 32;                 // quant blocks per chunk: 4 / 8 / 16
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
     constexpr int NWI = MAXT * 16 / RPW, NSI = MAXT, NXP = XR / RPX, NXI = 3 * NXP, NI = NWI + NSI + NXI;
     constexpr int NIW = (NI + NWV - 1) / NWV;   // DMA instructions per wave and chunk
     constexpr int WAITN = NIW * (NIMG - 2) < 64 ? NIW * (NIMG - 2) : 63;
-    constexpr uint32_t W_BYTES = MAXT * 16 * KC, S_BYTES = MAXT * 1024, XP_BYTES = XR * KC * 2, IMG_BYTES = W_BYTES + S_BYTES + 3 * XP_BYTES;
+    constexpr uint32_t W_BYTES = MAXT * 16 * KC, S_BYTES = MAXT * NB * 64, XP_BYTES = XR * KC * 2, IMG_BYTES = W_BYTES + S_BYTES + 3 * XP_BYTES;
     constexpr int WSH = KC == 128 ? 1 : 0;      // swz(r) = (r >> WSH) & min(GRW - 1, 15): 128-byte rows alias every second row, longer ones every row
     constexpr uint32_t WMASK = GRW - 1 < 15 ? GRW - 1 : 15;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
     // ---- this wave's DMA instructions of a chunk: piece q = NWV j + wave (weights, the tiles' scales, the three activation planes)
     const char* base[NIW];
     uint32_t voff[NIW], sstep[NIW], doff[NIW];
+    bool narrow[NIW];                                                      // a scale piece (fewer active lanes)
 #pragma unroll
     for (int j = 0; j < NIW; ++j) {
         uint32_t q = (uint32_t)j * NWV + (uint32_t)wave;
@@ -185,6 +188,7 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
             if (scales) return (const char*)((g == 0 ? a.ws[0] : (g == 1 ? a.ws[1] : a.ws[2])) + (size_t)tile * 16 * (a.K / 32) + kbase / 32);
             return (const char*)(g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2])) + (size_t)tile * 16 * a.K + kbase;
         };
+        narrow[j] = q >= (uint32_t)NWI && q < (uint32_t)(NWI + NSI);
         if (q < (uint32_t)NWI) {
             const uint32_t rr = q * RPW + (uint32_t)lane / GRW, gd = (uint32_t)lane % GRW, gs = gd ^ ((rr >> WSH) & WMASK);
             base[j] = tile_base((q * RPW) >> 4, false);
@@ -194,11 +198,11 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
         } else if (q < (uint32_t)(NWI + NSI)) {
             const uint32_t ts = q - NWI;
             constexpr uint32_t LPR = KC / 128;                             // 16-byte pieces per row's scales: 1 / 2 / 4
-            const uint32_t l = (uint32_t)lane & (16u * LPR - 1u);          // the other lanes repeat these into the padding
+            const uint32_t l = (uint32_t)lane & (16u * LPR - 1u);          // (lanes past 16 LPR are masked off when the instruction issues)
             base[j] = tile_base(ts, true);
             voff[j] = ((l / LPR) * (a.K / 32) + (l % LPR) * 4u) * 4u;
             sstep[j] = (KC / 32) * 4;
-            doff[j] = W_BYTES + ts * 1024u;
+            doff[j] = W_BYTES + ts * (NB * 64u);
         } else {
             const uint32_t xq = q - NWI - NSI, p = xq / NXP, xi = xq - p * NXP;
             const uint32_t rr = xi * RPX + (uint32_t)lane / GRX, gd = (uint32_t)lane % GRX, gs = gd ^ xswz(rr);
@@ -216,18 +220,22 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
     typedef int i4v __attribute__((ext_vector_type(4)));
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
     auto issue = [&](uint32_t ch) {
-        const uint32_t cc = ch < nch ? ch : nch - 1;                       // past the end: a harmless reload into a free image (uniform counts)
+        const uint32_t cc = ch;
         const uint32_t im = lds0 + (ch % NIMG) * IMG_BYTES;
 #pragma unroll
         for (int j = 0; j < NIW; ++j) {
             const uint64_t b = (uint64_t)sgpr_ptr(base[j]);
             const i4v rs = {(int)(uint32_t)b, (int)((uint32_t)(b >> 32) & 0xffffu), 0x7fffffff, 0x00020000};   // raw buffer, stride 0 (stream_rsrc's words)
             const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(im + doff[j])), so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cc * sstep[j]));
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(voff[j]), "s"(rs), "s"(so) : "memory", "m0");
+            if (narrow[j] && KC < 512) {   // a tile's scales: 16 KC / 128 active lanes
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %5\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(m0v), "v"(voff[j]), "s"(rs), "s"(so), "s"(KC == 128 ? 0xffffull : 0xffffffffull) : "memory", "m0");
+            } else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(m0v), "v"(voff[j]), "s"(rs), "s"(so) : "memory", "m0");
         }
     };
 #pragma unroll
-    for (int c = 0; c < NIMG - 1; ++c) issue((uint32_t)c);
+    for (int c = 0; c < NIMG - 1; ++c) if ((uint32_t)c < nch) issue((uint32_t)c);
     Q8B_STAMP(1);
     // ---- this wave's share of a chunk: quant block kb for the tiles tg, tg + TG, ...
     const uint32_t kb = (uint32_t)wave % NB, tg = (uint32_t)wave / NB;
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
         uint32_t t = tg + (uint32_t)j * TG;
         t = t < (uint32_t)MAXT ? t : (uint32_t)MAXT - 1;                   // (a slot past the tiles: the last one again, its sums are never stored)
         woff[j] = t * 16 * KC + r16 * KC + (((kb * 2 + (slot >> 1)) ^ ((r16 >> WSH) & WMASK)) * 16) + (slot & 1u) * 8;
-        soff[j] = W_BYTES + t * 1024 + r16 * (KC / 32) * 4 + kb * 4;
+        soff[j] = W_BYTES + t * (NB * 64) + r16 * (NB * 4) + kb * 4;
     }
     uint32_t xoff[NCT];
 #pragma unroll
@@ -261,13 +269,19 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
 #ifdef Q8B_TRACE
         const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
 #endif
-        wait_vm<WAITN>();                       // this wave's pieces of chunk ch have landed; the younger chunks' may still be in flight
+        // this wave's pieces of chunk ch have landed; the younger chunks' (min(NIMG - 2, chunks left) of them) may still be in flight
+        {
+            const uint32_t left = nch - 1 - ch;
+            if (left >= (uint32_t)(NIMG - 2)) wait_vm<WAITN>();
+            else if (NIMG >= 4 && left == 1) wait_vm<(NIW < 64 ? NIW : 63)>();
+            else wait_vm<0>();
+        }
 #ifdef Q8B_TRACE
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
 #endif
         barrier_lds_only();                     // barrier ch: every piece of chunk ch is in its image, and everybody has left chunk ch - 1's ...
-        if ((Q8B_ABL & 16) == 0) issue(ch + NIMG - 1);   // ... which takes chunk ch + NIMG - 1
+        if ((Q8B_ABL & 16) == 0 && ch + NIMG - 1 < nch) issue(ch + NIMG - 1);   // ... which takes chunk ch + NIMG - 1
 #ifdef Q8B_TRACE
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long tc = __builtin_amdgcn_s_memrealtime();
@@ -333,7 +347,6 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
 #ifdef Q8B_TRACE
     tstamp[4] = twait; tstamp[5] = tbar; tstamp[1] = tcomp;
 #endif
-    wait_vm<0>();      // the clamped tail requests
     __syncthreads();   // the images are dead
     Q8B_STAMP(6);
     stream_epilogue<MAXT, NCT, 1, true, NB>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t / TG][c]; });

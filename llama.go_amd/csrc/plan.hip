@@ -783,7 +783,7 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
 // barriers; standalone on 7B 20.2-22.2 us against 23.5); 128 from three column tiles on and where K is not a multiple of 256.
 constexpr int q8b_nimg_fit(int maxt, int xr, int kc) {
     const int n = (int)(160 * 1024 / stream_q8b_image_bytes(maxt, xr, kc));
-    return n < 4 ? n : 4;
+    return n < 3 ? n : 3;   // (a fourth image measured 1-4 % slower on every 7B launch where it fits, profiles/r05_q8b_probe.txt)
 }
 template <int MAXT, int NCT, int KC, int XR>
 static int launch_stream_q8b(lh_ctx* ctx, const StreamArgs& a, const char* name) {
