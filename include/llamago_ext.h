@@ -71,6 +71,9 @@ int llamago_BatchGreedyDecode(llama_batch* b, const uint32_t* const* prompts, co
 void llamago_BatchSetKeepCount(llama_batch* b, uint32_t keep);   /* ModelParams.KeepCount of every pod (see llamago_SetKeepCount) */
 int llamago_BatchPrompt(llama_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t* ids_out);
 int llamago_BatchTick(llama_batch* b, uint32_t* ids_out);
+/* lh_batch_set_sampler on the batch: the following ticks pick every pod's id with SampleTopPTopK (llama.go:455-707) instead of the argmax, every
+ * pod seeded like a solo run; ringSize slots of lastNTokens per pod, empty.  May be called mid-stream (behind llamago_BatchPrompt and ticks). */
+int llamago_BatchSetSampler(llama_batch* b, uint32_t topK, float topP, float temp, float repeatPenalty, uint64_t seed, uint32_t ringSize);
 
 /* ---- [product] pods as pipeline streams over a layer-sharded model ---------------------------- */
 typedef struct llama_pipeline llama_pipeline;

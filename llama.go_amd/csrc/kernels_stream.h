@@ -31,7 +31,7 @@ struct StreamArgs {
     const float* w[3];   // matrices of the group, each [M][K] row-major
     float* y[3];         // outputs, y[g][c * ldy + row]
     const float* r[3];   // optional residuals, same layout as y
-    const float* ws[3];  // block-int8 models (k_stream_mm2<.., true>): w[] are the int8 planes [M][K], ws[] the fp32 scales [M][K / 32]
+    const float* ws[3];  // block-int8 models (k_stream_q8b): w[] are the int8 planes [M][K], ws[] the fp32 scales [M][K / 32]
     const float* x;      // activations [n][K], row c at x + c * ldx
     uint32_t groups, M, K, n, ldx, ldy;
 #if defined(STREAM_TRACE) || defined(Q8B_TRACE)
@@ -440,9 +440,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
 // the memory pipeline accepts at once, the issue blocks, and with one wave per SIMD a blocked wave also stops feeding its matrix
 // core.  Here a loader wave that blocks costs nothing (that is its job) and the MFMA waves never touch global memory.
 // Same image layout, operand mapping and summation structure as k_stream_mm (4 compute waves x k-blocks, wave order in the epilogue).
-// Q8: block-int8 weights (format of kernels_q8.h).  The loader waves fetch 16 quants + their block's scale per 16-byte load and write
-// fl32(d * q) into the image - literally the checker's dequantise-then-fp32 semantics, like k_gemm_q8 - the compute waves see fp32.
-template <int MAXT, int NCT, int KC, bool Q8 = false>
+template <int MAXT, int NCT, int KC>
 #ifndef STREAM_KERNEL_ATTR
 #define STREAM_KERNEL_ATTR           // probe builds: e.g. -DSTREAM_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(4,4)))' for two workgroups per CU
 #endif
@@ -506,7 +504,7 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
         // register sets = chunks in flight.  Two everywhere except the single-tile fp32 launches of <= 16 rows (wo, w2: one 16-row tile per CU,
         // 8 / 16 KB per chunk - too few bytes in flight with two): four there (profiles/r03_stream_sets_in_flight.txt: wo 18.6 -> 17.8 us, w2
         // 42.8 -> 38.4; with more tiles three are flat and four much slower: 144+ registers of rows in flight).  -DSTREAM_NS=n overrides for probes.
-        constexpr int NS = (STREAM_NS == 2 && !Q8 && MAXT == 1 && NCT == 1) ? 4 : STREAM_NS;
+        constexpr int NS = (STREAM_NS == 2 && MAXT == 1 && NCT == 1) ? 4 : STREAM_NS;
         // gamma chunk: fetched with every set (from x itself when the launch has no norm: the count of loads per set stays a constant)
         const float* gp = (a.gamma ? a.gamma : a.x) + kbase + seg * 4;
         const bool norm = a.gamma != nullptr;
@@ -537,97 +535,7 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
                 if (seg == 0) scl[i * RPP + rsub] = (float)(1.0 / sqrt(t / (double)a.K + 1e-5));
             }
         };
-        if constexpr (Q8) {
-            constexpr int GPR = KC / 16;                            // 16-quant groups per row and chunk
-            constexpr int ITEMS = MAXT * 16 * GPR, NQ = (ITEMS + 255) / 256;
-            const signed char* qp[NQ];
-            const float* sp[NQ];
-            uint32_t irow[NQ], igrp[NQ];
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                uint32_t e = (uint32_t)tid + (uint32_t)i * 256;
-                e = e < (uint32_t)ITEMS ? e : (uint32_t)ITEMS - 1;  // surplus threads repeat the last item (same bytes to the same place)
-                irow[i] = e / GPR; igrp[i] = e % GPR;
-                const uint32_t rr = irow[i] < nt * 16 ? irow[i] : nt * 16 - 1;
-                uint32_t g, tile;
-                tile_of(t0 + (rr >> 4), &g, &tile);
-                const uint32_t row = tile * 16 + (rr & 15);
-                const uint64_t qb = (uint64_t)a.w[0] + (g >= 1 ? (uint64_t)a.w[1] - (uint64_t)a.w[0] : 0) + (g == 2 ? (uint64_t)a.w[2] - (uint64_t)a.w[1] : 0);
-                const uint64_t sb = (uint64_t)a.ws[0] + (g >= 1 ? (uint64_t)a.ws[1] - (uint64_t)a.ws[0] : 0) + (g == 2 ? (uint64_t)a.ws[2] - (uint64_t)a.ws[1] : 0);
-                qp[i] = (const signed char*)qb + (size_t)row * a.K + kbase + igrp[i] * 16;
-                sp[i] = (const float*)sb + (size_t)row * (a.K / 32) + kbase / 32 + igrp[i] / 2;
-            }
-            typedef const u4 __attribute__((address_space(1))) gu4;
-            typedef const float __attribute__((address_space(1))) gfl;
-            u4 qs[NS][NQ];
-            float ds[NS][NQ];
-            f4 xs[NS][NX], gs[NS];
-            auto issue = [&](u4 (&qr)[NQ], float (&dr)[NQ], f4 (&xr)[NX], f4& gq, uint32_t ch) {
-                const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
-                gq = *(gf4*)(uintptr_t)(gp + k0);
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) {
-                    qr[i] = __builtin_nontemporal_load((gu4*)(uintptr_t)(qp[i] + k0));
-                    dr[i] = __builtin_nontemporal_load((gfl*)(uintptr_t)(sp[i] + k0 / 32));
-                }
-#pragma unroll
-                for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
-            };
-            auto stash = [&](const u4 (&qr)[NQ], const float (&dr)[NQ], const f4 (&xr)[NX], const f4& gq, float* im) {
-#pragma unroll
-                for (int i = 0; i < NQ; ++i) {
-                    float* dst = im + (size_t)irow[i] * ST_PITCH + igrp[i] * 16;
-                    // fl32(d * q) with q = u - 128, u = the byte with its sign bit flipped: one v_cvt_f32_ubyteN + one fma per value
-                    // (d * u - 128 d is exact before the fma's single rounding, so the result IS fl32(d * q))
-                    const float d = dr[i], nd = __fmul_rn(d, -128.0f);
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const unsigned int pk = qr[i][w] ^ 0x80808080u;
-                        f4 o;
-                        o.x = fmaf(d, (float)(pk & 255u), nd);
-                        o.y = fmaf(d, (float)((pk >> 8) & 255u), nd);
-                        o.z = fmaf(d, (float)((pk >> 16) & 255u), nd);
-                        o.w = fmaf(d, (float)(pk >> 24), nd);
-                        *(f4*)(dst + w * 4) = o;
-                    }
-                }
-                stash_x(xr, gq, im);
-            };
-            constexpr int PER_SET = 2 * NQ + NX + 1;
-            static_assert(PER_SET * (NS - 1) < 64 || STREAM_NS != 2, "vmcnt range");   // (experiment builds with more sets in flight only launch the shapes that fit)
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                issue(qs[q], ds[q], xs[q], gs[q], (uint32_t)q);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            uint32_t ch = 0;
-#ifdef STREAM_TRACE
-            unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-#endif
-            for (; ch + NS <= nch; ch += NS) {
-#pragma unroll
-                for (int q = 0; q < NS; ++q) {
-                    wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
-                    ST_STAMP(0);
-                    stash(qs[q], ds[q], xs[q], gs[q], (q & 1) ? img + IMG : img);
-                    ST_STAMP(1);
-                    issue(qs[q], ds[q], xs[q], gs[q], ch + q + NS);
-                    ST_STAMP(2);
-                    __syncthreads();
-                    ST_STAMP(3);
-                }
-            }
-#ifdef STREAM_TRACE
-            if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
-#endif
-            if (ch < nch) {              // one chunk left (NS = 2), already requested into set 0
-                wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
-                stash(qs[0], ds[0], xs[0], gs[0], img);
-                __syncthreads();
-            }
-            wait_vm<0>();
-            publish_scales();
-        } else {
+        {
         const float* wp[NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
@@ -1082,235 +990,8 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
     stream_epilogue<MAXT, NCT, CS>(a, smem_raw, (uint32_t)(NIMG * IMGF), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_stream_q8 — block-int8 weights (format of kernels_q8.h: int8 plane [M][K] + fp32 scale per 32 columns) on the LDS-DMA structure of
-// k_stream_dma, 3..48 token rows (BASELINE config 4: "dequant-in-LDS + fp32 MFMA").
-// Why a kernel of its own (round 3: 3.55x fewer bytes bought 0-9 % over fp32 at 8..48 rows): k_stream_mm2<.., true> dequantises in the LOADER waves -
-// per value one convert and one fma on the vector ALU of waves that only get issue slots in the gaps of the MFMA wave they share a SIMD with,
-// then a 4-byte LDS write per value - and its chunk is sized in columns, so it carries a quarter of the fp32 chunk's bytes behind the same
-// barrier.  Here the loader waves move the RAW bytes (`buffer_load_dwordx4 ... lds`: int8 rows, their scales, the activation rows; nothing
-// else in their loop) and the chunk is sized in BYTES: 256 (or 128) columns = 256 (128) B per weight row, the 64 (32)-column fp32 chunk's
-// footprint.  The MFMA waves dequantise on the operand-read side, where the matrix pipe leaves the vector ALU idle anyway: a lane's A operand
-// for four MFMAs is ONE dword of the image (4 quants), flipped to unsigned (xor 0x80808080), and  w = fma(d, float(u), -128 d)  - exact
-// before the fma's single rounding, so w IS fl32(d * q), the checker's dequantise-then-fp32 value (v_cvt_f32_ubyteN + v_fma_f32 per
-// value, 9 vector instructions per four MFMAs per row tile at one column tile).
-//   * image per chunk: weights [MAXT * 16 rows][KC bytes], granule = 16 quants = one k-block of a row, stored at position g ^ (row & (KC / 16 - 1))
-//     (source-side swizzle; the dword reads of a k-block are then 2-way conflicted at worst); scales [MAXT tiles][1 KB]: a tile's 16 rows x KC / 32
-//     floats in the first lanes' slots of one DMA instruction, the rest of its KB is padding the idle lanes write duplicates into; activations
-//     [NCT * 16 rows][KC floats] as in k_stream_dma.
-//   * the launch is bound by the matrix pipe from the first row on (4x the MACs per byte of fp32): per 256-column chunk and MFMA wave
-//     4 k-blocks x 4 MAXT NCT MFMAs; w1|w3 of 7B at <= 16 rows: 49 k clocks = 23.5 us at the 2.09 GHz the chip holds under this load.
-// Summation structure, epilogues, tile pairs, K-split pairs, batched rows: k_stream_dma's.  No folded norm.
-__host__ __device__ constexpr size_t stream_q8_image_bytes(int maxt, int nct, int kc) { return (size_t)maxt * 16 * kc + (size_t)maxt * 1024 + (size_t)nct * 16 * kc * 4; }
-
-template <int MAXT, int NCT, int KC, int NIMG>
-__global__ __launch_bounds__(2 * ST_TH) void k_stream_q8(const StreamArgs a) {
-    static_assert(KC == 128 || KC == 256, "chunk");
-    static_assert(NIMG >= 2 && NIMG <= 4, "ring");
-    constexpr int GRW = KC / 16;                // granules (= k-blocks) per weight row
-    constexpr int RPW = 64 / GRW;               // weight rows per DMA instruction: 4 / 8
-    constexpr int GRX = KC / 4;                 // granules per activation row: 64 / 32
-    constexpr int RPX = 64 / GRX;               // activation rows per DMA instruction: 1 / 2
-    constexpr int NWI = MAXT * 16 / RPW, NSI = MAXT, NXI = NCT * 16 / RPX, NI = NWI + NSI + NXI;
-    constexpr int NIW = (NI + 3) / 4;           // DMA instructions per loader wave and chunk (the last wave(s) repeat the final piece: uniform counts)
-    constexpr int WAITN = NIW * (NIMG - 2) < 64 ? NIW * (NIMG - 2) : 63;
-    constexpr uint32_t W_BYTES = MAXT * 16 * KC, S_BYTES = MAXT * 1024, X_BYTES = NCT * 16 * KC * 4, IMG_BYTES = W_BYTES + S_BYTES + X_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
-    const bool pairs = a.epi == ST_EPI_SILU_MUL;
-    const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
-    const uint32_t S = a.ksplit > 1 ? a.ksplit : 1u, bg = (uint32_t)blockIdx.x / S, ks = (uint32_t)blockIdx.x - bg * S, ng = (uint32_t)gridDim.x / S;
-    if (bg >= ng) return;
-    const uint32_t t0 = um * (uint32_t)(((uint64_t)bg * units) / ng), t1 = um * (uint32_t)(((uint64_t)(bg + 1) * units) / ng);
-    if (t1 <= t0) return;
-    const uint32_t nt = t1 - t0;
-    const uint32_t nch_all = a.K / KC, ch0 = (uint32_t)(((uint64_t)ks * nch_all) / S);
-    const uint32_t nch = (uint32_t)(((uint64_t)(ks + 1) * nch_all) / S) - ch0;
-    const uint32_t kbase = ch0 * KC;
-    if (nch == 0) return;
-    const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
-    constexpr int KB = KC / 64;                 // k-blocks per MFMA wave and chunk
-    f4m acc[MAXT][NCT];
-    if (wave < 4) {
-        // ---- loader waves: piece q = 4 j + wave of the chunk (weights, then the tiles' scales, then activations), one DMA instruction each
-        const char* base[NIW];
-        uint32_t voff[NIW], sstep[NIW], doff[NIW];
-#pragma unroll
-        for (int j = 0; j < NIW; ++j) {
-            uint32_t q = (uint32_t)j * 4 + (uint32_t)wave;
-            q = q < (uint32_t)NI ? q : (uint32_t)NI - 1;                   // surplus slots repeat the last piece (same bytes to the same place)
-            auto tile_base = [&](uint32_t ts, bool scales) -> const char* {   // first row of the tile in slot ts of this workgroup
-                ts = ts < nt ? ts : nt - 1;
-                const uint32_t v = t0 + ts;
-                uint32_t g, tile;
-                if (pairs) { g = v & 1u; tile = v >> 1; }
-                else { g = v / tiles_per_mat; tile = v - g * tiles_per_mat; }
-                if (scales) return (const char*)((g == 0 ? a.ws[0] : (g == 1 ? a.ws[1] : a.ws[2])) + (size_t)tile * 16 * (a.K / 32) + kbase / 32);
-                return (const char*)(g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2])) + (size_t)tile * 16 * a.K + kbase;
-            };
-            if (q < (uint32_t)NWI) {
-                const uint32_t rr = q * RPW + (uint32_t)lane / GRW, gd = (uint32_t)lane % GRW, gs = gd ^ (rr & (uint32_t)(GRW - 1));
-                base[j] = tile_base((q * RPW) >> 4, false);
-                voff[j] = (rr & 15u) * a.K + gs * 16u;
-                sstep[j] = KC;
-                doff[j] = q * 1024u;
-            } else if (q < (uint32_t)(NWI + NSI)) {
-                const uint32_t ts = q - NWI;
-                constexpr uint32_t LPR = KC / 128;                         // lanes (16-byte pieces) per row's scales: 2 / 1
-                const uint32_t l = (uint32_t)lane & (16u * LPR - 1u);      // the other lanes repeat these into the padding
-                base[j] = tile_base(ts, true);
-                voff[j] = ((l / LPR) * (a.K / 32) + (l % LPR) * 4u) * 4u;
-                sstep[j] = (KC / 32) * 4;
-                doff[j] = W_BYTES + ts * 1024u;
-            } else {
-                const uint32_t xq = q - NWI - NSI;
-                const uint32_t rr = xq * RPX + (uint32_t)lane / GRX, gd = (uint32_t)lane % GRX, gs = gd ^ (rr & 15u);
-                const uint32_t c = rr < a.n ? rr : a.n - 1;
-                base[j] = (const char*)(a.x + kbase);
-                voff[j] = (c * a.ldx + gs * 4u) * 4u;
-                sstep[j] = KC * 4;
-                doff[j] = W_BYTES + S_BYTES + xq * 1024u;
-            }
-        }
-        auto issue = [&](uint32_t ch) {
-            const uint32_t cc = ch < nch ? ch : nch - 1;
-            char* im = smem_raw + (size_t)(ch % NIMG) * IMG_BYTES;
-#pragma unroll
-            for (int j = 0; j < NIW; ++j) {
-                const __amdgpu_buffer_rsrc_t rs = stream_rsrc(base[j]);
-                __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(im + doff[j]);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, (int)voff[j], (int)(cc * sstep[j]), 0, 0);
-            }
-        };
-#pragma unroll
-        for (int c = 0; c < NIMG - 1; ++c) issue((uint32_t)c);
-        for (uint32_t ch = 0; ch < nch; ++ch) {
-            wait_vm<WAITN>();
-            __builtin_amdgcn_s_barrier();
-            issue(ch + NIMG - 1);
-        }
-        __builtin_amdgcn_s_barrier();           // the MFMA waves' barrier in front of their last k-block (their pipeline looks one k-block ahead)
-        wait_vm<0>();
-    } else {
-        // ---- MFMA waves: dequantise on the operand-read side.  Software pipeline over the k-blocks of a chunk: while k-block h multiplies, the
-        // raw quants and scales of k-block h + 1 (requested in front of it) are converted - sched_group_barrier pins the interleave, a few
-        // vector instructions behind every MFMA; left to itself the compiler converts a whole k-block and only then starts its MFMAs, and the
-        // matrix pipe idles through every conversion (measured: 51 us instead of 31 for w1|w3 of 7B at <= 16 rows).
-        const int cw = wave - 4;
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[t][c] = f4m{0.f, 0.f, 0.f, 0.f};
-        f4 af[2][MAXT], bf[2][NCT];
-        unsigned int raw[MAXT];
-        float d[MAXT];
-        auto load_ops = [&](const char* im, int h, f4 (&b)[NCT]) {
-            const uint32_t kbc = (uint32_t)(KB * cw + h);               // k-block of the chunk
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) b[c] = *(const f4*)(im + W_BYTES + S_BYTES + ((size_t)(c * 16 + r16) * GRX + ((kbc * 4 + slot) ^ r16)) * 16);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                raw[t] = *(const unsigned int*)(im + (size_t)(t * 16 + r16) * KC + (kbc ^ (r16 & (uint32_t)(GRW - 1))) * 16 + slot * 4);
-                d[t] = *(const float*)(im + W_BYTES + (size_t)t * 1024 + r16 * (KC / 32) * 4 + (kbc >> 1) * 4);
-            }
-        };
-#ifndef Q8_ABL
-#define Q8_ABL 0   // tools/stream_mm_check timing-only builds: 1 = no conversion (the raw dword's bits as the operand), 2 = no MFMAs, 4 = no operand reads after the first
-#endif
-        auto dequant = [&](f4 (&a4)[MAXT]) {
-            if constexpr ((Q8_ABL & 1) != 0) {
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) { const float fv = __builtin_bit_cast(float, raw[t]); a4[t] = f4{fv, d[t], fv, d[t]}; }
-                return;
-            }
-#ifndef Q8_CVT
-#define Q8_CVT 3   // 0: unsigned convert + fma (k_stream_mm2's form), 1: sign-extending convert (SDWA byte select) + multiply, 2: byte permute into 2^23 + u, subtract, fma, 3: form 1 with packed multiplies
-#endif
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                if constexpr (Q8_CVT == 1) {
-                    // (float)q is exact, d * (float)q rounds once: fl32(d * q), the checker's dequantised weight; 2 vector instructions per value
-                    const int dq = (int)raw[t];
-                    a4[t].x = __fmul_rn(d[t], (float)(int)(signed char)(dq));
-                    a4[t].y = __fmul_rn(d[t], (float)(int)(signed char)(dq >> 8));
-                    a4[t].z = __fmul_rn(d[t], (float)(int)(signed char)(dq >> 16));
-                    a4[t].w = __fmul_rn(d[t], (float)(dq >> 24));
-                } else if constexpr (Q8_CVT == 3) {
-                    // the same values with the four multiplies as two v_pk_mul_f32 (scale broadcast to both halves; IEEE multiply per half: the same bits)
-                    const int dq = (int)raw[t];
-                    const f2 dd = f2{d[t], d[t]};
-                    const f2 lo = f2{(float)(int)(signed char)(dq), (float)(int)(signed char)(dq >> 8)} * dd;
-                    const f2 hi = f2{(float)(int)(signed char)(dq >> 16), (float)(dq >> 24)} * dd;
-                    a4[t] = f4{lo.x, lo.y, hi.x, hi.y};
-                } else if constexpr (Q8_CVT == 2) {
-                    // 0x4B000000 | u = 2^23 + u as a float (one byte permute), minus 2^23 + 128 = q exactly, then the one rounding multiply
-                    const unsigned int pk = raw[t] ^ 0x80808080u;
-                    const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c00u)) - 8388736.0f;
-                    const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c01u)) - 8388736.0f;
-                    const float q2 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c02u)) - 8388736.0f;
-                    const float q3 = __builtin_bit_cast(float, __builtin_amdgcn_perm(0x4B000000u, pk, 0x07060c03u)) - 8388736.0f;
-                    a4[t].x = __fmul_rn(d[t], q0); a4[t].y = __fmul_rn(d[t], q1); a4[t].z = __fmul_rn(d[t], q2); a4[t].w = __fmul_rn(d[t], q3);
-                } else {
-                    const unsigned int pk = raw[t] ^ 0x80808080u;
-                    const float nd = __fmul_rn(d[t], -128.0f);
-                    a4[t].x = fmaf(d[t], (float)(pk & 255u), nd);
-                    a4[t].y = fmaf(d[t], (float)((pk >> 8) & 255u), nd);
-                    a4[t].z = fmaf(d[t], (float)((pk >> 16) & 255u), nd);
-                    a4[t].w = fmaf(d[t], (float)(pk >> 24), nd);
-                }
-            }
-        };
-        auto mfmas = [&](const f4 (&a4)[MAXT], const f4 (&b)[NCT]) {
-            if constexpr ((Q8_ABL & 2) != 0) {   // keep the operands alive, multiply nothing
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) asm volatile("" :: "v"(a4[t].x), "v"(a4[t].y), "v"(a4[t].z), "v"(a4[t].w));
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) asm volatile("" :: "v"(b[c].x), "v"(b[c].y), "v"(b[c].z), "v"(b[c].w));
-                return;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-                    for (int c = 0; c < NCT; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t][s], b[c][s], acc[t][c], 0, 0, 0);
-        };
-        constexpr int NM = 4 * MAXT * NCT, NV = (Q8_CVT == 1 ? 8 : Q8_CVT == 2 ? 13 : Q8_CVT == 3 ? 6 : 10) * MAXT, VPM = (NV + NM - 1) / NM;   // MFMAs of a k-block, vector instructions of one conversion, of them behind each MFMA
-        static_assert(KB % 2 == 0, "the two operand sets alternate by k-block parity across chunks");
-        // The pipeline runs ACROSS chunks: the step behind the last k-block of chunk ch is the first of chunk ch + 1, so barrier ch + 1 stands
-        // in front of that k-block's MFMAs (its operands are in registers by then: the image of chunk ch is not read any more).
-        barrier_lds_only();                     // barrier 0
-        load_ops(smem_raw, 0, bf[0]);
-        dequant(af[0]);
-        for (uint32_t ch = 0; ch < nch; ++ch) {
-            const char* im = smem_raw + (size_t)(ch % NIMG) * IMG_BYTES;
-#pragma unroll
-            for (int h = 0; h < KB; ++h) {
-                // straight-line, no condition on the chunk index (a branch splits the block and the interleave with it): behind the LAST chunk
-                // the step reads and converts whatever the ring's next image holds (the loader's clamped tail request) - never multiplied
-                __builtin_amdgcn_sched_barrier(0);
-                if (h + 1 < KB) load_ops(im, h + 1, bf[(h + 1) & 1]);
-                else {
-                    barrier_lds_only();         // barrier ch + 1: the next chunk is in its image (and the loader may refill chunk ch's)
-                    load_ops(smem_raw + (size_t)((ch + 1) % NIMG) * IMG_BYTES, 0, bf[0]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(af[h & 1], bf[h & 1]);
-                dequant(af[(h + 1) & 1]);
-#pragma unroll
-                for (int i = 0; i < NM; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();
-    stream_epilogue<MAXT, NCT>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
-}
+// (Block-int8 weights ran on this structure as k_stream_q8 in round 4 - fp32-input MFMAs behind a vector-ALU dequantisation; round 5 replaced
+// it by k_stream_q8b, kernels_stream_q8b.h: the bf16 matrix pipe through a lossless split of the activations, 2x faster standalone.)
 
 // Second half of a K-split launch: token row b of  y = resid + ((p_0 + p_1) + ...) + p_{S-1}  (fixed order: bit-reproducible; Add
 // ml.go:2515-2584), and - gamma != nullptr - the RMSNorm * weight of that row for the next matmul into h (ml.go:1753-1812, 1877-1914: fp32

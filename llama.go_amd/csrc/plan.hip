@@ -386,17 +386,10 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
     return 0;
 }
 
-static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
-                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const lh::StreamArgs* fused, const float* const* wsc);
-
-// block-int8 weights, N >= 32: dequantising MFMA GEMM (k_gemm_q8), 128 x 128 tiles, persistent one workgroup per CU
+// block-int8 weights, prompts beyond the 64 rows of k_stream_q8b (and shapes it is not built for): dequantising MFMA GEMM (k_gemm_q8), persistent one workgroup per CU
 static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* wq, const float* const* wsc, float* const* y,
                          const float* const* r, uint32_t M, uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
     if (K % GBK || ldx % 4 || ((uintptr_t)x & 15)) LH_FAIL(ctx, LH_ESHAPE, "gemm_q8 %s: K=%u / ldx=%u / X alignment not supported", name, K, ldx);
-    {   // up to 32 rows: the streaming MFMA kernel with dequantising loader waves (kernels_stream.h)
-        const int rs = gemm_stream_group(ctx, x, ldx, groups, wq, y, r, M, K, n, ldy, name, nullptr, wsc);
-        if (rs != ST_NA) return rs;
-    }
     GemmArgs a = {};
     a.x = x; a.groups = groups; a.N = n; a.M = M; a.K = K; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) { a.w[g] = wq[g]; a.ws[g] = wsc[g]; a.y[g] = y[g]; a.r[g] = r ? r[g] : nullptr; }
@@ -562,25 +555,22 @@ static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
 
 template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    static bool flags[3][16] = {};
+    static bool flags[2][16] = {};
     // wave-specialised variant (loader waves + MFMA waves, two LDS images) whenever the two images fit, else the first variant (every
-    // wave loads and computes).  Block-int8 weights (a.ws set) exist in the specialised variant only.
-    const bool q8 = a.ws[0] != nullptr;
+    // wave loads and computes)
+    if (a.ws[0]) return ST_NA;   // (block-int8: k_stream_q8b)
     const bool v2 = stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
-    if ((q8 || a.gamma || a.ksplit > 1 || NCT > 2 || a.rows) && !v2) return ST_NA;   // block-int8, folded norm, K-split, 3 / 4 column tiles, batched rows: specialised variant only
-    if (q8 && NCT > 3) return ST_NA;
+    if ((a.gamma || a.ksplit > 1 || NCT > 2 || a.rows) && !v2) return ST_NA;   // folded norm, K-split, 3 / 4 column tiles, batched rows: specialised variant only
     const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     constexpr int KC2 = KC <= 256 ? KC : 256;
     const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
     // instantiations outside a variant's range are never launched (returned above); the clamps only keep them from being compiled
-    constexpr int NCT1 = NCT <= 2 ? NCT : 2, KC1 = KC >= 128 ? KC : 128, NCTQ = NCT <= 3 ? NCT : 3, KCQ = KC2 >= 128 ? KC2 : 128;
-    int rc = q8 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCTQ, KCQ, true>, lds, flags[2])
-                : v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2, false>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT1, KC1>, lds, flags[0]);
+    constexpr int NCT1 = NCT <= 2 ? NCT : 2, KC1 = KC >= 128 ? KC : 128;
+    int rc = v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT1, KC1>, lds, flags[0]);
     if (rc) return rc;
     if (g_prepare_only) return 0;
-    ProfScope ps(ctx->stream, name, q8 ? (uint64_t)a.groups * a.M * a.K / 32 * 36 : (uint64_t)a.groups * a.M * a.K * 4);
-    if (q8) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCTQ, KCQ, true>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
-    else if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2, false>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
+    ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
+    if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT1, KC1>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -612,38 +602,6 @@ static int launch_stream_dma(lh_ctx* ctx, const StreamArgs& a, const char* name)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
-}
-// ---- k_stream_q8 (kernels_stream.h): block-int8 weights on the LDS-DMA structure, dequantised by the MFMA waves.  Chunk = 256 columns where
-// three images fit, else 128 (LLAMAHIP_Q8_KC overrides for A/B runs).
-constexpr int q8_nimg_fit(int maxt, int nct, int kc) {
-    const int n = (int)(160 * 1024 / stream_q8_image_bytes(maxt, nct, kc));
-    return n < 4 ? n : 4;
-}
-template <int MAXT, int NCT, int KC, int NIMG>
-static int launch_stream_q8(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    static_assert(NIMG >= 2, "ring");
-    static bool flags[16] = {};
-    auto kern = k_stream_q8<MAXT, NCT, KC, NIMG>;
-    const size_t lds = std::max<size_t>((size_t)NIMG * stream_q8_image_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
-    int rc = set_lds_once(ctx, kern, lds, flags);
-    if (rc) return rc;
-    if (g_prepare_only) return 0;
-    const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
-    ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K / 32 * 36);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
-    LH_HIP(ctx, hipGetLastError());
-    return 0;
-}
-template <int MAXT, int NCT>
-static int launch_stream_q8_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    static int kc_env = -1;
-    if (kc_env < 0) { const char* e = getenv("LLAMAHIP_Q8_KC"); kc_env = e ? atoi(e) : 0; }
-    constexpr int N256 = q8_nimg_fit(MAXT, NCT, 256), N128 = q8_nimg_fit(MAXT, NCT, 128);
-    static_assert(N128 >= 2, "two images of 128-column chunks fit every built shape");
-    if constexpr (N256 >= 2) {
-        if ((kc_env == 256 || (kc_env == 0 && N256 >= 3)) && a.K % 256 == 0) return launch_stream_q8<MAXT, NCT, 256, N256>(ctx, a, name);
-    }
-    return launch_stream_q8<MAXT, NCT, 128, N128>(ctx, a, name);
 }
 // variants: 0 = 64-column chunks, as many images as fit (<= 4); 2 = 128-column chunks, two images; 1 / 3 = the same with pipelined operands
 // (measured round 4, profiles/r04_stream_dma_variants.txt: the operand pipeline buys nothing on two to six column tiles - the LDS
@@ -686,9 +644,6 @@ static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name)
         const int ve = stream_dma_variant_env();
         if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
     }
-    if constexpr (NCT <= 3 || (NCT == 4 && MAXT <= 6)) {   // block-int8, up to 64 rows (eight row tiles: 48; their 8 x 4 tiles + two operand sets would spill): raw bytes by LDS-DMA, dequantised by the MFMA waves (no folded norm: the host runs the norm's own launch)
-        if (a.ws[0] && !a.gamma && !a.tiled && stream_dma_variant_env() != -1) return launch_stream_q8_kc<MAXT, NCT>(ctx, a, name);
-    }
     if constexpr (NCT > 6) return ST_NA;   // (k_stream_mm2 holds MAXT x NCT accumulator tiles per wave: up to six column tiles)
     else return launch_stream_kc<MAXT, NCT>(ctx, a, name);
 }
@@ -718,8 +673,8 @@ static int launch_stream_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name
 }
 // returns ST_NA when the shape is not one the kernel is built for (the caller then takes the tile GEMM)
 static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* w, float* const* y, const float* const* r, uint32_t M,
-                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr, const float* const* wsc = nullptr) {
-    if (n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return ST_NA;
+                             uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr) {
+    if (n > stream_max_rows() || groups > 3 || M % 16 || K % 128 || ldx % 4 || ldy % 4 || ((uintptr_t)x & 15)) return ST_NA;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, T = M / 16 * groups;
     // ST_EPI_SILU_MUL deals (w1, w3) tile pairs: twice the pairs' ceiling
     const uint32_t maxt = (fused && fused->epi == ST_EPI_SILU_MUL) ? 2 * ((M / 16 + ncu - 1) / ncu) : (T + ncu - 1) / ncu;
@@ -733,8 +688,8 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
     if (fused) a = *fused;
     a.x = x; a.groups = groups; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = ldy;
     for (uint32_t g = 0; g < groups; ++g) {
-        a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr; a.ws[g] = wsc ? wsc[g] : nullptr;
-        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || (a.ws[g] && ((uintptr_t)a.ws[g] & 3))) return ST_NA;
+        a.w[g] = w[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr;
+        if (((uintptr_t)w[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15))) return ST_NA;
     }
     return launch_stream_maxt(ctx, a, name, maxt);
 }
@@ -744,13 +699,13 @@ static int gemm_stream_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t
 // writes the RMSNorm * gamma rows the NEXT matmul reads - it stands where that norm's launch stood.  Standalone, 32 rows (tools/
 // stream_mm_check, profiles/r02d_stream_ksplit.txt): w2 55.6 -> 45.6 us, wo 23.9 -> 22.0 us; at 16 rows nothing (37.7 -> 37.0, 17.9 -> 21.1).
 // returns ST_NA when not applicable (the caller takes the one-launch path).
-static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, const float* x, uint32_t ldx, uint32_t M, uint32_t K, uint32_t n, const float* resid,
+static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* x, uint32_t ldx, uint32_t M, uint32_t K, uint32_t n, const float* resid,
                              float* y, const float* gamma, float* h, const char* name) {
     // pairs: four-way splits measured no better, standalone (w2 at 32 / 48 rows: 45.6 / 62.2 us in pairs, 47.6 / 60.6 in fours, + a longer
     // reduce pass) and in the model (40 / 48 tokens: 8.94 / 9.01 ms vs 9.08 / 9.24)
     const uint32_t S = 2u;
-    if (n <= 16 || n > stream_max_rows() || (wsc && n > STREAM_ROWS_Q8) || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return ST_NA;
-    if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15) || ((uintptr_t)wsc & 3)) return ST_NA;
+    if (n <= 16 || n > stream_max_rows() || M % 16 || M > 8192 || K % 128 || K / 128 < 4 * S || ldx % 4) return ST_NA;
+    if ((((uintptr_t)w | (uintptr_t)x | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h) & 15)) return ST_NA;
     const uint32_t ncu = (uint32_t)ctx->ds->num_cu, ngrp = ncu / S;
     if (ngrp == 0) return ST_NA;
     const uint32_t maxt = (M / 16 + ngrp - 1) / ngrp;
@@ -766,7 +721,7 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* wsc, cons
         ctx->splitk_floats = need;
     }
     StreamArgs a = {};
-    a.x = x; a.groups = 1; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = M; a.w[0] = w; a.ws[0] = wsc; a.y[0] = ctx->splitk;
+    a.x = x; a.groups = 1; a.M = M; a.K = K; a.n = n; a.ldx = ldx; a.ldy = M; a.w[0] = w; a.y[0] = ctx->splitk;
     a.ksplit = S; a.ysplit = (uint64_t)n * M;
     const int rs = launch_stream_maxt(ctx, a, name, maxt);
     if (rs) return rs;
@@ -1408,10 +1363,17 @@ int plan_decode_step(Plan* p, uint32_t token, uint32_t past) {
 // reads the row table (k_stream_mm2's RoPE epilogue, k_rope_store, k_attention, k_attention_split).  Routes that do not (k_skinny, the
 // tile GEMM's RoPE epilogue above 64 rows, the flash kernel, block-int8 single-token steps) are excluded here; lh_batch then evaluates
 // the rows one after the other on their own plans.
+// block-int8 on k_stream_q8b: the shapes every launch of an Eval has an instantiation for (kernels_stream_q8b.h; <= 8 row tiles per workgroup
+// in each of wq|wk|wv, w1|w3 pairs, the K-split fours of wo / w2 and the output matrix)
+static bool q8b_shape_ok(lh_ctx* ctx, const ModelDesc& m) {
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, d = m.d, F = m.F;
+    if (m.wtype != 7 || ncu < 4 || d > 8192 || d % 128 || F % 128 || m.hd % 4 || d % m.hd) return false;
+    if ((3 * d / 16 + ncu - 1) / ncu > 8 || 2 * ((F / 16 + ncu - 1) / ncu) > 8 || (d / 16 + ncu / 4 - 1) / (ncu / 4) > 8) return false;
+    if (m.last_stage() && (m.V % 16 || (m.V / 16 + ncu - 1) / ncu > 8)) return false;
+    return true;
+}
 static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n_min) {
-    const uint32_t ncu = (uint32_t)ctx->ds->num_cu;
-    return m.wtype == 7 && n >= n_min && n <= std::min(stream_max_rows(), STREAM_ROWS_Q8) && m.d % 128 == 0 && m.F % 128 == 0 && m.hd % 32 == 0 &&
-           (3 * m.d / 16 + ncu - 1) / ncu <= 8 && 2 * ((m.F / 16 + ncu - 1) / ncu) <= 8;
+    return n >= n_min && n <= STREAM_ROWS_Q8 && q8b_shape_ok(ctx, m);
 }
 bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     const ModelDesc& m = p->md;
@@ -1432,14 +1394,8 @@ bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
 static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n, uint32_t past, bool last_row_only, const BatchCtx* bc) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
-    const uint32_t d = m.d, F = m.F, ncu = (uint32_t)ctx->ds->num_cu;
-    if (d > 8192 || d % 128 || F % 128 || (3 * d / 16 + ncu - 1) / ncu > 8 || 2 * ((F / 16 + ncu - 1) / ncu) > 8 || (d / 16 + ncu / 4 - 1) / (ncu / 4) > 8 || ncu < 4) return ST_NA;
-    if (m.last_stage() && (m.V % 16 || (m.V / 16 + ncu - 1) / ncu > 8)) return ST_NA;
-    for (uint32_t il = m.layer0; il < m.layer1; ++il) {
-        const LayerW& L = m.layers[il];
-        const float* sc[] = {L.s_wq, L.s_wk, L.s_wv, L.s_wo, L.s_w1, L.s_w2, L.s_w3};
-        for (const float* q : sc) if (!q || ((uintptr_t)q & 15)) return ST_NA;
-    }
+    const uint32_t d = m.d, F = m.F;
+    if (!q8b_shape_ok(ctx, m)) return ST_NA;
     const BatchRow* rows = bc ? bc->rows : nullptr;
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
     const uint64_t pd = (uint64_t)p->n_cap * d, pf = (uint64_t)p->n_cap * F;   // plane strides (elements)
@@ -1702,9 +1658,10 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
     }
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
     const uint32_t d = m.d, F = m.F;
-    if (q8_stream && p->s3) {
+    if (q8_stream) {   // block-int8, up to 64 rows: the bf16 matrix pipe (kernels_stream_q8b.h)
         const int rs = eval_q8b_layers(p, x, x_out_dev, n, past, last_row_only, bc);
-        if (rs != ST_NA) return rs;
+        if (rs == ST_NA) LH_FAIL(ctx, LH_ESHAPE, "block-int8 Eval of %u rows: the plan's shape has no k_stream_q8b launch", n);
+        return rs;
     }
     bool h_ready = false;   // p->h already holds this layer's RMSNorm * attn_norm rows (written by the previous layer's w2 reduce pass)
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
@@ -1714,7 +1671,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const bool q8 = m.wtype == 7;
         bool qkv_roped = false, gated = false;
         // 17..64 rows: wo / w2 as K-split pairs whose reduce pass also writes the next norm's rows into p->h (gemm_stream_split)
-        const bool ksp = n > 16 && n <= stream_max_rows() && (q8 ? q8_stream : mfma);
+        const bool ksp = n > 16 && n <= stream_max_rows() && !q8 && mfma;
         bool hf_ready = false;
         const float* wqkv[3] = {L.wq, L.wk, L.wv};
         const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
@@ -1723,24 +1680,21 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         StreamArgs fq = {};
         fq.epi = ST_EPI_QKV_ROPE; fq.q_out = p->q; fq.k_cache = m.kc + slot; fq.v_cache = m.vc + slot; fq.rope = rope; fq.hd = m.hd; fq.past = past;
         fq.rows = rows; fq.kv_off = slot;
-        const bool fold_norm = n <= 16 && (q8 ? stream_dma_variant_env() == -1 : mfma);   // (block-int8: k_stream_q8 moves raw bytes - the norm keeps its own launch)
+        const bool fold_norm = n <= 16 && !q8 && mfma;
         if (n <= stream_max_rows() && fold_norm) {
             // short prompts: ONE launch for RMSNorm (folded: gamma at staging, the per-token scale in the epilogue) -> wq|wk|wv -> RoPE -> cache append
             // (folded up to 16 rows: -3..5 % per Eval; at 17..32 rows the extra staging work of the loader waves eats the saved launch)
             StreamArgs fa = fq;
             fa.gamma = L.attn_norm;
-            const int rs = gemm_stream_group(ctx, x, d, 3, wqkv, nullptr, nullptr, d, d, n, d, q8 ? "stream_q8_norm_wqkv_rope" : "stream_norm_wqkv_rope", &fa, q8 ? sqkv : nullptr);
+            const int rs = gemm_stream_group(ctx, x, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_norm_wqkv_rope", &fa);
             if (rs < 0) return rs;
             qkv_roped = rs == 0;
         }
         if (!qkv_roped && !h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
         h_ready = false;
         if (qkv_roped) {
-        } else if (q8) {
-            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_q8_wqkv_rope", &fq, sqkv) : ST_NA;
-            if (rs < 0) return rs;
-            qkv_roped = rs == 0;
-            if (!qkv_roped && (rc = gemm_q8_group(ctx, p->h, d, 3, wqkv, sqkv, yqkv, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
+        } else if (q8) {   // (prompts beyond k_stream_q8b's 64 rows)
+            if ((rc = gemm_q8_group(ctx, p->h, d, 3, wqkv, sqkv, yqkv, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
         } else if (mfma) {
             int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fq) : ST_NA;
             if (rs == ST_NA && n > 64) {   // long prompts: the same epilogue in the tile GEMM
@@ -1774,7 +1728,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         int wo_rs = ST_NA;
         if (ksp) {
-            wo_rs = gemm_stream_split(ctx, L.wo, q8 ? L.s_wo : nullptr, p->attn, d, d, d, n, x, p->xb, L.ffn_norm, p->h, q8 ? "stream_q8_wo_ksplit" : "stream_wo_ksplit");
+            wo_rs = gemm_stream_split(ctx, L.wo, p->attn, d, d, d, n, x, p->xb, L.ffn_norm, p->h, "stream_wo_ksplit");
             if (wo_rs < 0) return wo_rs;
             hf_ready = wo_rs == 0;
         }
@@ -1789,19 +1743,14 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL;
             fa.gamma = L.ffn_norm;
-            const int rs = gemm_stream_group(ctx, p->xb, d, 2, w13, yg, nullptr, F, d, n, F, q8 ? "stream_q8_norm_w1w3_silu" : "stream_norm_w1w3_silu", &fa, q8 ? s13 : nullptr);
+            const int rs = gemm_stream_group(ctx, p->xb, d, 2, w13, yg, nullptr, F, d, n, F, "stream_norm_w1w3_silu", &fa);
             if (rs < 0) return rs;
             gated = rs == 0;
         }
         if (!gated && !hf_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
         if (gated) {
         } else if (q8) {
-            StreamArgs fa = {};
-            fa.epi = ST_EPI_SILU_MUL;
-            const int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_q8_w1w3_silu", &fa, s13) : ST_NA;
-            if (rs < 0) return rs;
-            gated = rs == 0;
-            if (!gated && (rc = gemm_q8_group(ctx, p->h, d, 2, w13, s13, y13, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
+            if ((rc = gemm_q8_group(ctx, p->h, d, 2, w13, s13, y13, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
         } else if (mfma) {
             StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
             fa.epi = ST_EPI_SILU_MUL;
@@ -1825,7 +1774,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         int w2_rs = ST_NA;
         if (ksp) {
             const float* next_gamma = last ? nullptr : m.layers[il + 1].attn_norm;   // the next layer's first norm rides on the reduce pass
-            w2_rs = gemm_stream_split(ctx, L.w2, q8 ? L.s_w2 : nullptr, p->g, F, d, F, n, p->xb, y, next_gamma, p->h, q8 ? "stream_q8_w2_ksplit" : "stream_w2_ksplit");
+            w2_rs = gemm_stream_split(ctx, L.w2, p->g, F, d, F, n, p->xb, y, next_gamma, p->h, "stream_w2_ksplit");
             if (w2_rs < 0) return w2_rs;
             h_ready = w2_rs == 0 && next_gamma != nullptr;
         }
@@ -1841,14 +1790,10 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
         { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(nr), dim3(256), 0, ctx->stream, x + (size_t)r0 * d, m.norm, p->h + (size_t)r0 * d, d); }
         if (m.wtype == 7) {
-            if (nr >= 32) {
+            if (nr >= Q8_GEMM_MIN_ROWS) {
                 if ((rc = gemm_q8(ctx, m.output, m.s_output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_q8_lmhead"))) return rc;
-            } else {
-                // a few rows: one launch of the stream kernel's dequantising loader when the shape allows, else the int8 GEMV row by row
-                const float* wv = m.output; const float* sv = m.s_output; float* yv = p->logits + (size_t)r0 * m.V;
-                const int rs = nr >= 2 ? gemm_stream_group(ctx, p->h + (size_t)r0 * d, d, 1, &wv, &yv, nullptr, m.V, d, nr, m.V, "stream_q8_lmhead", nullptr, &sv) : ST_NA;
-                if (rs < 0) return rs;
-                for (uint32_t i = 0; i < nr && rs == ST_NA; ++i) {
+            } else {   // a few rows (the last row of a long prompt): the int8 GEMV row by row
+                for (uint32_t i = 0; i < nr; ++i) {
                     GemvArgs ga = {};
                     ga.w[0] = m.output; ga.ws[0] = m.s_output; ga.M = m.V; ga.K = d; ga.x = p->h + (size_t)(r0 + i) * d; ga.y = p->logits + (size_t)(r0 + i) * m.V;
                     if ((rc = gemv<PRO_PLAIN, EPI_STORE, MAP_SINGLE>(ctx, ga, "gemv_lmhead_row", 7))) return rc;
@@ -2416,7 +2361,17 @@ int lh_batch_set_sampler(lh_batch* h, const lh_sample_params* sp, uint32_t ring_
     }
     LH_HIP(ctx, hipMemcpy(b->ring_dev, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
     LH_HIP(ctx, hipMemcpy(b->ss_dev, st.data(), sizeof(SampleState) * b->B, hipMemcpyHostToDevice));
-    // the rows' output lists restart (.step = index into them); token ids and positions stay what lh_batch_set / lh_batch_prompt / the ticks made them
+    // the rows' output lists restart (.step = index into them); token ids and positions stay what lh_batch_set / lh_batch_prompt / the ticks made
+    // them.  The HOST mirror restarts with them: what the ticks so far produced is read first (the histories of the context swap and
+    // each row's pending token), then the mirror is re-based on "tick 0 evaluates the pending token and writes entry 0" - the call may come
+    // mid-stream, behind a prompt and any number of ticks.
+    if (b->step0 + b->ticks > 0) {
+        if ((rc = batch_drain(b))) return rc;
+        b->pos_set = b->pos;
+        b->tok0 = b->pending;
+        b->tok0_known = true;
+        b->step0 = 0; b->ticks = 0; b->drained = 0;
+    }
     hipLaunchKernelGGL(k_batch_reset_steps, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, b->B);
     LH_HIP(ctx, hipGetLastError());
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -1020,6 +1020,13 @@ int llamago_BatchPrompt(llama_batch* p, const uint32_t* const* prompts, const ui
     if (lh_batch_read_ids(p->b, ids_out)) return halt_rc(lh_last_error(hip));
     return 0;
 }
+int llamago_BatchSetSampler(llama_batch* p, uint32_t topK, float topP, float temp, float repeatPenalty, uint64_t seed, uint32_t ringSize) {
+    if (!p) return halt_rc("llamago_BatchSetSampler: bad arguments");
+    lh_ctx* hip = p->mlctx->hip;
+    lh_sample_params sp = {topK, topP, temp, repeatPenalty, seed};
+    if (lh_batch_set_sampler(p->b, &sp, ringSize, nullptr, nullptr)) return halt_rc(lh_last_error(hip));
+    return 0;
+}
 int llamago_BatchTick(llama_batch* p, uint32_t* ids_out) {
     if (!p || !ids_out) return halt_rc("llamago_BatchTick: bad arguments");
     lh_ctx* hip = p->mlctx->hip;

@@ -552,6 +552,13 @@ class Batch:
             raise MLError(f"llamago_BatchPrompt: {self.ml.last_error()}")
         return list(out)
 
+    def SetSampler(self, topK=40, topP=0.95, temp=0.8, repeatPenalty=1.10, seed=0, ringSize=64):
+        """lh_batch_set_sampler: the following ticks sample (SampleTopPTopK on the device) instead of taking the argmax; allowed mid-stream."""
+        f = self.ml.lib.llamago_BatchSetSampler
+        f.restype, f.argtypes = C.c_int, [VP, c_u32, C.c_float, C.c_float, C.c_float, C.c_uint64, c_u32]
+        if f(self.h, topK, topP, temp, repeatPenalty, seed, ringSize):
+            raise MLError(f"llamago_BatchSetSampler: {self.ml.last_error()}")
+
     def Tick(self):
         """BatchHIP.Tick: one decode step of every pod in one pass over the weights; returns the ids produced."""
         out = (c_u32 * self.pods)()

@@ -22,11 +22,62 @@ def built():
     return True
 
 
+class _CheckerModelPool:
+    """The checker's synthetic models are generated on ONE host core (hundreds of millions of hashed weights for a 7B-shape slice: seconds per
+    model) and most GPU tests want the same few: keep the most recent ones alive across tests instead of regenerating them.  Tests only read a
+    checker model, except QuantizeQ8, which replaces its weights - a quantised model is therefore a pool entry of its own."""
+
+    def __init__(self, make, keep=5):
+        self.make, self.keep, self.models = make, keep, {}
+
+    def get(self, key, hp):
+        m = self.models.pop(key, None)
+        if m is None:
+            m = self.make(hp, *key[5:8])
+            if key[-1] == "q8":
+                m.QuantizeQ8()
+            while len(self.models) >= self.keep:
+                self.models.pop(next(iter(self.models))).free()   # least recently used
+        self.models[key] = m
+        return m
+
+    def close(self):
+        for m in self.models.values():
+            m.free()
+        self.models = {}
+
+
+class _PooledModel:
+    """What oracle.NewSyntheticModel hands out: the pool's model behind the Model interface; free() leaves it to the pool."""
+
+    def __init__(self, pool, key, hp):
+        self.__dict__.update(_pool=pool, _key=key, _hp=hp, _m=pool.get(key, hp))
+
+    def QuantizeQ8(self):
+        self.__dict__.update(_key=self._key + ("q8",))
+        self.__dict__.update(_m=self._pool.get(self._key, self._hp))
+        return self
+
+    def free(self):
+        pass
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+
 @pytest.fixture(scope="session")
 def oracle(built):
     """TEST-ONLY checker: CPU restatement of the reference (oracle/liboracle.so)."""
     from llama_go_amd.mlapi import MLLib
-    return MLLib(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib = MLLib(os.path.join(ROOT, "oracle", "liboracle.so"))
+    pool = _CheckerModelPool(lib.NewSyntheticModel)
+
+    def pooled(hp, seed=1234, layer0=0, layer1=0):
+        return _PooledModel(pool, (hp.vocabSize, hp.embdSize, hp.multSize, hp.headsCount, hp.layersCount, seed, layer0, layer1), hp)
+
+    lib.NewSyntheticModel = pooled
+    yield lib
+    pool.close()
 
 
 @pytest.fixture(scope="session")

@@ -174,6 +174,31 @@ def test_pods_in_one_weight_pass_swap_context_per_row(product, oracle, shape, in
 
 
 @pytest.mark.gpu
+def test_sampler_set_mid_stream_keeps_the_swap_history_right(product):
+    """lh_batch_set_sampler behind a prompt and a few ticks: it restarts the rows' output lists on the device, so the host's
+    mirror of them has to restart too - the context swap reads the tokens of the window through that mirror.  A top-1 sampler picks the
+    argmax, so pods that switch to it after three greedy ticks must go on decoding exactly what all-greedy pods decode, through two swaps."""
+    from llama_go_amd.mlapi import Batch
+    ctx_size, n_ticks = 24, 50
+    hp = make_hparams(**SHAPES["small"], ctx=ctx_size)
+    rng = np.random.default_rng(77)
+    prompts = [[int(t) for t in rng.integers(0, hp.vocabSize, n)] for n in (5, 11, 2)]
+    m = product.NewSyntheticModel(hp, 12)
+    runs = []
+    for switch_at in (None, 3):
+        b = Batch(m, ctx_size, len(prompts))
+        ids = [b.Prompt(prompts)]
+        for t in range(n_ticks):
+            if t == switch_at:
+                b.SetSampler(topK=1, topP=1.0, temp=1.0, repeatPenalty=1.0, seed=5, ringSize=ctx_size)
+            ids.append(b.Tick())
+        b.free()
+        runs.append(ids)
+    m.free()
+    assert runs[0] == runs[1]
+
+
+@pytest.mark.gpu
 def test_unsharded_pipeline_swaps_context(product, oracle):
     """The scheduler on one rank (lh_pipeline_run over lh_batch ticks): streams outlive their windows across run() calls."""
     from llama_go_amd.mlapi import Pipeline

@@ -13,7 +13,9 @@ import os
 import numpy as np
 import pytest
 
-from llama_go_amd.mlapi import PROMPT, SHAPES, make_hparams
+import json
+
+from llama_go_amd.mlapi import PROMPT, SHAPES, decode_greedy_resident, make_hparams
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -239,7 +241,7 @@ def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     assert greedy_margin(lg_o) > 10 * TOL, "test seed has a near-tie; pick another"
 
 
-@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 56, 63, 64, 65, 66, 80, 81, 96, 97, 100, 127, 128, 129])
+@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 32, 33, 48, 49, 64, 65, 80, 81, 96, 97, 112, 113, 128, 129])   # both sides of every launch-shape boundary
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
     """One Eval of N tokens: 2..96 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
     append / SiLU fused into its epilogues; one to six 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
@@ -509,6 +511,36 @@ def test_7b_shape_slice_matches_oracle(product, oracle, layers):
     assert out["fused"] == 1
     assert rel(lg_h, lg_o) <= TOL
     assert toks_h == toks_o
+
+
+@pytest.mark.parametrize("int8", [False, True])
+def test_headline_workload_at_full_depth(product, int8):
+    """BASELINE config 2 (and 4) ITSELF, not a slice: all 32 layers of LLaMA-7B, synthetic weights seed 1234, the fixed 8-token prompt,
+    context 128, 100 greedy steps - through BOTH routes a caller has: the device-resident loop (lh_llama_decode_greedy) and one
+    ml_GraphCompute per token (what server.Do's loop does, pkg/server/server.go:153-217).  The ids must equal the committed ones, which the
+    checker decoded on its own (tests/golden/7b_seed1234[_int8]_ids.json: `oracle_ids_match`, written by tools/make_golden_ids.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "7b_seed1234_int8_ids.json" if int8 else "7b_seed1234_ids.json")))
+    assert gold["oracle_ids_match"] and gold["oracle_steps"] == len(gold["ids"]) == 100
+    assert gold["min_top2_margin_rel"] > TOL, "the checker's own logits have a near-tie on the golden run"   # (fp32 1.3e-3, int8 1.5e-4; GPU vs checker 6e-6)
+    hp = make_hparams(**SHAPES["7B"], ctx=128)
+    m = product.NewSyntheticModel(hp, 1234)
+    if int8:
+        m.QuantizeQ8()
+    c = m.NewContext(128, 1)
+    first = int(np.argmax(c.Eval(PROMPT, 0)))
+    toks, _ = decode_greedy_resident(c, first, len(PROMPT), 99)
+    assert [first] + toks == gold["ids"], "device-resident loop"
+    c.free()
+    c = m.NewContext(128, 1)
+    ids, tok = [], None
+    for i in range(100):
+        lg = c.Eval(PROMPT, 0) if i == 0 else c.Eval([tok], len(PROMPT) + i - 1)
+        tok = int(np.argmax(lg))
+        ids.append(tok)
+    assert ids == gold["ids"], "one ml_GraphCompute per token"
+    c.free()
+    m.free()
 
 
 @pytest.mark.parametrize("n_prompt", [3, 6, 8, 12, 24, 40, 56, 72, 90, 97, 112, 127, 128, 129])

@@ -1,5 +1,6 @@
 // tools/q8b_probe.hip — k_stream_q8b (csrc/kernels_stream_q8b.h: block-int8 weights on the bf16 matrix pipe through the lossless
-// three-piece split of the activations) against k_stream_q8 (round 4: fp32-input MFMA) and a double-precision host product.
+// three-piece split of the activations) against a double-precision host product (round 4's k_stream_q8, fp32-input MFMA, was timed beside it
+// until it was removed: profiles/r05_q8b_probe.txt keeps those numbers).
 // usage: q8b_probe M K N [KC [groups [epi [ksplit]]]]      (7B: w1|w3 = 11008 4096 n 256 2 1, wq|wk|wv = 4096 4096 n 256 3, wo = 4096 4096 n, w2 = 4096 11008 n)
 // Timing rotates over enough copies of the weights to exceed the 256 MB Infinity Cache (a re-read matrix would come out of it).
 #define Q8B_TRACE
@@ -41,32 +42,16 @@ template <int MAXT, int NCT, int KC, int NIMG, int XR> static void run_b(const C
 #endif
     } else printf("k_stream_q8b<%d,%d,%d>: images do not fit\n", MAXT, NCT, KC);
 }
-template <int MAXT, int NCT, int KC, int NIMG> static void run_a(const Copies& c, int nCU, double wbytes) {
-    if constexpr (NIMG >= 2) {
-        const size_t lds = (size_t)NIMG * stream_q8_image_bytes(MAXT, NCT, KC);
-        auto kern = k_stream_q8<MAXT, NCT, KC, NIMG>;
-        const size_t req = std::max<size_t>(lds, 82 * 1024);
-        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)req));
-        const double us = time_us([&](int i) { hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, c.a[i]); }, (int)c.a.size());
-        printf("k_stream_q8<%d,%d,%d,%d> (fp32 MFMA, round 4): %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, NIMG, us, wbytes / us / 1e3);
-    }
-}
 constexpr int q8b_nimg(int maxt, int xr, int kc, int want) { int n = (int)(160 * 1024 / stream_q8b_image_bytes(maxt, xr, kc)); n = n < 4 ? n : 4; return want && want < n ? want : n; }
 template <int MAXT, int NCT, int KC, int XR> static void run_bk(const Copies& c, int nCU, double wbytes) {
     if (g_nimg == 2) run_b<MAXT, NCT, KC, q8b_nimg(MAXT, XR, KC, 2), XR>(c, nCU, wbytes);
     else if (g_nimg == 3) run_b<MAXT, NCT, KC, q8b_nimg(MAXT, XR, KC, 3), XR>(c, nCU, wbytes);
     else run_b<MAXT, NCT, KC, q8b_nimg(MAXT, XR, KC, 0), XR>(c, nCU, wbytes);
 }
-template <int MAXT, int NCT, int XR> static void run(const Copies& c, const Copies& c4, int nCU, double wbytes) {
+template <int MAXT, int NCT, int XR> static void run(const Copies& c, const Copies&, int nCU, double wbytes) {
     if (g_kc == 512) { if constexpr (NCT <= 2 && MAXT <= 4) run_bk<MAXT, NCT, 512, XR>(c, nCU, wbytes); else printf("KC 512: up to four tiles and two column tiles\n"); }
     else if (g_kc == 256) { if constexpr (NCT <= 2) run_bk<MAXT, NCT, 256, XR>(c, nCU, wbytes); else run_bk<MAXT, NCT, 128, XR>(c, nCU, wbytes); }
     else run_bk<MAXT, NCT, 128, XR>(c, nCU, wbytes);
-    if (getenv("Q8B_ONLY") || c.a[0].ksplit > 1) return;
-    constexpr int cap = 4;
-    if constexpr (NCT <= 3 || (NCT == 4 && MAXT <= 6)) {
-        constexpr int A256 = (int)std::min<size_t>(cap, 160 * 1024 / stream_q8_image_bytes(MAXT, NCT, 256)), A128 = (int)std::min<size_t>(cap, 160 * 1024 / stream_q8_image_bytes(MAXT, NCT, 128));
-        if (g_kc == 256) run_a<MAXT, NCT, 256, A256>(c4, nCU, wbytes); else run_a<MAXT, NCT, 128, A128>(c4, nCU, wbytes);
-    }
 }
 int main(int argc, char** argv) {
     const uint32_t M = argc > 1 ? atoi(argv[1]) : 256, K = argc > 2 ? atoi(argv[2]) : 1024, N = argc > 3 ? atoi(argv[3]) : 8;
@@ -148,6 +133,6 @@ int main(int argc, char** argv) {
         double e0 = fabs(ref - Y0[oi]), e1 = fabs(ref - Y1[oi]); if (!(e0 == e0)) e0 = 1e30; if (!(e1 == e1)) e1 = 1e30;
         worst0 = std::max(worst0, e0); worst1 = std::max(worst1, e1); scale = std::max(scale, fabs(ref)); rms0 += e0 * e0; rms1 += e1 * e1; ++cnt;
     }
-    printf("vs the f64 product of the dequantised weights (max |ref| %.3e): bf16 x 3: max err %.3e rms %.3e | fp32 MFMA: max err %.3e rms %.3e\n", scale, worst0, sqrt(rms0 / cnt), worst1, sqrt(rms1 / cnt));
+    printf("vs the f64 product of the dequantised weights (max |ref| %.3e): max err %.3e rms %.3e\n", scale, worst0, sqrt(rms0 / cnt));
     return (worst0 > 1e-4 * scale) ? 2 : 0;
 }

@@ -1,6 +1,6 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
 // (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit]]]
-// mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 3 specialised waves + block-int8, 5 block-int8 with LDS-DMA loaders (k_stream_q8), 4 specialised waves with LDS-DMA
+// mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 4 specialised waves with LDS-DMA   (modes 3 / 5, the round-3 / round-4 block-int8 kernels, went with them in round 5: tools/q8b_probe)
 // loaders (k_stream_dma; STREAM_DMA_IMAGES=2..4 images in the ring, default 3; STREAM_DMA_PIPE=1 pipelined operands); ksplit S > 1 (mode 2 / 3 / 4): groups of S
 // workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
 // Built with -DSTREAM_PROBE=bits (tools/build_probes.sh -> stream_mm_check_p<bits>) the specialised kernel takes one traffic class out of
@@ -35,8 +35,8 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
     const int nCU = nCU0 * g_wgpcu;
     const size_t lds = g_wgpcu == 2 ? stream2_lds_bytes(MAXT, NCT, KC) : std::max<size_t>(stream2_lds_bytes(MAXT, NCT, KC), 82 * 1024);
     if (lds > 160 * 1024 || (g_wgpcu == 2 && lds > 80 * 1024)) { printf("k_stream_mm2<%d,%d,%d>: images do not fit (%zu B)\n", MAXT, NCT, KC, lds); return; }
-    const bool q8 = a.ws[0] != nullptr;
-    auto kern = q8 ? k_stream_mm2<MAXT, NCT, KC, true> : k_stream_mm2<MAXT, NCT, KC, false>;
+    const bool q8 = false;
+    auto kern = k_stream_mm2<MAXT, NCT, KC>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
@@ -88,33 +88,6 @@ template <int MAXT, int NCT, int KC, int NIMG, bool PIPE, int CS = 1> static voi
         printf("   with the reduce pass: %.2f us per pair of launches\n", ms * 200);
     }
 }
-static int g_q8dma = 0;
-template <int MAXT, int NCT, int KC, int NIMG> static void run_q8_img(const StreamArgs& a, int nCU) {
-    if constexpr (NIMG >= 2) {
-        const size_t lds = (size_t)NIMG * stream_q8_image_bytes(MAXT, NCT, KC);
-        auto kern = k_stream_q8<MAXT, NCT, KC, NIMG>;
-        const size_t req = std::max<size_t>(lds, 82 * 1024);
-        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)req));
-        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, a);
-        CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, a);
-        CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("k_stream_q8<%d,%d,%d> with %d images%s: %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, NIMG, a.ksplit > 1 ? ", K-split" : "", ms * 200, (double)a.M * a.K * 36.0 / 32 / (ms * 200) / 1e3);
-        if (a.ksplit > 1) {
-            StreamReduceArgs r = {}; r.part = a.y[0]; r.stride = a.ysplit; r.y = g_yfinal; r.S = a.ksplit; r.d = a.M; r.ldy = a.ldy;
-            hipLaunchKernelGGL(k_stream_reduce_norm, dim3(a.n), dim3(256), 0, 0, r); CK(hipDeviceSynchronize());
-        }
-    } else printf("k_stream_q8<%d,%d,%d>: images do not fit\n", MAXT, NCT, KC);
-}
-template <int MAXT, int NCT> static void run_q8(const StreamArgs& a, int nCU) {
-    if constexpr (NCT <= 3 || (NCT == 4 && MAXT <= 6)) {
-        constexpr int cap = 4;
-        constexpr int N256 = (int)std::min<size_t>(cap, 160 * 1024 / stream_q8_image_bytes(MAXT, NCT, 256)), N128 = (int)std::min<size_t>(cap, 160 * 1024 / stream_q8_image_bytes(MAXT, NCT, 128));
-        if (g_kc == 256) run_q8_img<MAXT, NCT, 256, N256>(a, nCU); else run_q8_img<MAXT, NCT, 128, N128>(a, nCU);
-    } else printf("k_stream_q8: up to four column tiles (three with eight row tiles)\n");
-}
 template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const StreamArgs& a, int nCU) {
     if constexpr (NCT == 8) {   // eight column tiles: 2 K-groups x 2 column halves, 64-column chunks, pipelined
         if constexpr (KC == 64 && MAXT <= 6) { if (g_pipe) run_dma_img<MAXT, NCT, KC, NIMG, true, 2>(a, nCU); else run_dma_img<MAXT, NCT, KC, NIMG, false, 2>(a, nCU); }
@@ -132,7 +105,6 @@ template <int MAXT, int NCT, int KC> static void run_dma(const StreamArgs& a, in
     if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
 }
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
-    if (g_q8dma) { if constexpr (NCT <= 6) run_q8<MAXT, NCT>(a, nCU); return; }
     if constexpr (NCT >= 7) { run_dma<MAXT, NCT, 64>(a, nCU); return; }   // (mode 4 only: the other kernels are built for up to six column tiles)
     else {
     if (g_dma) { if (g_kc == 64) run_dma<MAXT, NCT, 64>(a, nCU); else run_dma<MAXT, NCT, 128>(a, nCU); return; }
@@ -149,11 +121,9 @@ int main(int argc, char** argv) {
     const bool tiled = argc > 5 && atoi(argv[5]) == 1;
     g_v2 = argc > 5 && (atoi(argv[5]) == 2 || atoi(argv[5]) == 3 || atoi(argv[5]) == 4);   // (mode 4 takes mode 2's dispatch over the tile counts)
     g_dma = argc > 5 && atoi(argv[5]) == 4;
-    g_q8dma = argc > 5 && atoi(argv[5]) == 5;   // mode 5: block-int8 on the LDS-DMA structure (k_stream_q8; KC = 256 / 128)
-    if (g_q8dma) g_v2 = 1;
     if (getenv("STREAM_DMA_IMAGES")) g_nimg = atoi(getenv("STREAM_DMA_IMAGES"));
     if (getenv("STREAM_DMA_PIPE")) g_pipe = atoi(getenv("STREAM_DMA_PIPE"));
-    const bool q8 = argc > 5 && (atoi(argv[5]) == 3 || atoi(argv[5]) == 5);
+    const bool q8 = false;
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); const int nCU = p.multiProcessorCount;
     std::vector<float> W((size_t)M * K), X((size_t)N * K), Y((size_t)N * M);
     unsigned s = 1; auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 8) - (1 << 23)) * (1.0f / (1 << 23)); };
