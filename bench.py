@@ -169,7 +169,7 @@ def main():
     if args.layers:
         kw["layers"] = args.layers
     K, W = args.steps, args.warmup
-    ctx_size = max(128, len(PROMPT) + K + W + 1)
+    ctx_size = max(128, len(PROMPT) + K + W + 1 + 8)   # (+ 8: the head steps of the per-token host loop measurement)
     hp = make_hparams(**kw, ctx=ctx_size)
     d, L, V = hp.embdSize, hp.layersCount, hp.vocabSize
     PROMPT = [t % V for t in PROMPT]  # the fixed ids are 7B-vocabulary ids; debug shapes have smaller tables
@@ -203,19 +203,30 @@ def main():
         produced = toks
         # ---- the reference's own loop shape: llama.Eval per token through ml_GraphCompute (graph build + structural match on the
         # host, hipGraph replay, 128 KB logits D2H, argmax on the host) = the PCIe-inclusive rate a Go caller of the shim gets
+        # Timed INSIDE the host library (llama_GreedyDecode of the C++ twin = the Go loop of server.Do with an argmax for the sampler: one llama.Eval
+        # per token, the last logits row read back, argmax on the host) as t[prompt + K steps] - t[prompt], so that the figure is what a Go caller
+        # of the shim pays and carries none of this script's interpreter time; the same loop driven from Python is reported beside it.
         c3 = model.NewContext(ctx_size, 1)
+        HEAD = 8   # both timed calls run the prompt + HEAD steps first: the first single-token Eval behind a prompt pays a one-off ~0.45 ms (its graph's first launch)
+        c3.GreedyDecode(PROMPT, HEAD + 1, want_logits=False)
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        c3.GreedyDecode(PROMPT, HEAD + 1, want_logits=False)
+        t_b = time.perf_counter()
+        ids_host_loop, _ = c3.GreedyDecode(PROMPT, HEAD + K + 1, want_logits=False)
+        t_c = time.perf_counter()
+        eval_dt = (t_c - t_b) - (t_b - t_a)
         c3.Eval(PROMPT, 0)
-        tk = first
-        for s_ in range(min(W, 2)):
-            tk = int(np.argmax(c3.Eval([tk], P0 + s_)))
         tk = first
         torch.cuda.synchronize()
         t_e = time.perf_counter()
         for s_ in range(K):
             tk = int(np.argmax(c3.Eval([tk], P0 + s_)))
-        eval_dt = time.perf_counter() - t_e
+        py_dt = time.perf_counter() - t_e
         c3.free()
         result["eval_per_token_loop"] = {"tokens_per_s": round(K / eval_dt, 2), "ms_per_token": round(eval_dt / K * 1e3, 4),
+                                         "ids_equal_resident_loop": [int(t) for t in ids_host_loop[:min(K, len(produced)) + 1]] == ([first] + [int(t) for t in produced])[:min(K, len(produced)) + 1],
+                                         "driven_from_python_tokens_per_s": round(K / py_dt, 2),
                                          "note": "llama.Eval per token via ml_GraphCompute incl. host graph build, logits D2H and host argmax (not `value`)"}
         # ---- the reference's real generation loop: SampleTopPTopK (topK 40, topP 0.95, repeat penalty 1.10 — main.go:87-90) after every
         # Eval, sampler resident on the device (no logits D2H).  Decode rate = (t[K+1 samples] - t[1 sample]) / K, same prefill in both.

@@ -41,6 +41,18 @@ Buffer* find_buffer(DeviceState* ds, lh_buf id) {
     return it == ds->bufs.end() ? nullptr : it->second.get();
 }
 
+Buffer* find_buffer_fast(lh_ctx* ctx, lh_buf id) {
+    DeviceState* ds = ctx->ds;
+    const uint64_t g = ds->bufs_gen.load(std::memory_order_acquire);
+    if (ctx->buf_snap_gen != g) {
+        std::lock_guard<std::mutex> lk(ds->mu);
+        ctx->buf_snap.assign((size_t)ds->next_id, nullptr);
+        for (auto& kv : ds->bufs) if (kv.first < ds->next_id) ctx->buf_snap[(size_t)kv.first] = kv.second.get();
+        ctx->buf_snap_gen = ds->bufs_gen.load(std::memory_order_relaxed);
+    }
+    return id < ctx->buf_snap.size() ? ctx->buf_snap[(size_t)id] : nullptr;
+}
+
 int ensure_arena(lh_ctx* ctx, uint64_t bytes) {
     if (bytes <= ctx->arena_bytes) return 0;
     uint64_t want = bytes + (bytes >> 2) + (1u << 20);
@@ -236,6 +248,7 @@ int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4
         lh_buf id = ctx->ds->next_id++;
         if (key) ctx->ds->by_key[key] = id;
         ctx->ds->bufs[id] = std::move(b);
+        ctx->ds->bufs_gen.fetch_add(1, std::memory_order_release);
         *out = id;
         return LH_OK;
     }
@@ -262,6 +275,7 @@ int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4
     lh_buf id = ds->next_id++;
     if (key) ds->by_key[key] = id;
     ds->bufs[id] = std::move(b);
+    ds->bufs_gen.fetch_add(1, std::memory_order_release);
     *out = id;
     return LH_OK;
 }
@@ -335,6 +349,7 @@ int lh_buf_quantize_q8(lh_ctx* ctx, lh_buf src, uint32_t rows, uint32_t cols, lh
     std::lock_guard<std::mutex> lk(ctx->ds->mu);
     lh_buf id = ctx->ds->next_id++;
     ctx->ds->bufs[id] = std::move(b);
+    ctx->ds->bufs_gen.fetch_add(1, std::memory_order_release);
     *out = id;
     return LH_OK;
 }
@@ -365,6 +380,7 @@ int lh_buf_free(lh_ctx* ctx, lh_buf buf) {
         if (it == ds->bufs.end()) return LH_EINVAL;
         b = std::move(it->second);
         ds->bufs.erase(it);
+        ds->bufs_gen.fetch_add(1, std::memory_order_release);
         if (b->key) ds->by_key.erase(b->key);
     }
     hipSetDevice(ctx->device);

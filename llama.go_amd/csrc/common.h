@@ -9,6 +9,7 @@
 #include <vector>
 #include <unordered_map>
 #include <mutex>
+#include <atomic>
 #include <memory>
 #include "../../include/llamahip.h"
 
@@ -56,6 +57,7 @@ struct DeviceState {
     std::unordered_map<lh_buf, std::unique_ptr<Buffer>> bufs;
     std::unordered_map<uint64_t, lh_buf> by_key;
     lh_buf next_id = 1;
+    std::atomic<uint64_t> bufs_gen{1};   // bumped (under mu) by every insertion into / removal from bufs: contexts keep lock-free snapshots (find_buffer_fast)
     // RoPE tables, one per rotation width `dims`: [positions][dims/2] of (cos, sin) in f64, built on the host with libm
     // exactly as the reference computes them per element (ml.go:2307-2310).  A table that has to grow is REPLACED by a larger
     // one and the old allocation is kept alive (captured graphs and plans of other contexts hold its address; tables are
@@ -65,6 +67,7 @@ struct DeviceState {
 };
 DeviceState* device_state(int device);
 Buffer* find_buffer(DeviceState* ds, lh_buf id);
+Buffer* find_buffer_fast(lh_ctx* ctx, lh_buf id);   // the same through the context's snapshot of the table: no lock, no hashing (ids are small integers)
 
 struct Plan;  // fused LLaMA plan (plan.hip)
 
@@ -82,6 +85,15 @@ struct lh_ctx {
     // pinned staging for small host leafs / parameters
     char* staging = nullptr;
     uint64_t staging_bytes = 0;
+    // snapshot of ds->bufs indexed by buffer id, valid while buf_snap_gen == ds->bufs_gen (a Matcher run looks up ~300 weight buffers per Eval)
+    std::vector<lh::Buffer*> buf_snap;
+    uint64_t buf_snap_gen = 0;
+    // the rows a fused Eval's caller is known to read (LH_GRAPH_LAST_ROW_LOGITS: the last logits row, llama.go:394-401) are copied to pinned host
+    // memory behind the Eval's kernels, in front of its ONE synchronisation; lh_node_read of exactly that range is then a host copy
+    float* out_pinned = nullptr;
+    uint64_t out_pinned_floats = 0;
+    int64_t pre_index = -1;
+    uint64_t pre_off = 0, pre_n = 0;
     // last computed graph: device address + element count of every tensor (for lh_node_read)
     std::vector<float*> last_ptr;
     std::vector<uint64_t> last_len;

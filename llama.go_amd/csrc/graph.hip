@@ -6,6 +6,7 @@
 // 3. otherwise — or with LH_GRAPH_NO_FUSION — run node by node, one kernel per op, exactly like the reference's
 //    sequential walk (INIT/FINALIZE phases are no-ops for every implemented op, ml.go:1501-1526).
 #include "plan.h"
+#include <chrono>
 #include "kernels_generic.h"
 #include <math.h>
 #include <algorithm>
@@ -65,7 +66,7 @@ struct Matcher {
         const lh_tensor& t = T[i];
         if (t.op != OP_NONE || t.storage != i || !t.buf) return nullptr;
         if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.ne[2] != 1 || t.ne[3] != 1) return nullptr;
-        Buffer* b = find_buffer(ctx->ds, t.buf);
+        Buffer* b = find_buffer_fast(ctx, t.buf);
         if (!b || b->nfloats < (uint64_t)ne0 * ne1 || b->dtype != (int)t.dtype) return nullptr;
         if (!matrix) return b->dtype == 0 && contiguous(t) ? b->dev : nullptr;
         if (b->dtype != 0 && b->dtype != 7) return nullptr;
@@ -268,7 +269,7 @@ struct Matcher {
             if (!is(vt, OP_CPY) || !is(s0(vt), OP_PERMUTE) || !is(s0(s0(vt)), OP_RESHAPE) || !is(s0(s0(s0(vt))), OP_VIEW)) return false;
             const int own = T[s0(s0(s0(vt)))].storage;
             if (own < 0 || !T[own].buf) return false;
-            Buffer* b = find_buffer(ctx->ds, T[own].buf);
+            Buffer* b = find_buffer_fast(ctx, T[own].buf);
             if (!b) return false;
             const uint64_t per = (uint64_t)md.d * md.L;
             if (b->nfloats % per) return false;
@@ -290,8 +291,8 @@ struct Matcher {
             tokens[i] = (uint32_t)ids[i];  // ids travel as fp32 (ml.go:1739)
             if (tokens[i] >= md.V) return false;
         }
-        Buffer* kb = find_buffer(ctx->ds, T[kc_owner].buf);
-        Buffer* vb = find_buffer(ctx->ds, T[vc_owner].buf);
+        Buffer* kb = find_buffer_fast(ctx, T[kc_owner].buf);
+        Buffer* vb = find_buffer_fast(ctx, T[vc_owner].buf);
         if (!kb || !vb || kb == vb || vb->nfloats != kb->nfloats) return false;
         md.kc = kb->dev;
         md.vc = vb->dev;
@@ -415,6 +416,10 @@ extern "C" {
 
 int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t n_nodes, uint32_t flags) {
     if (!ctx || !T) return LH_EINVAL;
+    static const bool timing = getenv("LLAMAHIP_TIMING") != nullptr;   // stderr: host phases of a fused Eval in microseconds
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1000.0; };
+    const auto tq0 = now();
     LH_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t total = n_leafs + n_nodes;
     if (total == 0) return LH_OK;
@@ -433,22 +438,42 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
     ctx->last_ptr.assign(total, nullptr);
     ctx->last_len.assign(total, 0);
     ctx->last_fused = 0;
+    ctx->pre_index = -1;
 
     // ---- fused LLaMA plan?
     if (!(flags & LH_GRAPH_NO_FUSION)) {
         Matcher m;
         m.ctx = ctx; m.T = T; m.total = total; m.n_leafs = n_leafs;
+        const auto tq1 = now();
         if (m.run()) {
             int rc = 0;
+            const auto tq2 = now();
             Plan* p = plan_find_or_create(ctx, m.md, &rc);
+            const auto tq3 = now();
             if (p) rc = plan_eval(p, m.tokens.data(), nullptr, nullptr, m.N, m.past, (flags & LH_GRAPH_LAST_ROW_LOGITS) != 0);
+            const auto tq4 = now();
             if (!rc && m.emb_node >= 0 && (T[m.emb_node].flags & LH_T_OUTPUT)) {
                 float* emb = nullptr;
                 rc = plan_embeddings(p, m.N, &emb);   // the final norm * weight rows [N][embd] (the fused lm_head launches never write them out)
                 if (!rc) { ctx->last_ptr[m.emb_node] = emb; ctx->last_len[m.emb_node] = (uint64_t)m.N * m.md.d; }
             }
+            if (!rc && (flags & LH_GRAPH_LAST_ROW_LOGITS)) {
+                // this caller reads row N - 1 of the final node and nothing else (llama.go:394-401): the row follows the kernels into pinned host
+                // memory in front of the Eval's one synchronisation, and lh_node_read of that range is then a host copy (round 5: a second
+                // synchronise + copy + synchronise cost ~20 us of the 4.5 ms a token takes through this route)
+                const uint64_t V = m.md.V;
+                if (ctx->out_pinned_floats < V) {
+                    if (ctx->out_pinned) hipHostFree(ctx->out_pinned);
+                    ctx->out_pinned = nullptr; ctx->out_pinned_floats = 0;
+                    if (hipHostMalloc((void**)&ctx->out_pinned, V * 4, hipHostMallocDefault) == hipSuccess) ctx->out_pinned_floats = V;
+                }
+                if (ctx->out_pinned && hipMemcpyAsync(ctx->out_pinned, p->logits + (uint64_t)(m.N - 1) * V, V * 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess) {
+                    ctx->pre_index = (int64_t)total - 1; ctx->pre_off = (uint64_t)(m.N - 1) * V; ctx->pre_n = V;
+                }
+            }
             if (!rc) {
                 LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (timing) fprintf(stderr, "[llamahip] graph_compute N=%u: validate %.1f us, match %.1f, find plan %.1f, enqueue %.1f, wait %.1f\n", m.N, us(tq0, tq1), us(tq1, tq2), us(tq2, tq3), us(tq3, tq4), us(tq4, now()));
                 ctx->last_ptr[total - 1] = p->logits;  // [N][V], the final node's layout (ne0 = V, ne1 = N)
                 ctx->last_len[total - 1] = (uint64_t)m.N * m.md.V;
                 ctx->last_fused = 1;
@@ -518,6 +543,10 @@ int lh_node_read(lh_ctx* ctx, uint32_t index, uint64_t off, float* dst, uint64_t
     if (index >= ctx->last_ptr.size() || !ctx->last_ptr[index])
         LH_FAIL(ctx, LH_EINVAL, "lh_node_read: tensor %u was not materialised by the last graph (a fused plan keeps the final node and the nodes flagged LH_T_OUTPUT; flag it, or use LH_GRAPH_NO_FUSION)", index);
     if (off > ctx->last_len[index] || n > ctx->last_len[index] - off) LH_FAIL(ctx, LH_EINVAL, "lh_node_read: range outside tensor %u", index);
+    if ((int64_t)index == ctx->pre_index && off == ctx->pre_off && n == ctx->pre_n) {   // already on the host (lh_graph_compute synchronised behind the copy)
+        memcpy(dst, ctx->out_pinned, n * 4);
+        return LH_OK;
+    }
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     LH_HIP(ctx, hipMemcpyAsync(dst, ctx->last_ptr[index] + off, n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -2042,6 +2042,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->splitk) hipFree(ctx->splitk);
     if (ctx->staging) hipHostFree(ctx->staging);
+    if (ctx->out_pinned) hipHostFree(ctx->out_pinned);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -49,6 +49,12 @@ struct ml_context {  // ml.Context ml.go:50-57
     int maxThreads;
     lh_ctx* hip;
     uint64_t generation = 0;  // bumped by every GraphCompute (validity of tensor->graph indices)
+    // scratch of graph_compute, kept between calls (an Eval per token flattens ~1500 tensors each time): the array the C side sees, the owner
+    // list, and the index of every persistent (shared, read-only) tensor by its device buffer id, stamped with the call that set it
+    std::vector<lh_tensor> flat;
+    std::vector<ml_tensor*> flat_leafs;
+    struct SharedIdx { uint64_t mark; int idx; };
+    std::vector<SharedIdx> shared_idx;
 };
 
 struct ml_tensor {  // ml.Tensor ml.go:180-203
@@ -289,12 +295,19 @@ static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
     g_err.clear();
     if (!ctx || !ctx->hip) return halt_rc("ml_GraphCompute: no HIP context");
     // every storage owner must be part of the array the C side sees; indices live in the tensors (flat_gen / flat_idx)
-    std::vector<ml_tensor*> leafs = g->leafs;
+    const auto tf0 = std::chrono::steady_clock::now();
+    std::vector<ml_tensor*>& leafs = ctx->flat_leafs;
+    leafs.assign(g->leafs.begin(), g->leafs.end());
     const uint64_t fg = next_mark();
-    std::unordered_map<const ml_tensor*, int> shared_idx;  // persistent (shared, read-only) tensors: see ml_graph
-    auto set_idx = [&](ml_tensor* t, int i) { if (t->persistent) shared_idx[t] = i; else { t->flat_gen = fg; t->flat_idx = i; } };
-    auto has_idx = [&](const ml_tensor* t) { return t->persistent ? shared_idx.count(t) != 0 : t->flat_gen == fg; };
-    auto index_of = [&](const ml_tensor* t) { return t->persistent ? shared_idx.find(t)->second : t->flat_idx; };
+    // persistent (shared, read-only) tensors must not be written (see ml_graph): their index lives in a table of this context, by buffer id
+    auto& sidx = ctx->shared_idx;
+    auto slot = [&](const ml_tensor* t) -> ml_context::SharedIdx& {
+        if ((size_t)t->buf >= sidx.size()) sidx.resize((size_t)t->buf + 64, ml_context::SharedIdx{0, -1});
+        return sidx[(size_t)t->buf];
+    };
+    auto set_idx = [&](ml_tensor* t, int i) { if (t->persistent) slot(t) = ml_context::SharedIdx{fg, i}; else { t->flat_gen = fg; t->flat_idx = i; } };
+    auto has_idx = [&](const ml_tensor* t) { return t->persistent ? slot(t).mark == fg : t->flat_gen == fg; };
+    auto index_of = [&](const ml_tensor* t) { return t->persistent ? slot(t).idx : t->flat_idx; };
     for (size_t i = 0; i < leafs.size(); ++i) set_idx(leafs[i], (int)i);
     for (ml_tensor* t : g->nodes) set_idx(t, -2);
     auto add_owner = [&](ml_tensor* t) {
@@ -305,7 +318,8 @@ static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
     for (ml_tensor* t : g->nodes) add_owner(t);
     const uint32_t nl = (uint32_t)leafs.size(), nn = (uint32_t)g->nodes.size();
     for (uint32_t i = 0; i < nn; ++i) set_idx(g->nodes[i], (int)(nl + i));
-    std::vector<lh_tensor> T(nl + nn);
+    std::vector<lh_tensor>& T = ctx->flat;
+    T.resize(nl + nn);
     ctx->generation++;
     for (uint32_t i = 0; i < nl + nn; ++i) {
         ml_tensor* t = i < nl ? leafs[i] : g->nodes[i - nl];
@@ -329,6 +343,8 @@ static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
             t->last_index = i;
         }
     }
+    static const bool timing = getenv("LLAMAGO_TIMING") != nullptr;
+    if (timing) fprintf(stderr, "[llamago] flatten %u tensors: %.1f us\n", nl + nn, (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count() / 1000.0);
     if (lh_graph_compute(ctx->hip, T.data(), nl, nn, flags)) return halt_rc(lh_last_error(ctx->hip));
     return 0;
 }
@@ -824,8 +840,22 @@ int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_
 }
 
 static uint32_t argmax_f32(const float* x, uint32_t n) {  // strict >, lowest index wins ties
-    uint32_t best = 0;
-    for (uint32_t i = 1; i < n; i++) if (x[i] > x[best]) best = i;
+    // two passes: the maximum over eight independent lanes (vectorises; the one-pass `x[i] > x[best]` chain cost ~40 us on 32000 logits, a
+    // tenth of what a token's whole host side may cost), then the first index that holds it
+    float m[8];
+    uint32_t i = 0;
+    if (n >= 8) {
+        for (int j = 0; j < 8; j++) m[j] = x[j];
+        for (i = 8; i + 8 <= n; i += 8)
+            for (int j = 0; j < 8; j++) m[j] = x[i + j] > m[j] ? x[i + j] : m[j];
+    } else {
+        for (int j = 0; j < 8; j++) m[j] = x[0];
+    }
+    float mx = m[0];
+    for (int j = 1; j < 8; j++) mx = m[j] > mx ? m[j] : mx;
+    for (; i < n; i++) mx = x[i] > mx ? x[i] : mx;
+    for (uint32_t k = 0; k < n; k++) if (x[k] == mx) return k;
+    uint32_t best = 0;   // (NaNs only: the reference's loop keeps index 0 then as well)
     return best;
 }
 int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t* out_tokens,
