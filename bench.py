@@ -587,8 +587,18 @@ def main():
         allt = all_ids[0]
         assert len(allt) == 1 + W + K, (len(allt), W, K)
         pl.free()
+        # Side measurements from here on: a failure in one of them must not cost the headline line that is already measured.  A rank
+        # that fails records the error; the ranks compare notes (gloo) behind every side phase and skip the remaining ones together, so nobody
+        # walks alone into a collective.  (A rank that fails INSIDE a library collective aborts the communicator: its peers fail too, and say so.)
+        def all_ranks_ok(err):
+            flags = [None] * world
+            dist.all_gather_object(flags, err)
+            return [f for f in flags if f], flags
+
+        side_alive = True
         # ---- second curve of SURVEY §8e in the same invocation: ONE greedy stream walking through the stages (latency, not throughput)
         if pods != 1:
+            err = None
             try:
                 pl1, dt1, ids1 = timed_phase(1)
                 pl1.free()
@@ -596,29 +606,41 @@ def main():
                                            "ids_match_batched_stream0": ids1[0] == allt,
                                            "note": "pods = 1: every token passes the stages one after the other (R weight-stream stages + R hops per token); not `value`"}
             except Exception as e:
-                fail("single-stream phase", e)
+                err = f"rank {rank}: {e}"
+            bad, _ = all_ranks_ok(err)
+            if bad:
+                result["single_stream"] = {"error": "; ".join(bad)}
+                side_alive = False
         # ---- where the time goes, per rank (not part of the timed runs above: three event records per tick): the rank's own stage, the
         # exchange behind it (RCCL: includes waiting for the predecessor, i.e. pipeline bubbles), and a pre-flight of the ring itself
-        try:
-            pld = new_pipeline(pods)
-            pld.run([PROMPT] * pods, 2)
-            hop_us = pld.hop_probe(d * 4, 1000)          # one residual row (16 KB on 7B), every rank shifting at the same time
-            hop_us_tick = pld.hop_probe(d * 4 * max(1, pods // pld.groups), 200)   # the rows of one tick's exchange
-            sync_all()
-            pld.profile(True)
-            kd = min(K, 8)
-            pld.run(None, kd)
-            st = pld.stats()
-            pld.free()
-            mine = {"rank": rank, "layers": l1 - l0, "ticks": st["ticks"], "stage_ms_per_tick": round(st["stage_ms"] / max(st["ticks"], 1), 4),
-                    "exchange_us_per_tick": round(st["exchange_ms"] * 1e3 / max(st["ticks"], 1), 2), "hop_us_one_row": round(hop_us, 2), "hop_us_tick_rows": round(hop_us_tick, 2)}
-            allst = [None] * world
-            dist.all_gather_object(allst, mine)
-            result["pipeline_breakdown"] = {"by_rank": allst, "steps": kd, "streams": pods,
-                                            "note": "HIP events on each rank's compute stream around every tick's stage and exchange (lh_pipeline_profile); exchange includes waiting for the "
-                                                    "predecessor's rows; hop_us = grouped send + receive round the ring (lh_pipeline_hop_probe)"}
-        except Exception as e:
-            fail("pipeline breakdown", e)
+        if side_alive:
+            mine, err = None, None
+            try:
+                pld = new_pipeline(pods)
+                pld.run([PROMPT] * pods, 2)
+                hop_us = pld.hop_probe(d * 4, 1000)          # one residual row (16 KB on 7B), every rank shifting at the same time
+                hop_us_tick = pld.hop_probe(d * 4 * max(1, pods // pld.groups), 200)   # the rows of one tick's exchange
+                sync_all()
+                pld.profile(True)
+                kd = min(K, 8)
+                pld.run(None, kd)
+                st = pld.stats()
+                pld.free()
+                mine = {"rank": rank, "layers": l1 - l0, "ticks": st["ticks"], "stage_ms_per_tick": round(st["stage_ms"] / max(st["ticks"], 1), 4),
+                        "exchange_us_per_tick": round(st["exchange_ms"] * 1e3 / max(st["ticks"], 1), 2), "hop_us_one_row": round(hop_us, 2), "hop_us_tick_rows": round(hop_us_tick, 2)}
+            except Exception as e:
+                err = f"rank {rank}: {e}"
+            bad, _ = all_ranks_ok(err)
+            if bad:
+                result["pipeline_breakdown"] = {"error": "; ".join(bad)}
+            else:
+                allst = [None] * world
+                dist.all_gather_object(allst, mine)
+                result["pipeline_breakdown"] = {"by_rank": allst, "steps": min(K, 8), "streams": pods,
+                                                "note": "HIP events on each rank's compute stream around every tick's stage and exchange (lh_pipeline_profile); exchange includes waiting for the "
+                                                        "predecessor's rows; hop_us = grouped send + receive round the ring (lh_pipeline_hop_probe)"}
+        else:
+            result["pipeline_breakdown"] = {"error": "skipped: the single-stream phase failed"}
         # ---- parity: every stream saw the same prompt, so all of them must produce the ids of the single-GPU run (committed with the
         # checker's verdict on them: tests/golden/7b_seed1234_ids.json, written by tools/make_golden_ids.py from a bench.py --gpus 1 run)
         par = {"all_streams_equal": all(t == allt for t in all_ids), "ids_match_single_gpu": None}

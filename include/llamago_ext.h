@@ -65,7 +65,7 @@ int llamago_BatchBatched(llama_batch* b);            /* lh_batch_batched */
 /* Every pod: its prompt as one Eval, then n_predict - 1 greedy steps of ALL pods per weight pass.  out[i * n_predict + s] = s-th id
  * of pod i (= llama_GreedyDecode of that prompt alone); logits (optional): [pods][vocab] of the last tick. */
 int llamago_BatchGreedyDecode(llama_batch* b, const uint32_t* const* prompts, const uint32_t* n_prompt, uint32_t n_predict, uint32_t* out, float* logits);
-/* The twins of the Go shim's BatchHIP.Prompt / BatchHIP.Tick (go/ml_hip.go): every pod's prompt as one Eval / one decode step of every pod
+/* The twins of the Go shim's BatchHIP.Prompt / BatchHIP.Tick (go/ml_hip_pods.go): every pod's prompt as one Eval / one decode step of every pod
  * in one pass over the weights; ids_out[pods] = the ids produced.  A tick that would leave a pod's context window is an error
  * (llama.Eval's pastCount + N <= CtxSize), never a write past its KV cache. */
 void llamago_BatchSetKeepCount(llama_batch* b, uint32_t keep);   /* ModelParams.KeepCount of every pod (see llamago_SetKeepCount) */

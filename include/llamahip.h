@@ -243,6 +243,9 @@ int lh_comm_init(lh_ctx* ctx, int rank, int world, const uint8_t id[LH_COMM_ID_B
 /* Alternative transport for hosts without RCCL peers (tests with several ranks on ONE GPU, which RCCL refuses; TCP):
  * the library stages the messages through host memory and hands both directions of a tick to ONE call, which must
  * post the send and the receive together (a ring of blocking sends would wait on itself).  NULL buffers = no message. */
+/* ABI note: lh_comm_init_hooks copies the WHOLE struct and lh_comm_abort calls `abort` whenever it is non-NULL: zero-initialise the struct
+ * (`lh_comm_hooks h = {0};`) and set the members you provide - a host that fills only `user` / `exchange` of an uninitialised struct
+ * hands the library an indeterminate function pointer.  The struct's size is part of ABI version 1 (lh_abi_version). */
 typedef struct lh_comm_hooks {
     void* user;
     int (*exchange)(void* user, const void* send_host, uint64_t send_bytes, int send_peer, void* recv_host, uint64_t recv_bytes, int recv_peer);

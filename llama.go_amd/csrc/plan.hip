@@ -1297,7 +1297,10 @@ bool swap_refeed_tokens(const Plan* p, uint32_t past, uint32_t pending, std::vec
 // context swap whenever the window is full (server.go:160-172): the host then learns the ids produced so far (one synchronisation per
 // (ctx - keep) / 2 tokens), re-feeds the run as ONE Eval at position keep and goes on.  first_token / past / step0 = what sp_dev[0] holds at
 // entry; the ids produced by step i land in out_tokens_dev[step0 + i].  *past_io returns the position behind the last evaluated token.
-static int resident_steps_swapping(Plan* p, uint32_t first_token, uint32_t* past_io, uint32_t step0, uint32_t n_steps, bool sampled) {
+// first_in_out (step0 >= 1): the first token is entry step0 - 1 of the output list (the sampler's pick behind the prompt) and is read together
+// with the ids the steps produce - the caller need not synchronise for it up front (lh_llama_decode_sample paid a host round trip
+// per generation for a value that is only needed at a swap or at the end).
+static int resident_steps_swapping(Plan* p, uint32_t first_token, uint32_t* past_io, uint32_t step0, uint32_t n_steps, bool sampled, bool first_in_out = false) {
     lh_ctx* ctx = p->ctx;
     const ModelDesc& md = p->md;
     const int slot1 = sampled ? Plan::G_SMP1 : Plan::G_ADV1, slotn = sampled ? Plan::G_SMPN : Plan::G_ADVN;
@@ -1307,9 +1310,12 @@ static int resident_steps_swapping(Plan* p, uint32_t first_token, uint32_t* past
     // records the tokens evaluated by steps [from, done): step j evaluated (j == 0 ? first_token : the id step j - 1 produced) at position pos0 + (j - from)
     auto learn = [&](uint32_t from, uint32_t pos0) -> int {
         if (done == 0) return 0;
-        got.resize(done);
-        LH_HIP(ctx, hipMemcpyAsync(got.data(), p->out_tokens_dev + step0, (size_t)done * 4, hipMemcpyDeviceToHost, ctx->stream));
+        got.resize(done + 1);
+        const uint32_t lead = (first_in_out && step0 >= 1) ? 1u : 0u;
+        LH_HIP(ctx, hipMemcpyAsync(got.data() + 1 - lead, p->out_tokens_dev + step0 - lead, (size_t)(done + lead) * 4, hipMemcpyDeviceToHost, ctx->stream));
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (lead) first_token = got[0];
+        got.erase(got.begin());
         for (uint32_t j = from; j < done; ++j) p->record(pos0 + (j - from), j == 0 ? first_token : got[j - 1]);
         pending = got[done - 1];
         return 0;
@@ -2210,10 +2216,8 @@ int lh_llama_decode_sample(lh_llama* m, const uint32_t* prompt, uint32_t n_promp
     if (n_predict > 1) {
         // the first id (entry 0 of the output list) is the first token the resident steps evaluate; past the window the loop swaps context
         // (server.go:160-172)
-        uint32_t first = 0, past = n_prompt;
-        LH_HIP(ctx, hipMemcpyAsync(&first, p->out_tokens_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if ((rc = resident_steps_swapping(p, first, &past, 1, n_predict - 1, true))) return rc;
+        uint32_t past = n_prompt;
+        if ((rc = resident_steps_swapping(p, 0, &past, 1, n_predict - 1, true, /*first_in_out=*/true))) return rc;
     }
     LH_HIP(ctx, hipMemcpyAsync(out_tokens, p->out_tokens_dev, (size_t)n_predict * 4, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -1,29 +1,16 @@
 //go:build hip
 
-// ml_hip.go — the reference-side binding of the MI355X backend.  Drop this file into pkg/ml of
-// gotzmann/llama.go and build with `CGO_ENABLED=1 go build -tags hip` (the stock Makefile sets
-// CGO_ENABLED=0, Makefile:25; add a sibling target).  It cannot be compiled in this repository's
-// image (no Go toolchain): it is deliberately logic-free — every decision lives behind the C-ABI
-// of include/llamahip.h, which the C++ twin of this file (llama.go_amd/host/llamago.cpp) exercises
-// in the test-suite (each fix made here is mirrored and tested there: concurrent pods, context
-// create/destroy returning device memory, empty tensors).
-//
-// What it does:
-//   - Context gains `UseHIP bool`, `HIPLastRowLogits bool` and `hip *hipState` (INTEGRATION.md hunk 1), routed exactly
-//     like UseAVX/UseNEON (Options -> ModelParams llama.go:38-39 -> ml.Context ml.go:52-53).
-//   - RegisterPersistent() copies a weight / KV-cache tensor to HBM once (LoadModel end, llama.go:975, through the
-//     package-level model context; NewContext, llama.go:91-98, through the pod's own context).  The Go slice may then
-//     be dropped.  UnregisterPersistent() releases a pod's KV caches when the pod ends (server.go:151 creates a
-//     context per job: without it every job would leak 2 x embd*layers*ctx floats of HBM).
-//   - GraphCompute (ml.go:1411) starts with `if ctx.UseHIP { hipGraphCompute(ctx, graph); return }`.
-//     hipGraphCompute flattens Graph.Leafs/Graph.Nodes into []C.lh_tensor (ml.Tensor 1:1, with the
-//     slice aliasing made explicit as storage index + float offset), calls lh_graph_compute ONCE,
-//     and copies the graph's root results back into their Data slices, so llama.Eval's logits read
-//     (llama.go:394-401) works unchanged.
-//   - StageHIP / BatchHIP: a pod's stage (executor + KV cache in HBM) built from llama.Model's tensors, and the pods of one GPU
-//     bound into ONE weight pass per decode step (lh_batch_*): what server.Engine's MaxPods concurrent Do() goroutines
-//     (server.go:84-106) become on one GPU.
-//   - PipelineHIP: the same streams over a layer-sharded model on N GPUs (lh_comm_* / lh_pipeline_*).
+// ml_hip.go — the reference-side binding of the MI355X backend for ml.GraphCompute (SURVEY §8b; pods and pipelines: ml_hip_pods.go).
+// Drop both files into pkg/ml of gotzmann/llama.go and build with `CGO_ENABLED=1 go build -tags hip` (the stock Makefile sets
+// CGO_ENABLED=0, Makefile:25; add a sibling target).  It cannot be compiled in this repository's image (no Go toolchain): it is
+// logic-free - every decision lives behind the C-ABI of include/llamahip.h, which the C++ twin (llama.go_amd/host/llamago.cpp)
+// exercises in the test-suite - and tests/test_abi.py checks every C call below against the header (names, arity, types, fields).
+//   - Context gains `UseHIP`, `HIPLastRowLogits bool` and `hip *hipState` (INTEGRATION.md hunk 1), routed like UseAVX/UseNEON.
+//   - RegisterPersistent() copies a weight / KV-cache tensor to HBM once (llama.go:975 through the model context; llama.go:91-98
+//     through the pod's own); UnregisterPersistent() / ReleaseContextHIP() release a pod's KV caches (server.go:151: a context per job).
+//   - GraphCompute (ml.go:1411) starts with `if ctx.UseHIP { hipGraphCompute(ctx, graph); return }`: Graph.Leafs/Nodes flattened into
+//     []C.lh_tensor (ml.Tensor 1:1, slice aliasing made explicit as storage index + float offset), ONE lh_graph_compute, and the graph's
+//     root results copied back into their Data slices, so llama.Eval's logits read (llama.go:394-401) works unchanged.
 package ml
 
 /*
@@ -43,13 +30,12 @@ import (
 )
 
 type hipState struct {
-	ctx *C.lh_ctx
-	// persistent tensors registered through THIS context (a pod's KV caches): released with it
-	owned []*Tensor
+	ctx   *C.lh_ctx
+	owned []*Tensor // persistent tensors registered through THIS context (a pod's KV caches): released with it
 }
 
-func hipHalt(ctx *C.lh_ctx) {
-	fmt.Printf("\n[HALT] HIP backend: %s", C.GoString(C.lh_last_error(ctx))) // same print-and-exit as ml.go:1538-1539
+func hipHalt(ctx *C.lh_ctx) { // same print-and-exit as ml.go:1538-1539
+	fmt.Printf("\n[HALT] HIP backend: %s", C.GoString(C.lh_last_error(ctx)))
 	os.Exit(1)
 }
 
@@ -65,15 +51,14 @@ func NewContextHIP(device int) *Context {
 // ReleaseContextHIP mirrors (*Context).ReleaseContext (ml.go:77-80): the pod's KV caches leave HBM with it.
 func (ctx *Context) ReleaseContextHIP() {
 	for _, key := range ctx.hip.owned {
-		unregisterKey(ctx, key)
+		UnregisterPersistent(ctx, key)
 	}
 	ctx.hip.owned = nil
 	C.lh_ctx_destroy(ctx.hip.ctx)
 	ctx.hip.ctx = nil
 }
 
-// The model is loaded before any pod exists (llama.go:975 runs at start-up, server.go:45 shares the Model): weights are
-// registered through one package-level context on the chosen device.
+// The model is loaded before any pod exists (llama.go:975, server.go:45 shares it): weights are registered through one package-level context.
 var (
 	modelOnce sync.Once
 	modelCtx  *Context
@@ -84,15 +69,13 @@ func ModelContextHIP(device int) *Context {
 	return modelCtx
 }
 
-// persistent[tensor] = device buffer.  Keyed by the *Tensor (the model's weight tensors and a context's KV cache tensors are the very
-// objects the graph's MulMat / View1D nodes point to, llama.go:263-265, 274-275), NOT by &Data[0]: a pointer into the backing array
-// would keep all 27 GB of host weights reachable for the garbage collector for as long as the map lives, and the device copy is the only
-// one inference reads (include/llamahip.h: "no host pointer is retained").  ReleaseHostWeights drops the host copies.
-// Pods run concurrently (server.go:88-101: one goroutine per job), so the map is guarded: Go aborts the process on an unsynchronised
-// concurrent map read + write.
+// persistent[tensor] = device buffer, keyed by the *Tensor (the very objects the graph's MulMat / View1D nodes point to,
+// llama.go:263-265, 274-275), not by &Data[0]: a pointer into the backing array would keep 27 GB of host weights reachable.
+// Pods run concurrently (server.go:88-101), so the maps are guarded.
 var (
 	persistentMu sync.RWMutex
 	persistent   = map[*Tensor]C.lh_buf{}
+	podOwned     = map[*Tensor]bool{} // registered through a pod's context (its KV caches)
 )
 
 func lookupPersistent(t *Tensor) (C.lh_buf, bool) {
@@ -102,23 +85,22 @@ func lookupPersistent(t *Tensor) (C.lh_buf, bool) {
 	return buf, ok
 }
 
-// ReleaseHostWeights: after RegisterPersistent the device holds the only copy inference needs; setting Data to nil lets the garbage
-// collector free the host copy (27 GB for 7B fp32).  Call once after LoadModel + registration (INTEGRATION.md §2); tensors that the host
-// still reads (none on the Eval path: logits come back through lh_node_read) must not be passed.
+// ReleaseHostWeights: after RegisterPersistent the device holds the only copy inference needs; Data = nil lets the garbage collector
+// free the host copy (27 GB for 7B fp32).  ONLY weights registered through the model context qualify (consumed whole by MulMat /
+// GetRows / Mul, never through a view); a pod's KV cache is addressed through View1D offsets derived from its Data slice
+// (viewOffset), so a tensor owned by a pod context is refused.
 func ReleaseHostWeights(tensors ...*Tensor) {
+	persistentMu.Lock()
+	defer persistentMu.Unlock()
 	for _, t := range tensors {
-		if t == nil {
-			continue
-		}
-		if _, ok := lookupPersistent(t); ok {
+		if _, ok := persistent[t]; t != nil && ok && !podOwned[t] {
 			t.Data = nil
 		}
 	}
 }
 
-// RegisterPersistent uploads t.Data to HBM under a stable key (the address of its backing array).  Tensors registered
-// through a pod's context (its KV caches) are released by ReleaseContextHIP; weights registered through
-// ModelContextHIP live as long as the process, like the reference's Model.
+// RegisterPersistent uploads t.Data to HBM.  Tensors registered through a pod's context (its KV caches) are released by
+// ReleaseContextHIP; weights registered through ModelContextHIP live as long as the process, like the reference's Model.
 func RegisterPersistent(ctx *Context, t *Tensor) {
 	if len(t.Data) == 0 {
 		return
@@ -130,39 +112,31 @@ func RegisterPersistent(ctx *Context, t *Tensor) {
 	}
 	var buf C.lh_buf
 	ne := [4]C.uint32_t{C.uint32_t(t.NE[0]), C.uint32_t(t.NE[1]), C.uint32_t(t.NE[2]), C.uint32_t(t.NE[3])}
-	// library-side key: the tensor's address as a number (a uintptr holds nothing alive); the data pointer is used for the duration of
-	// the call only and its pointee holds no Go pointers (cgo rule)
-	rc := C.lh_tensor_register(ctx.hip.ctx, C.uint64_t(uintptr(unsafe.Pointer(t))), C.int(TYPE_F32), &ne[0], 1,
-		unsafe.Pointer(&t.Data[0]), &buf)
-	if rc != 0 {
+	// library-side key: the tensor's address as a number; the data pointer is used for the duration of the call only (cgo rule)
+	if rc := C.lh_tensor_register(ctx.hip.ctx, C.uint64_t(uintptr(unsafe.Pointer(t))), C.int(TYPE_F32), &ne[0], 1, unsafe.Pointer(&t.Data[0]), &buf); rc != 0 {
 		hipHalt(ctx.hip.ctx)
 	}
 	persistent[t] = buf
 	if ctx != modelCtx {
 		ctx.hip.owned = append(ctx.hip.owned, t)
+		podOwned[t] = true
 	}
 }
 
 // UnregisterPersistent frees the device copy of a tensor (a finished pod's KV cache).
-func UnregisterPersistent(ctx *Context, t *Tensor) {
-	if t != nil {
-		unregisterKey(ctx, t)
-	}
-}
-
-func unregisterKey(ctx *Context, key *Tensor) {
+func UnregisterPersistent(ctx *Context, key *Tensor) {
 	persistentMu.Lock()
 	buf, ok := persistent[key]
 	delete(persistent, key)
+	delete(podOwned, key)
 	persistentMu.Unlock()
 	if ok {
 		C.lh_buf_free(ctx.hip.ctx, buf)
 	}
 }
 
-// root follows the reference's view constructors back to the tensor that owns the bytes:
-// ViewTensor users (Rope ml.go:862, Scale :948, DiagMaskInf :980, SoftMax :1005, Permute :809) and
-// View1D/Reshape3D alias src0; Copy's result is a view of its destination src1 (ml.go:718).
+// root follows the reference's view constructors back to the tensor that owns the bytes: ViewTensor users (Rope ml.go:862, Scale :948,
+// DiagMaskInf :980, SoftMax :1005, Permute :809) and View1D/Reshape3D alias src0; Copy's result is a view of its destination src1 (:718).
 func root(t *Tensor) *Tensor {
 	for {
 		switch t.op {
@@ -176,8 +150,13 @@ func root(t *Tensor) *Tensor {
 	}
 }
 
-// viewOffset: floats between a view's first element and its owner's (0 for empty tensors).
+// viewOffset: floats between a view's first element and its owner's (0 for empty tensors).  A view of an owner whose host copy is
+// gone has no offset to derive: ReleaseHostWeights only accepts tensors nothing views, so that is a caller bug and halts.
 func viewOffset(t, r *Tensor) C.uint64_t {
+	if t != r && len(t.Data) != 0 && len(r.Data) == 0 {
+		fmt.Printf("\n[HALT] HIP backend: view of a tensor whose host data was released")
+		os.Exit(1)
+	}
 	if len(t.Data) == 0 || len(r.Data) == 0 {
 		return 0
 	}
@@ -212,8 +191,7 @@ func hipGraphCompute(ctx *Context, graph *Graph) {
 		all = append(all, graph.Nodes[i])
 	}
 
-	// C-owned array + staging for the small host leafs (token ids, rope/mask/scale parameters):
-	// no Go pointer is ever stored in C memory.
+	// C-owned array + staging for the small host leafs (token ids, rope/mask/scale parameters): no Go pointer is ever stored in C memory
 	arr := (*[1 << 20]C.lh_tensor)(C.calloc(C.size_t(len(all)), C.size_t(unsafe.Sizeof(C.lh_tensor{}))))[:len(all):len(all)]
 	defer C.free(unsafe.Pointer(&arr[0]))
 	bufs := make([]C.lh_buf, len(all)) // one map lookup per tensor, under the read lock
@@ -262,8 +240,7 @@ func hipGraphCompute(ctx *Context, graph *Graph) {
 		}
 	}
 
-	// HIPLastRowLogits: set by llama.Eval (which copies out only row N-1 of the lm_head, llama.go:394-401) so that a fused plan
-	// skips the other N-1 logits rows; generic ml.Graph users leave it false and get every node in full.
+	// HIPLastRowLogits: set by llama.Eval (it copies out only row N-1 of the lm_head, llama.go:394-401): a fused plan skips the other rows
 	flags := C.uint32_t(0)
 	if ctx.HIPLastRowLogits {
 		flags = C.LH_GRAPH_LAST_ROW_LOGITS
@@ -272,8 +249,7 @@ func hipGraphCompute(ctx *Context, graph *Graph) {
 		hipHalt(ctx.hip.ctx)
 	}
 
-	// graph roots (nodes nobody consumes) that do not live in a persistent buffer go back to their Data slices;
-	// for llama.Eval that is exactly the lm_head output (llama.go:384-401): the K/V cache copies stay in HBM.
+	// graph roots (nodes nobody consumes) outside persistent buffers go back to their Data slices: for llama.Eval the lm_head output
 	for i := nl; i < len(all); i++ {
 		t := all[i]
 		if consumed[i] || len(t.Data) == 0 {
@@ -289,337 +265,3 @@ func hipGraphCompute(ctx *Context, graph *Graph) {
 	}
 }
 
-// ---- pods as pipeline streams over a layer-sharded model (include/llamahip.h: lh_comm_*, lh_pipeline_*) ----------------
-// One process per GPU.  Rank 0 runs the HTTP server of pkg/server; the other ranks run the same binary with --rank r and
-// only ever call PipelineHIP.Run.  The 128-byte RCCL id travels over any channel the deployment already has (here: the
-// caller passes it in; cmd-line, file or a TCP hello all work).
-type PipelineHIP struct {
-	ctx  *Context
-	comm *C.lh_comm
-	pl   *C.lh_pipeline
-	pods []*StageHIP
-}
-
-// CommUniqueIdHIP: call on rank 0, hand the bytes to every other rank.
-func CommUniqueIdHIP(ctx *Context) [C.LH_COMM_ID_BYTES]byte {
-	var id [C.LH_COMM_ID_BYTES]byte
-	if rc := C.lh_comm_unique_id(ctx.hip.ctx, (*C.uint8_t)(unsafe.Pointer(&id[0]))); rc != 0 {
-		hipHalt(ctx.hip.ctx)
-	}
-	return id
-}
-
-// ---- stages: what llama.Model + one pod's KV cache look like to the fused executor --------------------------------------
-// Package ml cannot import package llama (llama imports ml), so the caller hands over the tensors of llama.Model
-// (pkg/llama/llama.go:181-193) and llama.Layer (:128-146) in these two structs; pkg/llama gets a three-line helper that fills
-// them (INTEGRATION.md §2b).  Every tensor must have been RegisterPersistent'ed (LoadModel end, llama.go:975).
-type LayerWeightsHIP struct {
-	AttentionNorm, WQ, WK, WV, WO, FFNNorm, W1, W2, W3 *Tensor
-}
-type ModelWeightsHIP struct {
-	Vocab, Embd, Heads, Layers, FF uint32 // llama.HParams (llama.go:149-158) + ffSize (llama.go:761)
-	TokEmbeddings, Norm, Output    *Tensor // may be nil on ranks that do not hold them (first / last stage only)
-	Layer                          []LayerWeightsHIP // len == Layers; entries outside this rank's [layer0, layer1) may be zero
-}
-
-// StageHIP is one pod's stage on this rank: the lh_llama handle plus the pod's KV cache buffers (llama.Context's kvSelf,
-// llama.go:91-98, for the rank's layers only), which live in HBM and nowhere else.
-type StageHIP struct {
-	ctx  *Context
-	h    *C.lh_llama
-	k, v C.lh_buf
-}
-
-func bufOf(t *Tensor) C.lh_buf {
-	if t == nil {
-		return 0
-	}
-	b, ok := lookupPersistent(t)
-	if !ok {
-		fmt.Printf("\n[HALT] HIP backend: a model tensor was not registered (RegisterPersistent after LoadModel)")
-		os.Exit(1)
-	}
-	return b
-}
-
-// NewStageHIP mirrors llama.NewContext (llama.go:91-103) for layers [layer0, layer1) of the model: a zero-filled KV cache of
-// embd * (layer1 - layer0) * ctxSize floats per tensor, created directly in HBM (host pointer nil), and the executor's
-// description of the stage (lh_llama_desc).  layer1 == 0 means "to the last layer".  C++ twin: make_stage, host/llamago.cpp.
-func NewStageHIP(ctx *Context, w *ModelWeightsHIP, layer0, layer1, ctxSize uint32) *StageHIP {
-	if layer1 == 0 {
-		layer1 = w.Layers
-	}
-	st := &StageHIP{ctx: ctx}
-	// ml.Tensor.NE is uint32 (ml.go:187): the element count of a KV cache must fit it (C++ twin: llamago_NewBatch / make_stage halt likewise)
-	kvn := uint64(w.Embd) * uint64(layer1-layer0) * uint64(ctxSize)
-	if layer1 <= layer0 || kvn == 0 || kvn > 0xFFFFFFFF {
-		fmt.Printf("\n[HALT] NewStageHIP: KV cache of %d elements (embd %d x %d layers x ctx %d) outside uint32", kvn, w.Embd, layer1-layer0, ctxSize)
-		os.Exit(1)
-	}
-	ne := [4]C.uint32_t{C.uint32_t(kvn), 1, 1, 1}
-	if rc := C.lh_tensor_register(ctx.hip.ctx, 0, C.int(TYPE_F32), &ne[0], 1, nil, &st.k); rc != 0 {
-		hipHalt(ctx.hip.ctx)
-	}
-	if rc := C.lh_tensor_register(ctx.hip.ctx, 0, C.int(TYPE_F32), &ne[0], 1, nil, &st.v); rc != 0 {
-		hipHalt(ctx.hip.ctx)
-	}
-	// the layer table goes through C memory: a Go struct handed to C must not contain Go pointers
-	n := int(w.Layers)
-	layers := (*[1 << 16]C.lh_llama_layer)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.lh_llama_layer{}))))[:n:n]
-	defer C.free(unsafe.Pointer(&layers[0]))
-	for i := int(layer0); i < int(layer1); i++ {
-		l := &w.Layer[i]
-		layers[i] = C.lh_llama_layer{attention_norm: bufOf(l.AttentionNorm), wq: bufOf(l.WQ), wk: bufOf(l.WK), wv: bufOf(l.WV), wo: bufOf(l.WO),
-			ffn_norm: bufOf(l.FFNNorm), w1: bufOf(l.W1), w2: bufOf(l.W2), w3: bufOf(l.W3)}
-	}
-	var d C.lh_llama_desc
-	d.vocab, d.embd, d.heads, d.layers, d.ff, d.ctx = C.uint32_t(w.Vocab), C.uint32_t(w.Embd), C.uint32_t(w.Heads), C.uint32_t(w.Layers), C.uint32_t(w.FF), C.uint32_t(ctxSize)
-	d.layer0, d.layer1 = C.uint32_t(layer0), C.uint32_t(layer1)
-	if layer0 == 0 {
-		d.tok_embeddings = bufOf(w.TokEmbeddings)
-	}
-	if layer1 == w.Layers {
-		d.norm, d.output = bufOf(w.Norm), bufOf(w.Output)
-	}
-	d.layer = &layers[0]
-	d.k_cache, d.v_cache = st.k, st.v
-	d.weight_dtype = C.int(TYPE_F32)
-	if rc := C.lh_llama_create(ctx.hip.ctx, &d, &st.h); rc != 0 {
-		hipHalt(ctx.hip.ctx)
-	}
-	return st
-}
-
-// Release mirrors (*llama.Context).ReleaseContext (llama.go:105-113) for the stage: the executor state and the pod's KV cache
-// leave HBM.
-func (st *StageHIP) Release() {
-	C.lh_llama_destroy(st.h)
-	C.lh_buf_free(st.ctx.hip.ctx, st.k)
-	C.lh_buf_free(st.ctx.hip.ctx, st.v)
-	st.h = nil
-}
-
-// ---- the pods of ONE GPU in one weight pass (include/llamahip.h: lh_batch_*) --------------------------------------------
-// server.Engine starts up to MaxPods concurrent Do() goroutines over one Model (server.go:84-106, 151).  With UseHIP the engine
-// instead keeps ONE BatchHIP per GPU: every pod is a row; Prompt() evaluates the pods' prompts, each Tick() advances every pod by
-// one token in ONE pass over the weights (4-16 pods cost about what one costs: the decode step is bound by the weight stream).
-type BatchHIP struct {
-	ctx    *Context
-	b      *C.lh_batch
-	stages []*StageHIP
-}
-
-func NewBatchHIP(ctx *Context, stages []*StageHIP) *BatchHIP {
-	n := len(stages)
-	if n == 0 || n > 64 { // lh_batch_create would refuse it; the slice expression below must not panic first
-		fmt.Printf("\n[HALT] NewBatchHIP: %d pods outside 1..64", n)
-		os.Exit(1)
-	}
-	hs := (*[1 << 16]*C.lh_llama)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
-	defer C.free(unsafe.Pointer(&hs[0]))
-	for i, st := range stages {
-		hs[i] = st.h
-	}
-	bt := &BatchHIP{ctx: ctx, stages: stages}
-	if rc := C.lh_batch_create(ctx.hip.ctx, (**C.lh_llama)(unsafe.Pointer(&hs[0])), C.uint32_t(n), &bt.b); rc != 0 {
-		hipHalt(ctx.hip.ctx)
-	}
-	return bt
-}
-
-// cPrompts copies [][]uint32 into C memory (pointer table + rows); the returned func frees it.
-func cPrompts(prompts [][]uint32) (**C.uint32_t, *C.uint32_t, func()) {
-	n := len(prompts)
-	if n == 0 { // (SetSampler(nil prompts): nothing to hand over; &ptrs[0] below would panic)
-		return nil, nil, func() {}
-	}
-	ptrs := (*[1 << 16]*C.uint32_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
-	lens := (*[1 << 16]C.uint32_t)(C.malloc(C.size_t(4 * n)))[:n:n]
-	for i, pr := range prompts {
-		ptrs[i] = (*C.uint32_t)(C.malloc(C.size_t(4 * (len(pr) + 1))))
-		if len(pr) > 0 {
-			C.memcpy(unsafe.Pointer(ptrs[i]), unsafe.Pointer(&pr[0]), C.size_t(4*len(pr)))
-		}
-		lens[i] = C.uint32_t(len(pr))
-	}
-	return (**C.uint32_t)(unsafe.Pointer(&ptrs[0])), &lens[0], func() {
-		for i := range ptrs {
-			C.free(unsafe.Pointer(ptrs[i]))
-		}
-		C.free(unsafe.Pointer(&ptrs[0]))
-		C.free(unsafe.Pointer(&lens[0]))
-	}
-}
-
-// Prompt: server.Do's prompt Eval (server.go:185-192) for every pod; returns the id each pod's prompt produced (greedy, or the
-// first sampler draw after SetSampler).
-func (bt *BatchHIP) Prompt(prompts [][]uint32) []uint32 {
-	pp, nn, free := cPrompts(prompts)
-	defer free()
-	if rc := C.lh_batch_prompt(bt.b, pp, nn, nil, nil); rc != 0 {
-		hipHalt(bt.ctx.hip.ctx)
-	}
-	return bt.ids()
-}
-
-// Tick: one decode step of every pod (llama.Eval with N = 1 per pod, llama.go:211-426) in one pass over the weights; returns
-// the ids produced.  The ids feed the next Tick on the device; the host only reads them.
-func (bt *BatchHIP) Tick() []uint32 {
-	if rc := C.lh_batch_stage(bt.b, nil, nil, nil, nil); rc != 0 {
-		hipHalt(bt.ctx.hip.ctx)
-	}
-	return bt.ids()
-}
-
-func (bt *BatchHIP) ids() []uint32 {
-	out := make([]uint32, len(bt.stages))
-	if rc := C.lh_batch_read_ids(bt.b, (*C.uint32_t)(unsafe.Pointer(&out[0]))); rc != 0 {
-		hipHalt(bt.ctx.hip.ctx)
-	}
-	return out
-}
-
-// SetSampler: from the next Prompt on, ids are drawn with SampleTopPTopK (llama.go:455-707; server.go:201-204) on the device.
-// prompts seed every pod's lastNTokens ring (server.go:193-197); ringSize = CtxSize in the reference (server.go:127).
-func (bt *BatchHIP) SetSampler(topK uint32, topP, temp, repeatPenalty float32, seed uint64, ringSize uint32, prompts [][]uint32) {
-	sp := C.lh_sample_params{top_k: C.uint32_t(topK), top_p: C.float(topP), temp: C.float(temp), repeat_penalty: C.float(repeatPenalty), seed: C.uint64_t(seed)}
-	pp, nn, free := cPrompts(prompts)
-	defer free()
-	if rc := C.lh_batch_set_sampler(bt.b, &sp, C.uint32_t(ringSize), pp, nn); rc != 0 {
-		hipHalt(bt.ctx.hip.ctx)
-	}
-}
-
-// SetKeepCount: ModelParams.KeepCount (llama.go:47) of every pod.  A Tick of a pod that stands at the end of its window swaps its context
-// as server.Do does (server.go:160-172) inside lh_batch_stage: the host loop needs no swap code of its own.
-func (bt *BatchHIP) SetKeepCount(keep uint32) {
-	for _, st := range bt.stages {
-		C.lh_llama_set_keep(st.h, C.uint32_t(keep))
-	}
-}
-
-func (bt *BatchHIP) Release() { C.lh_batch_destroy(bt.b) }
-
-// NewPipelineHIP: `stages[i]` is this rank's stage of stream i (NewStageHIP over the rank's layer range: the stream's own KV
-// cache, all on ctx).  world == 1 needs no communicator.  The streams advance in groups: one pass over the rank's weights per
-// group and tick (lh_pipeline_create).
-func NewPipelineHIP(ctx *Context, rank, world int, id [C.LH_COMM_ID_BYTES]byte, stages []*StageHIP) *PipelineHIP {
-	n := len(stages)
-	p := &PipelineHIP{ctx: ctx, pods: stages}
-	if world > 1 {
-		if rc := C.lh_comm_init(ctx.hip.ctx, C.int(rank), C.int(world), (*C.uint8_t)(unsafe.Pointer(&id[0])), &p.comm); rc != 0 {
-			hipHalt(ctx.hip.ctx)
-		}
-	}
-	hs := (*[1 << 16]*C.lh_llama)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n] // C memory: the handles are C pointers, the table must be too
-	defer C.free(unsafe.Pointer(&hs[0]))
-	for i, st := range stages {
-		hs[i] = st.h
-	}
-	if rc := C.lh_pipeline_create(ctx.hip.ctx, p.comm, (**C.lh_llama)(unsafe.Pointer(&hs[0])), C.uint32_t(n), &p.pl); rc != 0 {
-		hipHalt(ctx.hip.ctx)
-	}
-	return p
-}
-
-// RunSample is Run with the reference's sampler after every Eval (server.go:201-204) instead of the argmax.  prompts must be
-// given on rank 0 and on the last rank (the repeat penalty runs over the ring of prompt ids there).
-func (p *PipelineHIP) RunSample(prompts [][]uint32, steps int, topK uint32, topP, temp, repeatPenalty float32, seed uint64, ringSize uint32) {
-	sp := C.lh_sample_params{top_k: C.uint32_t(topK), top_p: C.float(topP), temp: C.float(temp), repeat_penalty: C.float(repeatPenalty), seed: C.uint64_t(seed)}
-	if prompts == nil {
-		if rc := C.lh_pipeline_run_sample(p.pl, nil, nil, C.uint32_t(steps), &sp, C.uint32_t(ringSize)); rc != 0 {
-			hipHalt(p.ctx.hip.ctx)
-		}
-		return
-	}
-	pp, nn, free := cPrompts(prompts)
-	defer free()
-	if rc := C.lh_pipeline_run_sample(p.pl, pp, nn, C.uint32_t(steps), &sp, C.uint32_t(ringSize)); rc != 0 {
-		hipHalt(p.ctx.hip.ctx)
-	}
-}
-
-// Run: prompts != nil starts every stream from its prompt (server.go:185-192 feeds the prompt as one Eval), then `steps`
-// greedy decode steps per stream; prompts == nil continues.  Schedule, stages and RCCL p2p all run below this call.
-func (p *PipelineHIP) Run(prompts [][]uint32, steps int) {
-	if prompts == nil {
-		if rc := C.lh_pipeline_run(p.pl, nil, nil, C.uint32_t(steps)); rc != 0 {
-			hipHalt(p.ctx.hip.ctx)
-		}
-		return
-	}
-	n := len(prompts)
-	ptrs := (*[1 << 16]*C.uint32_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n] // C memory: no Go pointer to Go pointer
-	lens := make([]C.uint32_t, n)
-	for i, pr := range prompts {
-		ptrs[i] = (*C.uint32_t)(C.malloc(C.size_t(4 * len(pr))))
-		C.memcpy(unsafe.Pointer(ptrs[i]), unsafe.Pointer(&pr[0]), C.size_t(4*len(pr)))
-		lens[i] = C.uint32_t(len(pr))
-	}
-	rc := C.lh_pipeline_run(p.pl, (**C.uint32_t)(unsafe.Pointer(&ptrs[0])), &lens[0], C.uint32_t(steps))
-	for i := range ptrs {
-		C.free(unsafe.Pointer(ptrs[i]))
-	}
-	C.free(unsafe.Pointer(&ptrs[0]))
-	if rc != 0 {
-		hipHalt(p.ctx.hip.ctx)
-	}
-}
-
-// SetKeepCount: ModelParams.KeepCount (llama.go:47) of every stream; every rank calls it with the same value before the prompts.  A stream
-// that stands at the end of its window is swapped inside Run as server.Do does (server.go:160-172), on all ranks in the same tick.
-func (p *PipelineHIP) SetKeepCount(keep uint32) {
-	if rc := C.lh_pipeline_set_keep(p.pl, C.uint32_t(keep)); rc != 0 {
-		hipHalt(p.ctx.hip.ctx)
-	}
-}
-
-// Profile / Stats: where the time of the following Runs goes on THIS rank - its own kernels per tick (ms) and from the end of its stage to the
-// end of its send / receive (us; includes waiting for the predecessor).  Profile(true) also clears the totals.  Not for a timed run.
-func (p *PipelineHIP) Profile(on bool) {
-	v := C.int(0)
-	if on {
-		v = 1
-	}
-	if rc := C.lh_pipeline_profile(p.pl, v); rc != 0 {
-		hipHalt(p.ctx.hip.ctx)
-	}
-}
-
-func (p *PipelineHIP) Stats() (ticks uint32, stageMsPerTick, exchangeUsPerTick float32) {
-	var st C.lh_pipeline_stats
-	if rc := C.lh_pipeline_stats_read(p.pl, &st); rc != 0 {
-		hipHalt(p.ctx.hip.ctx)
-	}
-	if st.ticks == 0 {
-		return 0, 0, 0
-	}
-	return uint32(st.ticks), float32(st.stage_ms) / float32(st.ticks), float32(st.exchange_ms) * 1000 / float32(st.ticks)
-}
-
-// HopProbe: microseconds per grouped send + receive of `rows` residual rows round the ring (every rank calls it at the same time).
-func (p *PipelineHIP) HopProbe(rows, embd uint32, iters int) float32 {
-	var us C.float
-	if rc := C.lh_pipeline_hop_probe(p.pl, C.uint32_t(rows*embd*4), C.uint32_t(iters), &us); rc != 0 {
-		hipHalt(p.ctx.hip.ctx)
-	}
-	return float32(us)
-}
-
-// Tokens: ids of a stream known to this rank (rank 0: everything generated so far).
-func (p *PipelineHIP) Tokens(pod int) []uint32 {
-	n := int(C.lh_pipeline_tokens(p.pl, C.uint32_t(pod), nil, 0))
-	if n <= 0 {
-		return nil
-	}
-	out := make([]uint32, n)
-	C.lh_pipeline_tokens(p.pl, C.uint32_t(pod), (*C.uint32_t)(unsafe.Pointer(&out[0])), C.uint32_t(n))
-	return out
-}
-
-func (p *PipelineHIP) Release() {
-	C.lh_pipeline_destroy(p.pl)
-	if p.comm != nil {
-		C.lh_comm_destroy(p.comm)
-	}
-}

@@ -542,7 +542,7 @@ class Batch:
         self.ml.lib.llamago_BatchSetKeepCount(self.h, keep)
 
     def Prompt(self, prompts):
-        """BatchHIP.Prompt (go/ml_hip.go): every pod's prompt as one Eval; returns the id each prompt produced."""
+        """BatchHIP.Prompt (go/ml_hip_pods.go): every pod's prompt as one Eval; returns the id each prompt produced."""
         assert len(prompts) == self.pods
         arrs = [(c_u32 * len(p))(*[int(t) for t in p]) for p in prompts]
         pp = (c_u32p * self.pods)(*[C.cast(a, c_u32p) for a in arrs])

@@ -85,31 +85,101 @@ def _call_args(src, start):
         i += 1
 
 
-def test_go_shim_calls_only_declared_functions_with_the_declared_arity():
-    """The cgo shim cannot be compiled here (no Go toolchain): at least every C.lh_* it calls must be a function llamahip.h declares, called with
-    the number of arguments the prototype has, and every C.lh_* / C.LH_* type or constant it names must exist in the header."""
-    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "llamahip.h")).read(), flags=re.S)
+GO_FILES = ("ml_hip.go", "ml_hip_pods.go")
+
+
+def _go_code(name):
+    go = open(os.path.join(ROOT, "llama.go_amd", "go", name)).read()
+    go = re.sub(r"//[^\n]*", "", go)
+    return go.split('import "C"', 1)[1]          # below the cgo preamble
+
+
+def _c_header():
+    return re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "llamahip.h")).read(), flags=re.S)
+
+
+def _norm_ctype(t):
+    """'const float * const *x' -> ('float', 2): base type and pointer depth, qualifiers and the parameter name dropped."""
+    t = re.sub(r"\b(const|struct|volatile)\b", " ", t)
+    arrays = len(re.findall(r"\[[^\]]*\]", t))          # `uint8_t id[128]` is a pointer parameter
+    t = re.sub(r"\[[^\]]*\]", " ", t)
+    depth = t.count("*") + arrays
+    t = t.replace("*", " ")
+    words = t.split()
+    if len(words) > 1 and not (len(words) == 2 and words[0] in ("unsigned", "long")):
+        words = words[:-1]                      # the parameter name
+    return " ".join(words), depth
+
+
+def _prototypes(hdr):
     protos = {}
     for m in re.finditer(r"\b(lh_[A-Za-z0-9_]+)\s*\(", hdr):
         args = _call_args(hdr, m.end() - 1).strip()
-        protos[m.group(1)] = 0 if args in ("", "void") else len(_split_args(args))
-    go = open(os.path.join(ROOT, "llama.go_amd", "go", "ml_hip.go")).read()
-    go = re.sub(r"//[^\n]*", "", go)
-    go_code = go.split('import "C"', 1)[1]          # below the cgo preamble
-    calls = 0
-    for m in re.finditer(r"\bC\.(lh_[A-Za-z0-9_]+)\s*\(", go_code):
-        name = m.group(1)
-        if name not in protos:
-            # a conversion to a C type, e.g. C.lh_buf(x): the type must exist
-            assert re.search(r"\b" + name + r"\b", hdr), f"ml_hip.go uses C.{name}, which llamahip.h does not know"
-            continue
-        args = _call_args(go_code, m.end() - 1).strip()
-        n = 0 if not args else len(_split_args(args))
-        assert n == protos[name], f"ml_hip.go calls C.{name} with {n} arguments, llamahip.h declares {protos[name]}"
-        calls += 1
-    assert calls >= 30, calls
-    for name in set(re.findall(r"\bC\.((?:lh|LH)_[A-Za-z0-9_]+)\b", go_code)):
-        assert re.search(r"\b" + name + r"\b", hdr), f"ml_hip.go names C.{name}, which llamahip.h does not declare"
+        protos[m.group(1)] = [] if args in ("", "void") else [_norm_ctype(a) for a in _split_args(args)]
+    return protos
+
+
+def _go_arg_ctype(expr):
+    """The C type a cgo argument expression visibly has, or None when it is a plain Go variable (whose declaration is checked elsewhere)."""
+    e = expr.strip()
+    m = re.match(r"^\(\s*(\*+)\s*C\.([A-Za-z0-9_]+)\s*\)\s*\(", e)       # (*C.float)(unsafe.Pointer(...))
+    if m:
+        return m.group(2), len(m.group(1))
+    m = re.match(r"^C\.([A-Za-z0-9_]+)\s*\(", e)                             # C.uint32_t(x)
+    if m:
+        return m.group(1), 0
+    if e.startswith("unsafe.Pointer("):
+        return "void", 1
+    return None
+
+
+CGO_NAMES = {"int": "int", "uint": "unsigned", "float": "float", "double": "double", "char": "char", "size_t": "size_t"}
+
+
+def test_go_shim_calls_only_declared_functions_with_the_declared_arity():
+    """The cgo shim cannot be compiled here (no Go toolchain).  What can be checked without one: every C.lh_* it calls is a function
+    llamahip.h declares, called with the number of arguments the prototype has; every argument whose C type is visible in the call (an
+    explicit conversion C.T(x), a pointer cast (*C.T)(unsafe.Pointer(..)), unsafe.Pointer(..)) has the prototype's base type and pointer depth;
+    every C.lh_* / C.LH_* type or constant it names exists; every field of a C struct it writes (composite literals, the lh_tensor records of
+    hipGraphCompute) is a field of that struct; ml_hip.go stays the GraphCompute path (pods and pipelines live in ml_hip_pods.go)."""
+    hdr = _c_header()
+    protos = _prototypes(hdr)
+    structs = {m.group(1): set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])?\s*[,;]", m.group(2)))
+               for m in re.finditer(r"typedef struct (lh_[a-z_]+) \{(.*?)\} \1;", hdr, flags=re.S)}
+    calls = typed = 0
+    for fname in GO_FILES:
+        go_code = _go_code(fname)
+        for m in re.finditer(r"\bC\.(lh_[A-Za-z0-9_]+)\s*\(", go_code):
+            name = m.group(1)
+            if name not in protos:
+                # a conversion to a C type, e.g. C.lh_buf(x): the type must exist
+                assert re.search(r"\b" + name + r"\b", hdr), f"{fname} uses C.{name}, which llamahip.h does not know"
+                continue
+            args = _call_args(go_code, m.end() - 1).strip()
+            got = [] if not args else _split_args(args)
+            assert len(got) == len(protos[name]), f"{fname} calls C.{name} with {len(got)} arguments, llamahip.h declares {len(protos[name])}"
+            for k, (expr, (base, depth)) in enumerate(zip(got, protos[name])):
+                if expr.strip() == "nil":
+                    assert depth >= 1, f"{fname}: C.{name} argument {k} is nil but the parameter is {base}"
+                    continue
+                vis = _go_arg_ctype(expr)
+                if vis is None:
+                    continue
+                gbase, gdepth = CGO_NAMES.get(vis[0], vis[0]), vis[1]
+                assert (gbase, gdepth) == (base, depth), f"{fname}: C.{name} argument {k} is {gbase}{'*' * gdepth}, llamahip.h declares {base}{'*' * depth}"
+                typed += 1
+            calls += 1
+        for name in set(re.findall(r"\bC\.((?:lh|LH)_[A-Za-z0-9_]+)\b", go_code)):
+            assert re.search(r"\b" + name + r"\b", hdr), f"{fname} names C.{name}, which llamahip.h does not declare"
+        for m in re.finditer(r"\bC\.(lh_[a-z_]+)\{([^}]*)\}", go_code):           # composite literals
+            for field in re.findall(r"\b([a-z_0-9]+)\s*:", m.group(2)):
+                assert field in structs[m.group(1)], f"{fname}: {m.group(1)} has no field {field}"
+    assert calls >= 30 and typed >= 25, (calls, typed)
+    contract = _go_code("ml_hip.go")
+    fields = set(re.findall(r"\bo\.([a-z_0-9]+)", contract))                         # o := &arr[i], a *C.lh_tensor
+    assert fields and fields <= structs["lh_tensor"], fields - structs["lh_tensor"]
+    assert len(open(os.path.join(ROOT, "llama.go_amd", "go", "ml_hip.go")).read().splitlines()) <= 280
+    assert not re.search(r"\bC\.lh_(batch|pipeline|comm|llama)_", contract), "ml_hip.go is the GraphCompute path only"
 
 
 def test_host_library_and_oracle_export_the_mirror_api(built):
