@@ -34,8 +34,8 @@ struct StreamArgs {
     const float* ws[3];  // block-int8 models (k_stream_q8b): w[] are the int8 planes [M][K], ws[] the fp32 scales [M][K / 32]
     const float* x;      // activations [n][K], row c at x + c * ldx
     uint32_t groups, M, K, n, ldx, ldy;
-#if defined(STREAM_TRACE) || defined(Q8B_TRACE)
-    unsigned long long* trace;   // tools/stream_mm_check: [4 waves][8] shader-clock totals of workgroup 0's loop phases
+#ifdef Q8B_TRACE
+    unsigned long long* trace;   // tools/q8b_probe: timeline stamps of one workgroup
 #endif
     // fused epilogues of k_stream_mm2 (the launches llama.Eval makes, llama.go:255-297 and :346-361)
     uint32_t epi;        // ST_EPI_*
@@ -213,42 +213,20 @@ __global__ __launch_bounds__(ST_TH) void k_stream_mm(const StreamArgs a) {
     __builtin_amdgcn_sched_barrier(0);   // keep the issue order: the scheduler swapped the two groups, and the first stash then had to drain both
     issue(wb, xb, 1);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef STREAM_TRACE
-    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-// (sched_barrier on both sides: without it the compiler samples the clock in the middle of a phase - the MFMA waves' "compute" stamp of
-// the round-2 traces sits behind the 4th of 144 MFMAs, profiles/r02d_stream_traffic_probe.txt: only per-chunk SUMS of those are meaningful)
-#define ST_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[i] += tn_ - tl; tl = tn_; \
-                         __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define ST_STAMP(i) do { } while (0)
-#endif
     for (uint32_t ch = 0; ch + 1 < nch; ch += 2) {
         barrier_lds_only();              // everybody is done with the image of the previous chunk
-        ST_STAMP(0);
         wait_vm<PER_SET>();
-        ST_STAMP(1);
         stash(wa, xa);
         issue(wa, xa, ch + 2);
-        ST_STAMP(2);
         __syncthreads();
-        ST_STAMP(3);
         compute();
-        ST_STAMP(4);
         barrier_lds_only();
-        ST_STAMP(0);
         wait_vm<PER_SET>();
-        ST_STAMP(1);
         stash(wb, xb);
         issue(wb, xb, ch + 3);
-        ST_STAMP(2);
         __syncthreads();
-        ST_STAMP(3);
         compute();
-        ST_STAMP(4);
     }
-#ifdef STREAM_TRACE
-    if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
-#endif
     if (nch & 1) {                       // odd chunk count: the last chunk sits in the first register set
         barrier_lds_only();
         wait_vm<PER_SET>();
@@ -572,36 +550,11 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
             }
         }
         f4 ws[NS][NW], xs[NS][NX], gs[NS];
-        // tools/stream_mm_check builds timing-only variants (-DSTREAM_PROBE=bits; results are wrong on purpose) that take one traffic class
-        // out of the loop with the instruction stream otherwise unchanged: 1 = every X load re-reads chunk 0 (L1 hits: no L2 -> CU activation
-        // traffic), 2 = X loads non-temporal, 4 = W loads temporal, 8 = every W load re-reads chunk 0 (no HBM stream).  0 in the product.
-#if defined(STREAM_TRACE) && defined(STREAM_PROBE)
-        constexpr int PROBE = STREAM_PROBE;
-#else
-        constexpr int PROBE = 0;
-#endif
-        // 16 = addresses as a uniform (SGPR) base that advances per chunk + a constant 32-bit lane offset (single matrix only: the
-        // checker's case), so the ~20 loads of a chunk need no vector ALU instruction: tests whether the v_lshl_add_u64 in front of every
-        // load is what keeps the loader waves waiting for the MFMA waves' burst to end.  It is: issue phase 5544 -> 1700 clocks per chunk
-        // at 48 rows, launch 114.1 -> 103.5 us.  TIMING ONLY: the loads are inline asm, invisible to the compiler's bookkeeping of
-        // registers with loads in flight (a checked run faults); a product version uses buffer loads with a scalar offset.
-        uint32_t wv[NW], xv[NX];
-        if constexpr (PROBE & 16) {
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                uint32_t rr = (uint32_t)i * RPP + rsub;
-                rr = rr < nt * 16 ? rr : nt * 16 - 1;
-                wv[i] = (rr * a.K + seg * 4) * 4u;
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                uint32_t c = (uint32_t)i * RPP + rsub;
-                c = c < a.n ? c : a.n - 1;
-                xv[i] = (c * a.ldx + seg * 4) * 4u;
-            }
-        }
+        // (Round 2-3's timing-only probe builds of this loader - one traffic class taken out at a time, uniform-base addressing - showed that the
+        // loads' vector address arithmetic waits for the MFMA burst: profiles/r02d_stream_traffic_probe.txt; they led to the buffer loads below
+        // and to k_stream_dma and are no longer part of the kernel.)
         auto issue = [&](f4 (&wr)[NW], f4 (&xr)[NX], f4& gq, uint32_t ch) {
-            const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC, k0w = (PROBE & 8) ? 0u : k0, k0x = (PROBE & 1) ? 0u : k0;
+            const uint32_t k0 = (ch < nch ? ch : nch - 1) * KC;
             if constexpr (BUF) {
                 const uint32_t so = k0 * 4u;     // bytes, uniform: the soffset operand
 #pragma unroll
@@ -611,29 +564,10 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
                 gq = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(gres, seg * 16u, so, 0));
                 return;
             }
-            if constexpr (PROBE & 16) {
-                const char* wb = (const char*)(a.w[0] + (size_t)t0 * 16 * a.K + kbase + k0w);   // uniform
-                const char* xb = (const char*)(a.x + kbase + k0x);
-                // written out: the compiler folds base + offset into a 64-bit VGPR address (one vector add per load) otherwise.  The waits
-                // for these loads are the explicit counted ones of the loop (the compiler does not see asm loads in its own counters).
-                const uint32_t gv = seg * 16;
 #pragma unroll
-                for (int i = 0; i < NW; ++i) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(wr[i]) : "v"(wv[i]), "s"(wb) : "memory");
+            for (int i = 0; i < NW; ++i) wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0));
 #pragma unroll
-                for (int i = 0; i < NX; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[i]) : "v"(xv[i]), "s"(xb) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gq) : "v"(gv), "s"(xb) : "memory");
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                if constexpr (PROBE & 4) wr[i] = *(gf4*)(uintptr_t)(wp[i] + k0w);
-                else wr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(wp[i] + k0w));
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                if constexpr (PROBE & 2) xr[i] = __builtin_nontemporal_load((gf4*)(uintptr_t)(xp[i] + k0x));
-                else xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0x);
-            }
+            for (int i = 0; i < NX; ++i) xr[i] = *(gf4*)(uintptr_t)(xp[i] + k0);
             gq = *(gf4*)(uintptr_t)(gp + k0);
         };
         auto stash = [&](const f4 (&wr)[NW], const f4 (&xr)[NX], const f4& gq, float* im) {
@@ -649,25 +583,15 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
             __builtin_amdgcn_sched_barrier(0);   // keep the issue order (the waits below count on it)
         }
         uint32_t ch = 0;
-#ifdef STREAM_TRACE
-        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-#endif
         for (; ch + NS <= nch; ch += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 wait_vm<(PER_SET * (NS - 1) < 64 ? PER_SET * (NS - 1) : 63)>();
-                ST_STAMP(0);
                 stash(ws[q], xs[q], gs[q], ((ch + q) & 1) ? img + IMG : img);   // chunk ch + q lives in image (ch + q) & 1
-                ST_STAMP(1);
                 issue(ws[q], xs[q], gs[q], ch + q + NS);
-                ST_STAMP(2);
                 __syncthreads();         // barrier `ch + q`: the image holds the chunk; the compute waves are done with what it held before
-                ST_STAMP(3);
             }
         }
-#ifdef STREAM_TRACE
-        if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
-#endif
         const uint32_t rem = nch - ch;   // < NS chunks left, already requested into sets 0..rem-1; nothing new is issued any more
 #pragma unroll
         for (int q = 0; q < NS - 1; ++q) {
@@ -718,9 +642,6 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
                                 acc[(h0 + hh) % KA][t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[hh][t][s], bf[hh][c][s], acc[(h0 + hh) % KA][t][c], 0, 0, 0);
             }
         };
-#ifdef STREAM_TRACE
-        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tl = __builtin_amdgcn_s_memtime();
-#endif
         if constexpr (PIPE) {
             constexpr int NO = MAXT + NCT;
             f4 ops[2][KB][NO];           // [buffer][k-block][A tiles, then B tiles]
@@ -772,14 +693,9 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
         } else {
         for (uint32_t ch = 0; ch < nch; ++ch) {
             __syncthreads();             // barrier `ch`
-            ST_STAMP(0);
             compute((ch & 1) ? img + IMG : img);
-            ST_STAMP(1);
         }
         }
-#ifdef STREAM_TRACE
-        if (blockIdx.x == gridDim.x / 2 && lane == 0) for (int i = 0; i < 5; ++i) a.trace[wave * 8 + i] = tph[i];
-#endif
     }
     __syncthreads();
     // the folded RMSNorm's per-token scales sit behind the image memory (written by the loader waves; read before `part` is touched)
@@ -910,10 +826,6 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
     } else {
         // ---- MFMA waves (k_stream_mm2's structure; operands out of the dense, swizzled image)
         const int cw = wave - 4;
-#ifdef STREAM_TRACE
-        // tools/stream_mm_check: shader clocks and 100 MHz real-time ticks of one MFMA wave's main loop -> the clock the launch ran at
-        const unsigned long long tr_c0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
         const uint32_t kq = CS == 2 ? (uint32_t)cw >> 1 : (uint32_t)cw, c0 = CS == 2 ? ((uint32_t)cw & 1u) * NCW : 0u;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
@@ -982,9 +894,6 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
                 for (int h = 0; h < KB; ++h) mfma_kb(ops[h]);
             }
         }
-#ifdef STREAM_TRACE
-        if (blockIdx.x == gridDim.x / 2 && tid == 256) { a.trace[40] = __builtin_amdgcn_s_memtime() - tr_c0; a.trace[41] = __builtin_amdgcn_s_memrealtime() - tr_r0; }
-#endif
     }
     __syncthreads();   // the images are dead (the loader waves have drained their DMAs: a pending LDS-DMA would land in `part`)
     stream_epilogue<MAXT, NCT, CS>(a, smem_raw, (uint32_t)(NIMG * IMGF), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });

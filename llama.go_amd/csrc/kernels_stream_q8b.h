@@ -116,13 +116,22 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows_s3(const float* __restrict
 __host__ __device__ constexpr size_t stream_q8b_image_bytes(int maxt, int xr, int kc) { return (size_t)maxt * 16 * kc + (size_t)maxt * (kc / 32) * 64 + (size_t)3 * xr * kc * 2; }
 constexpr int stream_q8b_xr(int nct, uint32_t n) { return (nct == 1 && n <= 8) ? 8 : nct * 16; }
 
-#ifndef Q8B_ABL
-#define Q8B_ABL 0   // tools/q8b_probe timing-only builds: 1 = no conversion, 2 = no MFMAs, 4 = no scale fma, 8 = no LDS operand reads after the first chunk, 16 = no DMA after the prologue, 32 / 64 / 128 = no scale / activation / weight reads after the first chunk
-#endif
+// tools/q8b_probe builds with -DQ8B_TRACE: a timeline of one workgroup's waves 0 and 15 in 100 MHz ticks (stamps 0 start, 2 first barrier
+// passed, 3 loop end, 6 epilogue start, 7 end; laps 1 computing, 4 waiting for its DMAs, 5 at barriers + issuing).  Nothing of it exists in the
+// product build.  (The timing-only ablation builds that found the compiler's vmcnt(0) - profiles/r05_q8b_ablation.txt - are in the git history.)
 #ifdef Q8B_TRACE
-#define Q8B_STAMP(i) do { if (trace_on) { __builtin_amdgcn_sched_barrier(0); tstamp[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define Q8B_TR_DECL unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlap = 0; const bool trace_on = a.trace != nullptr && blockIdx.x == gridDim.x / 2
+#define Q8B_TR_NOW() (__builtin_amdgcn_sched_barrier(0), tlap = __builtin_amdgcn_s_memrealtime(), __builtin_amdgcn_sched_barrier(0), tlap)
+#define Q8B_STAMP(i) do { if (trace_on && !tstamp[i]) tstamp[i] = Q8B_TR_NOW(); } while (0)
+#define Q8B_LAP_START() unsigned long long tl0 = Q8B_TR_NOW()
+#define Q8B_LAP(i) do { const unsigned long long tn = Q8B_TR_NOW(); tstamp[i] += tn - tl0; tl0 = tn; } while (0)
+#define Q8B_TR_STORE(nwv) do { if (trace_on && lane == 0 && (wave == 0 || wave == (nwv) - 1)) for (int i_ = 0; i_ < 8; ++i_) a.trace[(wave ? 8 : 0) + i_] = tstamp[i_]; } while (0)
 #else
-#define Q8B_STAMP(i) do { } while (0)
+#define Q8B_TR_DECL
+#define Q8B_STAMP(i)
+#define Q8B_LAP_START()
+#define Q8B_LAP(i)
+#define Q8B_TR_STORE(nwv)
 #endif
 
 // MAXT: 16-row weight tiles per workgroup; NCT: 16-token column tiles; KC: columns per chunk; NIMG: images in the ring;
@@ -150,11 +159,8 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef Q8B_TRACE
-    unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool trace_on = a.trace != nullptr && blockIdx.x == gridDim.x / 2;
+    Q8B_TR_DECL;
     Q8B_STAMP(0);
-#endif
     const uint32_t tiles_per_mat = a.M >> 4, T = tiles_per_mat * a.groups;
     const bool pairs = a.epi == ST_EPI_SILU_MUL;
     const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
@@ -236,7 +242,6 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
     };
 #pragma unroll
     for (int c = 0; c < NIMG - 1; ++c) if ((uint32_t)c < nch) issue((uint32_t)c);
-    Q8B_STAMP(1);
     // ---- this wave's share of a chunk: quant block kb for the tiles tg, tg + TG, ...
     const uint32_t kb = (uint32_t)wave % NB, tg = (uint32_t)wave / NB;
     f4m acc[TPW][NCT];
@@ -258,17 +263,9 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
         const uint32_t row = XR == 8 ? (r16 & 7u) : (uint32_t)c * 16 + r16;   // (rows 8..15 of a half tile: copies of 0..7, never stored)
         xoff[c] = W_BYTES + S_BYTES + (row * GRX + ((kb * 4 + slot) ^ xswz(row))) * 16;
     }
-#ifdef Q8B_TRACE
-    unsigned long long twait = 0, tbar = 0, tcomp = 0;
-#endif
-    u4 xo[3][NCT];
-    uint2 raw[TPW];
-    float d[TPW];
     for (uint32_t ch = 0; ch < nch; ++ch) {
         const char* im = smem_raw + (size_t)(ch % NIMG) * IMG_BYTES;
-#ifdef Q8B_TRACE
-        const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
-#endif
+        Q8B_LAP_START();
         // this wave's pieces of chunk ch have landed; the younger chunks' (min(NIMG - 2, chunks left) of them) may still be in flight
         {
             const uint32_t left = nch - 1 - ch;
@@ -276,36 +273,27 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
             else if (NIMG >= 4 && left == 1) wait_vm<(NIW < 64 ? NIW : 63)>();
             else wait_vm<0>();
         }
-#ifdef Q8B_TRACE
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long tb = __builtin_amdgcn_s_memrealtime();
-#endif
+        Q8B_LAP(4);
         barrier_lds_only();                     // barrier ch: every piece of chunk ch is in its image, and everybody has left chunk ch - 1's ...
-        if ((Q8B_ABL & 16) == 0 && ch + NIMG - 1 < nch) issue(ch + NIMG - 1);   // ... which takes chunk ch + NIMG - 1
-#ifdef Q8B_TRACE
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long tc = __builtin_amdgcn_s_memrealtime();
-        if (ch == 0) tstamp[2] = tc;
-#endif
-        if ((Q8B_ABL & (8 | 64)) == 0 || ch == 0) {
+        if (ch + NIMG - 1 < nch) issue(ch + NIMG - 1);   // ... which takes chunk ch + NIMG - 1
+        Q8B_LAP(5);
+        Q8B_STAMP(2);
+        u4 xo[3][NCT];
+        uint2 raw[TPW];
+        float d[TPW];
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int c = 0; c < NCT; ++c) xo[p][c] = *(const u4*)(im + xoff[c] + (size_t)p * XP_BYTES);
-        }
-        if ((Q8B_ABL & (8 | 128)) == 0 || ch == 0) {
 #pragma unroll
-        for (int j = 0; j < TPW; ++j) raw[j] = *(const uint2*)(im + woff[j]);
-        }
-        if ((Q8B_ABL & (8 | 32)) == 0 || ch == 0) {
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) d[j] = *(const float*)(im + soff[j]);
+        for (int j = 0; j < TPW; ++j) {
+            raw[j] = *(const uint2*)(im + woff[j]);
+            d[j] = *(const float*)(im + soff[j]);
         }
         // int8 -> bf16: (float)q exact, its high half IS the bf16; v_perm_b32 packs two high halves
         u4 wb[TPW];
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-            if constexpr ((Q8B_ABL & 1) != 0) { wb[j] = u4{raw[j].x, raw[j].y, raw[j].x, raw[j].y}; continue; }
             const int d0 = (int)raw[j].x, d1 = (int)raw[j].y;
             const uint32_t f0 = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d0)), f1 = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d0 >> 8));
             const uint32_t f2 = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d0 >> 16)), f3 = __builtin_bit_cast(uint32_t, (float)(d0 >> 24));
@@ -318,42 +306,26 @@ __global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
         for (int c = 0; c < NCT; ++c) {
             // block sums, small pieces first; the wave's tiles interleaved so that consecutive MFMAs are independent
             f4m ps[TPW];
-            if constexpr ((Q8B_ABL & 2) != 0) {
-#pragma unroll
-                for (int j = 0; j < TPW; ++j) ps[j] = __builtin_bit_cast(f4m, wb[j] ^ xo[0][c] ^ xo[1][c] ^ xo[2][c]);
-            } else {
 #pragma unroll
             for (int j = 0; j < TPW; ++j) ps[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xo[2][c]), __builtin_bit_cast(bf16x8, wb[j]), f4m{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < TPW; ++j) ps[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xo[1][c]), __builtin_bit_cast(bf16x8, wb[j]), ps[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < TPW; ++j) ps[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xo[0][c]), __builtin_bit_cast(bf16x8, wb[j]), ps[j], 0, 0, 0);
-            }
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
-                if constexpr ((Q8B_ABL & 4) != 0) { acc[j][c] = __builtin_bit_cast(f4m, __builtin_bit_cast(u4, acc[j][c]) ^ __builtin_bit_cast(u4, ps[j])); continue; }
                 acc[j][c][0] = fmaf(d[j], ps[j][0], acc[j][c][0]); acc[j][c][1] = fmaf(d[j], ps[j][1], acc[j][c][1]);
                 acc[j][c][2] = fmaf(d[j], ps[j][2], acc[j][c][2]); acc[j][c][3] = fmaf(d[j], ps[j][3], acc[j][c][3]);
             }
         }
-#ifdef Q8B_TRACE
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long td = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_sched_barrier(0);
-        twait += tb - ta; tbar += tc - tb; tcomp += td - tc;
-#endif
+        Q8B_LAP(1);
     }
     Q8B_STAMP(3);
-#ifdef Q8B_TRACE
-    tstamp[4] = twait; tstamp[5] = tbar; tstamp[1] = tcomp;
-#endif
     __syncthreads();   // the images are dead
     Q8B_STAMP(6);
     stream_epilogue<MAXT, NCT, 1, true, NB>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t / TG][c]; });
-#ifdef Q8B_TRACE
     Q8B_STAMP(7);
-    if (trace_on && lane == 0 && (wave == 0 || wave == NWV - 1)) for (int i = 0; i < 8; ++i) a.trace[(wave ? 8 : 0) + i] = tstamp[i];
-#endif
+    Q8B_TR_STORE(NWV);
 }
 
 }  // namespace lh

@@ -278,11 +278,7 @@ static int gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name, int w
 // rows the decode stream carries: fp32 up to 8 (round 4; 32 FMAs per 16-byte load = a sixth of a CU's vector rate at the stream's pace),
 // block-int8 up to 4 (its 16 converts + 16 NC FMAs per load saturate the vector ALU from there on)
 static constexpr uint32_t GEMV_ROWS_MAX_F32 = 8, GEMV_ROWS_MAX_Q8 = 4;
-static uint32_t gemv_rows_max(int wtype) {
-    static int cap = -1;   // LLAMAHIP_ROWS_MAX=<n>: same-box A/B runs against the stream kernel (4 = round 3's split)
-    if (cap < 0) { const char* e = getenv("LLAMAHIP_ROWS_MAX"); cap = e ? atoi(e) : 1 << 20; }
-    return std::min<uint32_t>((uint32_t)cap, wtype == 7 ? GEMV_ROWS_MAX_Q8 : GEMV_ROWS_MAX_F32);
-}
+static uint32_t gemv_rows_max(int wtype) { return wtype == 7 ? GEMV_ROWS_MAX_Q8 : GEMV_ROWS_MAX_F32; }
 // every launch of a layer (and the lm_head on the last stage) has an n-row instantiation
 static bool rows_path_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n) {
     if (n > gemv_rows_max(m.wtype)) return false;
@@ -576,12 +572,8 @@ static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
     return 0;
 }
 // ---- k_stream_dma (kernels_stream.h): fp32 weights, two column tiles on, no folded norm.  Variant = (chunk length, images in the ring,
-// operand pipelining); LLAMAHIP_STREAM_V=<n> overrides the per-shape choice for same-box A/B runs (-1: k_stream_mm2 as in round 3).
-static int stream_dma_variant_env() {
-    static int v = -100;
-    if (v == -100) { const char* e = getenv("LLAMAHIP_STREAM_V"); v = e ? atoi(e) : -2; }
-    return v;   // -2: not set
-}
+// operand pipelining), chosen per shape by stream_dma_default_variant (the A/B switches of round 4, LLAMAHIP_STREAM_V / LLAMAHIP_ROWS_MAX, are gone:
+// profiles/r04_stream_dma_variants.txt and r04_ttft_round3_paths_same_session.json keep what they measured).
 constexpr int dma_nimg_fit(int maxt, int nct, int kc, int cap) {
     int n = (int)(160 * 1024 / ((size_t)(maxt + nct) * 16 * kc * 4));
     return n < cap ? n : cap;
@@ -641,8 +633,7 @@ static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name)
     if constexpr (NCT >= 2) {
         // (one column tile, 9..16 rows, stays on k_stream_mm2 with the norm folded into the launch: on the LDS-DMA kernel with the norm's own launch
         // in front it measured 6.12-6.14 ms per Eval against 5.63-5.68, 16 pods 5.91 against 5.81 ms per tick - profiles/r04_stream_one_column_tile_probe.txt)
-        const int ve = stream_dma_variant_env();
-        if (!a.ws[0] && !a.gamma && !a.tiled && ve != -1) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, ve >= 0 ? ve : stream_dma_default_variant(MAXT, NCT));
+        if (!a.ws[0] && !a.gamma && !a.tiled) return launch_stream_dma_v<MAXT, NCT>(ctx, a, name, stream_dma_default_variant(MAXT, NCT));
     }
     if constexpr (NCT > 6) return ST_NA;   // (k_stream_mm2 holds MAXT x NCT accumulator tiles per wave: up to six column tiles)
     else return launch_stream_kc<MAXT, NCT>(ctx, a, name);

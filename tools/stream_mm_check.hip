@@ -3,9 +3,8 @@
 // mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 4 specialised waves with LDS-DMA   (modes 3 / 5, the round-3 / round-4 block-int8 kernels, went with them in round 5: tools/q8b_probe)
 // loaders (k_stream_dma; STREAM_DMA_IMAGES=2..4 images in the ring, default 3; STREAM_DMA_PIPE=1 pipelined operands); ksplit S > 1 (mode 2 / 3 / 4): groups of S
 // workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
-// Built with -DSTREAM_PROBE=bits (tools/build_probes.sh -> stream_mm_check_p<bits>) the specialised kernel takes one traffic class out of
-// its loop (kernels_stream.h: 1 X from L1, 2 X non-temporal, 4 W temporal, 8 W from cache): timing only, run with STREAM_CHECK_SKIP=1.
-#define STREAM_TRACE
+// (The -DSTREAM_PROBE / STREAM_TRACE builds of rounds 2-4 - one traffic class taken out of the loop, per-phase shader clocks - went out of the
+// product header in round 5; their results are in profiles/r02d_stream_traffic_probe.txt, r03_stream_*.txt, r04_stream_*.txt.)
 #include "../llama.go_amd/csrc/kernels_stream.h"
 #include <cstdio>
 #include <cstdlib>
@@ -25,9 +24,6 @@ template <int MAXT, int NCT, int KC> static void run_kc(const StreamArgs& a, int
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k_stream_mm<MAXT, NCT, KC>), dim3(nCU), dim3(ST_TH), lds, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    { unsigned long long tr[32]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost)); const double nh = (double)(a.K / KC);
-      const char* nm[5] = {"lds-barrier", "wait loads", "stash+issue", "syncthreads", "compute"};
-      for (int w = 0; w < 4; w += 3) { printf("   wave %d, shader clocks per chunk:", w); for (int i = 0; i < 5; ++i) printf(" %s %.0f |", nm[i], tr[w * 8 + i] / nh); printf("\n"); } }
     printf("k_stream_mm<%d,%d,%d>: %.2f us per launch (same weights every launch: L2 / MALL may help), %.1f GB/s\n", MAXT, NCT, KC, ms * 200, (double)a.M * a.K * 4 / (ms * 200) / 1e3);
 }
 static int g_wgpcu = 1;   // STREAM_WGPCU=2: two workgroups per CU (grid 2 x #CU, LDS request = the images only; build with a 128-VGPR cap)
@@ -44,9 +40,6 @@ template <int MAXT, int NCT, int KC> static void run2_kc(const StreamArgs& a, in
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), lds, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    { unsigned long long tr[64]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost)); const double nh = (double)(a.K / KC);
-      printf("   loader wave 0, shader clocks per chunk: wait loads %.0f | stash %.0f | issue %.0f | barrier %.0f\n", tr[0] / nh, tr[1] / nh, tr[2] / nh, tr[3] / nh);
-      printf("   MFMA wave 4:                            barrier %.0f | compute %.0f\n", tr[32] / nh, tr[33] / nh); }
     printf("k_stream_mm2<%d,%d,%d%s> (specialised waves%s): %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, q8 ? ",int8" : "", a.ksplit > 1 ? ", K-split" : "", ms * 200,
            (double)a.M * a.K * (q8 ? 36.0 / 32 : 4.0) / (ms * 200) / 1e3);
     if (a.ksplit > 1) {
@@ -72,10 +65,6 @@ template <int MAXT, int NCT, int KC, int NIMG, bool PIPE, int CS = 1> static voi
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(2 * ST_TH), req, 0, a);
     CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    { unsigned long long tr[64]; CK(hipMemcpy(tr, a.trace, sizeof tr, hipMemcpyDeviceToHost));
-      const double mf = (double)(a.K / KC / (a.ksplit > 1 ? a.ksplit : 1)) * (KC / 16 / (4 / CS)) * 4 * MAXT * (NCT / CS);   // MFMAs of one wave's main loop
-      if (tr[41]) printf("   MFMA wave: %.0f shader clocks in %.2f us = %.2f GHz; %.0f MFMAs x 32 clocks = %.0f%% of them\n", (double)tr[40], tr[41] / 100.0, tr[40] / (tr[41] * 10.0), mf,
-                         100.0 * mf * 32 / (double)tr[40]); }
     printf("k_stream_dma<%d,%d,%d> with %d images%s%s: %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NCT, KC, NIMG, PIPE ? ", pipelined operands" : "", a.ksplit > 1 ? ", K-split" : "", ms * 200,
            (double)a.M * a.K * 4.0 / (ms * 200) / 1e3);
     if (a.ksplit > 1) {
@@ -147,7 +136,6 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dS, S.size() * 4)); CK(hipMemcpy(dS, S.data(), S.size() * 4, hipMemcpyHostToDevice));
     }
     StreamArgs a = {}; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
-    CK(hipMalloc(&a.trace, 512)); CK(hipMemset(a.trace, 0, 512));
     const uint32_t S = argc > 6 ? (uint32_t)atoi(argv[6]) : 1u;
     float* dP = nullptr;
     g_yfinal = dY;
