@@ -630,6 +630,10 @@ static int launch_stream_kc(lh_ctx* ctx, const StreamArgs& a, const char* name) 
 }
 template <int MAXT, int NCT>
 static int launch_stream_nct(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    // (one column tile, 9..16 rows, stays on k_stream_mm2 with the norm folded into the launch.  Round 5 built the sixteen-equal-waves LDS-DMA
+    // structure of k_stream_q8b for it, norm folded on the operand-read side (tools/kernels_stream_eq.h): correct, and slower on every 7B launch -
+    // w1|w3 72.0 us against 66-67, wq|wk|wv 43.3 / 39.5, wo 32.0 / 17.6, w2 79.3 / 37.6 at 16 rows - a workgroup barrier of sixteen waves costs
+    // ~0.45 us and fp32 chunks that fit the ring are 64 columns: 64..172 barriers per launch.  profiles/r05_stream_eq_probe.txt)
     if constexpr (NCT >= 2) {
         // (one column tile, 9..16 rows, stays on k_stream_mm2 with the norm folded into the launch: on the LDS-DMA kernel with the norm's own launch
         // in front it measured 6.12-6.14 ms per Eval against 5.63-5.68, 16 pods 5.91 against 5.81 ms per tick - profiles/r04_stream_one_column_tile_probe.txt)

@@ -1,11 +1,12 @@
 // tools/stream_mm_check.hip — k_stream_mm (csrc/kernels_stream.h) against a double-precision host product, with a map of which
 // (16-row tile, 16-column tile) blocks are wrong.  usage: stream_mm_check M K N [KC [mode [ksplit]]]
-// mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 4 specialised waves with LDS-DMA   (modes 3 / 5, the round-3 / round-4 block-int8 kernels, went with them in round 5: tools/q8b_probe)
+// mode: 0 first variant, 1 chunk-major weight copy, 2 specialised waves, 4 specialised waves with LDS-DMA, 6 sixteen equal waves (k_stream_eq: one column tile; STREAM_EQ_NORM=1 folds an RMSNorm)   (modes 3 / 5, the round-3 / round-4 block-int8 kernels, went with them in round 5: tools/q8b_probe)
 // loaders (k_stream_dma; STREAM_DMA_IMAGES=2..4 images in the ring, default 3; STREAM_DMA_PIPE=1 pipelined operands); ksplit S > 1 (mode 2 / 3 / 4): groups of S
 // workgroups split the contraction, k_stream_reduce_norm adds the partials (timed alone and with the reduce pass)
 // (The -DSTREAM_PROBE / STREAM_TRACE builds of rounds 2-4 - one traffic class taken out of the loop, per-phase shader clocks - went out of the
 // product header in round 5; their results are in profiles/r02d_stream_traffic_probe.txt, r03_stream_*.txt, r04_stream_*.txt.)
 #include "../llama.go_amd/csrc/kernels_stream.h"
+#include "kernels_stream_eq.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -93,7 +94,25 @@ template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const Strea
 template <int MAXT, int NCT, int KC> static void run_dma(const StreamArgs& a, int nCU) {
     if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
 }
+static int g_eq = 0;
+template <int MAXT, int NIMG> static void run_eq_img(const StreamArgs& a, int nCU) {
+    const size_t lds = std::max<size_t>(stream_eq_lds_bytes(MAXT, NIMG), 82 * 1024);
+    if (stream_eq_lds_bytes(MAXT, NIMG) > 160 * 1024) { printf("k_stream_eq<%d,%d>: images do not fit\n", MAXT, NIMG); return; }
+    auto kern = k_stream_eq<MAXT, NIMG>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(nCU), dim3(SEQ_TH), lds, 0, a);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(nCU), dim3(SEQ_TH), lds, 0, a);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("k_stream_eq<%d> with %d images%s: %.2f us per launch, %.1f GB/s of weight bytes\n", MAXT, NIMG, a.gamma ? ", folded norm" : "", ms * 200, (double)a.M * a.K * 4.0 / (ms * 200) / 1e3);
+}
+template <int MAXT> static void run_eq(const StreamArgs& a, int nCU) {
+    if (g_nimg == 2) run_eq_img<MAXT, 2>(a, nCU); else if (g_nimg == 3) run_eq_img<MAXT, 3>(a, nCU); else if (g_nimg == 5) run_eq_img<MAXT, 5>(a, nCU); else run_eq_img<MAXT, 4>(a, nCU);
+}
 template <int MAXT, int NCT> static void run(const StreamArgs& a, int nCU) {
+    if (g_eq) { if constexpr (NCT == 1) run_eq<MAXT>(a, nCU); else printf("k_stream_eq: one column tile\n"); return; }
     if constexpr (NCT >= 7) { run_dma<MAXT, NCT, 64>(a, nCU); return; }   // (mode 4 only: the other kernels are built for up to six column tiles)
     else {
     if (g_dma) { if (g_kc == 64) run_dma<MAXT, NCT, 64>(a, nCU); else run_dma<MAXT, NCT, 128>(a, nCU); return; }
@@ -110,6 +129,8 @@ int main(int argc, char** argv) {
     const bool tiled = argc > 5 && atoi(argv[5]) == 1;
     g_v2 = argc > 5 && (atoi(argv[5]) == 2 || atoi(argv[5]) == 3 || atoi(argv[5]) == 4);   // (mode 4 takes mode 2's dispatch over the tile counts)
     g_dma = argc > 5 && atoi(argv[5]) == 4;
+    g_eq = argc > 5 && atoi(argv[5]) == 6;
+    if (g_eq) g_v2 = 1;
     if (getenv("STREAM_DMA_IMAGES")) g_nimg = atoi(getenv("STREAM_DMA_IMAGES"));
     if (getenv("STREAM_DMA_PIPE")) g_pipe = atoi(getenv("STREAM_DMA_PIPE"));
     const bool q8 = false;
@@ -135,7 +156,18 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dW, Q.data(), Q.size(), hipMemcpyHostToDevice));
         CK(hipMalloc(&dS, S.size() * 4)); CK(hipMemcpy(dS, S.data(), S.size() * 4, hipMemcpyHostToDevice));
     }
-    StreamArgs a = {}; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
+    float* dG = nullptr;
+    std::vector<float> Gm(K, 1.0f);
+    if (getenv("STREAM_EQ_NORM")) {   // fold an RMSNorm: the checked product is W . (gamma * x * scale(x))
+        for (auto& v : Gm) v = 1.0f + 0.1f * rnd();
+        CK(hipMalloc(&dG, K * 4)); CK(hipMemcpy(dG, Gm.data(), K * 4, hipMemcpyHostToDevice));
+        for (uint32_t c = 0; c < N; ++c) {
+            double ss = 0; for (uint32_t k = 0; k < K; ++k) ss += (double)X[(size_t)c * K + k] * X[(size_t)c * K + k];
+            const float sc = (float)(1.0 / sqrt(ss / K + 1e-5));
+            for (uint32_t k = 0; k < K; ++k) X[(size_t)c * K + k] = Gm[k] * (X[(size_t)c * K + k] * sc);   // (the host product below runs on the normalised rows)
+        }
+    }
+    StreamArgs a = {}; a.gamma = dG; a.w[0] = dW; a.ws[0] = dS; a.y[0] = dY; a.x = dX; a.groups = 1; a.M = M; a.K = K; a.n = N; a.ldx = K; a.ldy = M; a.tiled = tiled ? 1u : 0u;
     const uint32_t S = argc > 6 ? (uint32_t)atoi(argv[6]) : 1u;
     float* dP = nullptr;
     g_yfinal = dY;
