@@ -306,8 +306,8 @@ __device__ __forceinline__ void stream_store_split3(const StreamArgs& a, uint32_
 // the MFMA waves are dealt as 2 K-groups x 2 column halves, MFMA wave w holds the sums of K-group w >> 1 for column tiles
 // (w & 1) NCT / 2 + c; two partials per tile meet instead of four.
 // TR (k_stream_q8b): the MFMA was issued transposed - a lane's four results are tokens 4 slot + i of ONE weight row (lane & 15).
-// NB > 0 (k_stream_q8b, sixteen equal waves): wave w holds the sums over quant block w % NB of every chunk for the tiles t with
-// t % (16 / NB) == w / NB; NB partials per tile meet.
+// NB > 0 (k_stream_q8b, equal waves): wave w holds the sums over quant block w % NB of every chunk for the tiles t with
+// t % (waves / NB) == w / NB; NB partials per tile meet.
 template <int MAXT, int NCT, int CS = 1, bool TR = false, int NB = 0, typename AccFn>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_raw, uint32_t lds_floats, const float* scales, uint32_t t0, uint32_t nt, uint32_t ks,
                                                 uint32_t tiles_per_mat, AccFn&& acc_of) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
     };
     constexpr int NC = NCT * 16, NKG = NB > 0 ? NB : 4 / CS, NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
-    constexpr int TGX = NB > 0 ? 16 / NB : 1;
+    const uint32_t TGX = NB > 0 ? ((uint32_t)blockDim.x >> 6) / (uint32_t)NB : 1u;   // tile groups of an equal-waves workgroup
     static_assert(CS == 1 || (CS == 2 && NCT % 2 == 0), "column split");
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = (uint32_t)NKG * NC * 16;
@@ -347,7 +347,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         if (NB > 0 || wave >= 4) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt && (NB == 0 || (uint32_t)(t % TGX) == tgw)) {
+                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt && (NB == 0 || (uint32_t)t % TGX == tgw)) {
 #pragma unroll
                     for (int c = 0; c < NCW; ++c) {
                         const f4m v = acc_of(t, c);

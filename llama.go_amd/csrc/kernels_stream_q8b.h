@@ -137,12 +137,13 @@ constexpr int stream_q8b_xr(int nct, uint32_t n) { return (nct == 1 && n <= 8) ?
 // MAXT: 16-row weight tiles per workgroup; NCT: 16-token column tiles; KC: columns per chunk; NIMG: images in the ring;
 // XR: activation rows staged per plane (8: launches of up to eight token rows stage half a column tile; else NCT * 16)
 constexpr int Q8B_TH = 1024;
-template <int MAXT, int NCT, int KC, int NIMG, int XR>
-__global__ __launch_bounds__(Q8B_TH) void k_stream_q8b(const StreamArgs a) {
+template <int MAXT, int NCT, int KC, int NIMG, int XR, int TH = Q8B_TH>
+__global__ __launch_bounds__(TH) void k_stream_q8b(const StreamArgs a) {
     static_assert(KC == 128 || KC == 256 || KC == 512, "chunk");
     static_assert(NIMG >= 2 && NIMG <= 4, "ring");   // (the product launches up to three)
     static_assert(XR == NCT * 16 || (NCT == 1 && XR == 8), "staged activation rows");
-    constexpr int NWV = Q8B_TH / 64;            // waves
+    constexpr int NWV = TH / 64;                // waves
+    static_assert(NWV >= KC / 32 && NWV % (KC / 32) == 0, "every quant block of a chunk needs its wave(s)");
     constexpr int NB = KC / 32;                 // quant blocks per chunk: 4 / 8 / 16
     constexpr int TG = NWV / NB;                // tile groups: 4 / 2 / 1
     constexpr int TPW = (MAXT + TG - 1) / TG;   // tiles per wave

@@ -1304,13 +1304,14 @@ static int resident_steps_swapping(Plan* p, uint32_t first_token, uint32_t* past
     std::vector<uint32_t> got, refeed;
     // records the tokens evaluated by steps [from, done): step j evaluated (j == 0 ? first_token : the id step j - 1 produced) at position pos0 + (j - from)
     auto learn = [&](uint32_t from, uint32_t pos0) -> int {
-        if (done == 0) return 0;
-        got.resize(done + 1);
         const uint32_t lead = (first_in_out && step0 >= 1) ? 1u : 0u;
+        if (done == 0 && !lead) return 0;
+        got.resize(done + 1);
         LH_HIP(ctx, hipMemcpyAsync(got.data() + 1 - lead, p->out_tokens_dev + step0 - lead, (size_t)(done + lead) * 4, hipMemcpyDeviceToHost, ctx->stream));
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (lead) first_token = got[0];
+        if (lead) { first_token = got[0]; first_in_out = false; }   // (known from here on: later calls read the produced ids only)
         got.erase(got.begin());
+        if (done == 0) { pending = first_token; return 0; }
         for (uint32_t j = from; j < done; ++j) p->record(pos0 + (j - from), j == 0 ? first_token : got[j - 1]);
         pending = got[done - 1];
         return 0;
@@ -1373,8 +1374,9 @@ static bool q8b_shape_ok(lh_ctx* ctx, const ModelDesc& m) {
     if (m.last_stage() && (m.V % 16 || (m.V / 16 + ncu - 1) / ncu > 8)) return false;
     return true;
 }
-static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n_min) {
-    return n >= n_min && n <= STREAM_ROWS_Q8 && q8b_shape_ok(ctx, m);
+static constexpr uint32_t Q8B_PROMPT_ROWS = 2 * STREAM_ROWS_Q8;   // a prompt takes up to two 64-row passes (beyond: the tile GEMM, one pass)
+static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n_min, bool batch_rows = true) {
+    return n >= n_min && n <= (batch_rows ? STREAM_ROWS_Q8 : Q8B_PROMPT_ROWS) && q8b_shape_ok(ctx, m);
 }
 bool plan_batch_rows_ok(const Plan* p, uint32_t n) {
     const ModelDesc& m = p->md;
@@ -1416,7 +1418,11 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             StreamArgs fq = {};
             fq.epi = ST_EPI_QKV_ROPE; fq.q_out = p->q; fq.k_cache = m.kc + slot; fq.v_cache = m.vc + slot; fq.rope = p->rope; fq.hd = m.hd; fq.past = past;
             fq.rows = rows; fq.kv_off = slot;
-            Q8B_TRY(gemm_q8b_group(ctx, hs, pd, d, 3, wqkv, sqkv, nullptr, nullptr, d, d, n, d, "q8b_wqkv_rope", &fq), "wq|wk|wv");
+            for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8) {   // (a prompt of 65..128 tokens: two passes over the weights, still 1.5x faster than the tile GEMM)
+                const uint32_t nb = std::min(STREAM_ROWS_Q8, n - b0);
+                fq.q_out = p->q + (size_t)b0 * d; fq.past = past + b0;
+                Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)b0 * d, pd, d, 3, wqkv, sqkv, nullptr, nullptr, d, d, nb, d, "q8b_wqkv_rope", &fq), "wq|wk|wv");
+            }
         }
         if (rows) {   // rows of different streams: one query each, against its own cache up to its own position
             AttnArgs a = {};
@@ -1434,19 +1440,26 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             if ((rc = launch_attention(ctx, a, past + n))) return rc;
         }
         // wo + residual + RMSNorm * ffn_norm -> planes   (llama.go:336-351)
-        Q8B_TRY(gemm_q8b_split(ctx, L.wo, L.s_wo, as, pd, d, d, d, n, x, p->xb, L.ffn_norm, nullptr, hs, pd, "q8b_wo_ksplit"), "wo");
+        for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8)
+            Q8B_TRY(gemm_q8b_split(ctx, L.wo, L.s_wo, as + (size_t)b0 * d, pd, d, d, d, std::min(STREAM_ROWS_Q8, n - b0), x + (size_t)b0 * d, p->xb + (size_t)b0 * d, L.ffn_norm, nullptr,
+                                   hs + (size_t)b0 * d, pd, "q8b_wo_ksplit"), "wo");
         {   // w1|w3 -> silu(w1 h) * (w3 h) -> planes   (llama.go:354-361)
             const float* w13[2] = {L.w1, L.w3};
             const float* s13[2] = {L.s_w1, L.s_w3};
             StreamArgs fa = {};
             fa.epi = ST_EPI_SILU_MUL; fa.ys = gs; fa.ys_plane = pf; fa.ldys = F;
-            Q8B_TRY(gemm_q8b_group(ctx, hs, pd, d, 2, w13, s13, nullptr, nullptr, F, d, n, F, "q8b_w1w3_silu", &fa), "w1|w3");
+            for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8) {
+                fa.ys = gs + (size_t)b0 * F;
+                Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)b0 * d, pd, d, 2, w13, s13, nullptr, nullptr, F, d, std::min(STREAM_ROWS_Q8, n - b0), F, "q8b_w1w3_silu", &fa), "w1|w3");
+            }
         }
         {   // w2 + residual (+ the next layer's first norm, or the final norm, on the reduce pass)   (llama.go:363-372)
             const bool last = il + 1 == m.layer1;
             float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
             const float* next_gamma = !last ? m.layers[il + 1].attn_norm : (m.last_stage() ? m.norm : nullptr);
-            Q8B_TRY(gemm_q8b_split(ctx, L.w2, L.s_w2, gs, pf, F, d, F, n, p->xb, y, next_gamma, (last && m.last_stage()) ? p->h : nullptr, next_gamma ? hs : nullptr, pd, "q8b_w2_ksplit"), "w2");
+            for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8)
+                Q8B_TRY(gemm_q8b_split(ctx, L.w2, L.s_w2, gs + (size_t)b0 * F, pf, F, d, F, std::min(STREAM_ROWS_Q8, n - b0), p->xb + (size_t)b0 * d, y + (size_t)b0 * d, next_gamma,
+                                       (last && m.last_stage()) ? p->h + (size_t)b0 * d : nullptr, next_gamma ? hs + (size_t)b0 * d : nullptr, pd, "q8b_w2_ksplit"), "w2");
             h_ready = next_gamma != nullptr;
         }
         x = p->xa;
@@ -1455,7 +1468,10 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
     if (m.last_stage()) {   // lm_head on the rows the caller reads (llama.go:374-384, 394-401); hs / p->h hold RMSNorm * norm of every row
         const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
         const float* wv = m.output; const float* sv = m.s_output; float* yv = p->logits + (size_t)r0 * m.V;
-        Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)r0 * d, pd, d, 1, &wv, &sv, &yv, nullptr, m.V, d, nr, m.V, "q8b_lmhead"), "lm_head");
+        for (uint32_t b0 = 0; b0 < nr; b0 += STREAM_ROWS_Q8) {
+            float* yb = yv + (size_t)b0 * m.V;
+            Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)(r0 + b0) * d, pd, d, 1, &wv, &sv, &yb, nullptr, m.V, d, std::min(STREAM_ROWS_Q8, nr - b0), m.V, "q8b_lmhead"), "lm_head");
+        }
     }
     LH_HIP(ctx, hipGetLastError());
 #undef Q8B_TRY
@@ -1563,7 +1579,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         return 0;
     }
     // block-int8: 3..48 rows on the stream kernel's dequantising loader
-    const bool q8_stream = q8_stream_ok(ctx, m, n, 3);
+    const bool q8_stream = q8_stream_ok(ctx, m, n, 3, bc != nullptr);
     if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
         // path produces for them), logits row i from step i like llama.go:384.  n >= 32 takes the dequantising GEMM below.

@@ -11,6 +11,9 @@
 #include <vector>
 #include <cmath>
 #include <algorithm>
+#ifndef Q8B_PROBE_TH
+#define Q8B_PROBE_TH 1024
+#endif
 using namespace lh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 static int g_kc = 256, g_nimg = 0;
@@ -28,11 +31,13 @@ template <typename F> static double time_us(F&& launch, int ncopies) {
 template <int MAXT, int NCT, int KC, int NIMG, int XR> static void run_b(const Copies& c, int nCU, double wbytes) {
     if constexpr (NIMG >= 2) {
     const size_t lds = (size_t)NIMG * stream_q8b_image_bytes(MAXT, XR, KC);
-    auto kern = k_stream_q8b<MAXT, NCT, KC, NIMG, XR>;
+    constexpr int TH = (KC == 256 && Q8B_PROBE_TH == 512) ? 512 : 1024;
+    auto kern = k_stream_q8b<MAXT, NCT, KC, NIMG, XR, TH>;
     const size_t req = std::max<size_t>(lds, 82 * 1024);
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)req));
     const uint32_t S = c.a[0].ksplit > 1 ? c.a[0].ksplit : 1;
-    const double us = time_us([&](int i) { hipLaunchKernelGGL(kern, dim3(nCU / S * S), dim3(Q8B_TH), req, 0, c.a[i]); }, (int)c.a.size());
+    const double us = time_us([&](int i) { hipLaunchKernelGGL(kern, dim3(nCU / S * S), dim3(TH), req, 0, c.a[i]); }, (int)c.a.size());
+    printf("%d threads: ", TH);
     printf("k_stream_q8b<%d,%d,%d,%d,%d>%s (bf16 x 3): %.2f us per launch, %.1f GB/s of weight bytes (LDS %zu B)\n", MAXT, NCT, KC, NIMG, XR, S > 1 ? " K-split" : "", us, wbytes / us / 1e3, lds);
 #ifdef Q8B_TRACE
     { unsigned long long tr[16]; CK(hipMemcpy(tr, c.a[0].trace, sizeof tr, hipMemcpyDeviceToHost));
