@@ -105,6 +105,9 @@ struct lh_ctx {
     float* splitk = nullptr;
     uint64_t splitk_floats = 0;
     uint64_t splitk_gen = 0;
+    // the activation rows of a long-prompt GEMM as three bf16 planes (k_gemm_b9); grows, never shrinks
+    uint16_t* xs3 = nullptr;
+    uint64_t xs3_elems = 0;
 };
 
 namespace lh {

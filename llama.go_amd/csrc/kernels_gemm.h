@@ -54,7 +54,12 @@ struct GemmArgs {
     float* v_cache;
     const double2* rope;
     uint32_t hd;
-#ifdef GEMM_CLOCK
+    // k_gemm_b9 (kernels_gemm_b9.h): X as three bf16 planes (x = hi + mid + lo exactly; row n of plane p at xs + p * xs_plane + n * ldxs, elements
+    // of 2 bytes); x above is then unused
+    const uint16_t* xs;
+    uint64_t xs_plane;
+    uint32_t ldxs;
+#if defined(GEMM_CLOCK) || defined(B9_TRACE)
     unsigned long long* clk;   // tools/gemm_probe.hip -DGEMM_CLOCK: shader clocks and 100 MHz ticks one workgroup spent in k_gemm_glds
 #endif
 };

@@ -10,6 +10,7 @@
 #include "kernels_sample.h"
 #include "kernels_stream.h"
 #include "kernels_stream_q8b.h"
+#include "kernels_gemm_b9.h"
 #include "kernels_rows.h"
 #include <math.h>
 #include <string.h>
@@ -833,6 +834,42 @@ static int gemm_q8b_split(lh_ctx* ctx, const float* wq, const float* wsc, const 
     return 0;
 }
 
+// fp32 weights, long prompts: the exact bf16 x 9 GEMM (kernels_gemm_b9.h) - 128 x 256 tiles, eight waves, X split into planes by one pass in
+// front (n K 10 bytes through HBM: ~1 % of the GEMM it feeds).  Per tile area one slab takes 0.62 (a partly filled round) to 0.73 (every CU
+// busy: the chip is then power-bound and clocks down) of k_gemm_glds' time, but the tiles are large: gemm_mfma_group takes it where rounds x slab
+// time beats the fp32 kernel's best shape.  13B at 1024 rows inside the model (profiles/r05_p13_kernel_trace.txt): wq|wk|wv 1040 us against
+// 1407, w1|w3 2030 against 2380, w2 1100 against 1290-1525, wo 424 against 450 (160 tiles of 128 x 256 against 256 of 128 x 160).
+static bool gemm_b9_ok(const GemmArgs& a) {
+    return a.N > 128 && !a.causal && a.splits <= 1 && gemm_dma_ok(a) && a.K >= 16 * GBK && a.K % 8 == 0;
+}
+static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name) {
+    auto kern = k_gemm_b9<1, 8, 4, 1, 2>;
+    const size_t lds = 2 * gemm_b9_stage_bytes(128, 256);
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, kern, lds, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    const uint64_t need = (uint64_t)3 * a.N * a.K;
+    if (need > ctx->xs3_elems) {
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->xs3) LH_HIP(ctx, hipFree(ctx->xs3));
+        ctx->xs3 = nullptr; ctx->xs3_elems = 0;
+        LH_HIP(ctx, hipMalloc((void**)&ctx->xs3, need * 2));
+        ctx->xs3_elems = need;
+    }
+    a.xs = ctx->xs3; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
+    {
+        TraceScope ts_(ctx->stream, "split3_rows");
+        Split3Args sa = {a.x, ctx->xs3, a.xs_plane, a.K, a.ldx, a.K};
+        hipLaunchKernelGGL(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
+    }
+    const uint64_t tiles = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4 * a.groups);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // fused != nullptr: GEMM_EPI_SILU_MUL (w = {w1, w3}, y[0] = gated output [n][M]) or GEMM_EPI_QKV_ROPE (w = {wq, wk, wv}; outputs in *fused) in
 // the epilogue of the LDS-DMA tile GEMM; returns ST_NA when the launch cannot take it (short prompt, split-K, register-staged kernel) and
 // the caller runs the plain GEMM + the separate pass.
@@ -864,6 +901,12 @@ int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, 
     // up to 64 rows: 64 x 128 tiles (half the matrix work of a 128-row tile whose upper half would be padding)
     if (n <= 64) return launch_gemm<2, 2, 1, 2>(ctx, a, name);
     const double c128 = cost(128, 1.0), c160 = cost(160, 1.03), c64 = cost(64, 1.10);
+    if (gemm_b9_ok(a)) {
+        const uint64_t tiles9 = (uint64_t)tn * ((a.M + 255) / 256) * a.groups;
+        const double unit = may_split ? 2.0 * 128 * GBK / (157.3e6 / 256.0) : 1.0;      // cost() is in microseconds when split-K is on the table
+        const double c9 = (double)((tiles9 + ncu - 1) / ncu) * (a.K / GBK + 8) * 256 * 0.62 * unit;
+        if (c9 < 0.97 * std::min(c128, std::min(c160, c64))) return launch_gemm_b9(ctx, a, name);
+    }
     if (c160 < c128 && c160 <= c64) return launch_gemm<4, 1, 1, 5>(ctx, a, name);
     if (c64 < c128) return launch_gemm<2, 2, 2, 1>(ctx, a, name);
     return launch_gemm<2, 2, 2, 2>(ctx, a, name);
@@ -2058,6 +2101,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     destroy_plans(ctx);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->splitk) hipFree(ctx->splitk);
+    if (ctx->xs3) hipFree(ctx->xs3);
     if (ctx->staging) hipHostFree(ctx->staging);
     if (ctx->out_pinned) hipHostFree(ctx->out_pinned);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);

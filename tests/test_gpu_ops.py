@@ -84,7 +84,9 @@ def assert_close(out, tol):
                                    (4096, 512, 64), (1024, 384, 130), (11008, 256, 33),
                                    # N >= 32: MFMA GEMMs.  K >= 512 -> persistent LDS-DMA kernel (ragged M and N, K = 512 edge,
                                    # more tiles than CUs); smaller K -> the register-staged kernel
-                                   (2048, 300, 200), (5120, 700, 257), (512, 256, 32), (480, 256, 40), (1024, 4200, 1100)])
+                                   (2048, 300, 200), (5120, 700, 257), (512, 256, 32), (480, 256, 40), (1024, 4200, 1100),
+                                   # long prompts x wide matrices: the exact bf16 x 9 GEMM (k_gemm_b9; ragged M and N, K = 512 edge)
+                                   (1024, 5000, 1100), (512, 5200, 1030), (2048, 10496, 513)])
 def test_mul_mat_weights(pair, K, M, N):
     r = rng(K + M + N)
     w = r.standard_normal((M, K)).astype(np.float32) / np.sqrt(K)
