@@ -216,6 +216,17 @@ def main():
         ids_host_loop, _ = c3.GreedyDecode(PROMPT, HEAD + K + 1, want_logits=False)
         t_c = time.perf_counter()
         eval_dt = (t_c - t_b) - (t_b - t_a)
+        # the same loop once more with the library's own timers on ("hipEvent around each lh_graph_compute"): device time
+        # and host time inside the contract call, summed over the K single-token computes (difference of the two runs, as above)
+        c3.TimeComputes(True)
+        c3.GreedyDecode(PROMPT, HEAD + 1, want_logits=False)
+        st_a = c3.ComputeStats()
+        c3.TimeComputes(True)
+        c3.GreedyDecode(PROMPT, HEAD + K + 1, want_logits=False)
+        st_b = c3.ComputeStats()
+        c3.TimeComputes(False)
+        n_calls = st_b["calls"] - st_a["calls"]
+        dev_us, in_call_us = st_b["device_us"] - st_a["device_us"], st_b["wall_us"] - st_a["wall_us"]
         c3.Eval(PROMPT, 0)
         tk = first
         torch.cuda.synchronize()
@@ -227,6 +238,11 @@ def main():
         result["eval_per_token_loop"] = {"tokens_per_s": round(K / eval_dt, 2), "ms_per_token": round(eval_dt / K * 1e3, 4),
                                          "ids_equal_resident_loop": [int(t) for t in ids_host_loop[:min(K, len(produced)) + 1]] == ([first] + [int(t) for t in produced])[:min(K, len(produced)) + 1],
                                          "driven_from_python_tokens_per_s": round(K / py_dt, 2),
+                                         "lh_graph_compute_hip_event_timed": {"calls": n_calls, "tokens_per_s": round(n_calls / max(dev_us, 1e-9) * 1e6, 2), "ms_per_call": round(dev_us / max(n_calls, 1) / 1e3, 4),
+                                                                              "note": "SURVEY 8d config 2: HIP events on the stream around everything one lh_graph_compute enqueues (lh_ctx_time_computes)"},
+                                         "inside_lh_graph_compute_wall": {"tokens_per_s": round(n_calls / max(in_call_us, 1e-9) * 1e6, 2), "ms_per_call": round(in_call_us / max(n_calls, 1) / 1e3, 4),
+                                                                          "note": "host clock from entry to return of the contract call (validate, match, enqueue, wait, pinned logits row); what is left of "
+                                                                                  "ms_per_token is the caller's graph build + flatten + argmax"},
                                          "note": "llama.Eval per token via ml_GraphCompute incl. host graph build, logits D2H and host argmax (not `value`)"}
         # ---- the reference's real generation loop: SampleTopPTopK (topK 40, topP 0.95, repeat penalty 1.10 — main.go:87-90) after every
         # Eval, sampler resident on the device (no logits D2H).  Decode rate = (t[K+1 samples] - t[1 sample]) / K, same prefill in both.

@@ -36,6 +36,8 @@ int llamago_DeviceCount(void);                       /* lh_device_count */
 int llamago_HbmReadProbe(uint64_t bytes, uint32_t repeats, float* gbps);   /* lh_hbm_read_probe on the model context's device */
 void llamago_SetStream(void* hip_stream);            /* HIP stream for contexts created from now on (NULL: a private one each) */
 int llamago_Sync(llama_context* c);                  /* waits for the context's stream */
+int llamago_TimeComputes(llama_context* c, int on);  /* lh_ctx_time_computes on the context llama_Eval computes in */
+int llamago_ComputeStats(llama_context* c, uint64_t* calls, double* wall_us, double* device_us);   /* lh_ctx_compute_stats */
 int llamago_LastGraphFused(ml_context* ctx);         /* 1 if the last ml_GraphCompute ran as the fused LLaMA plan */
 int llamago_GraphComputeNoFusion(ml_context* ctx, ml_graph* g);   /* ml_GraphCompute node by node with the generic kernels (op-level parity) */
 

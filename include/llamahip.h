@@ -116,6 +116,17 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* tensors, uint32_t n_leafs, ui
 int lh_node_read(lh_ctx* ctx, uint32_t index, uint64_t off_floats, float* dst, uint64_t n);
 /* 1 if the last lh_graph_compute ran as a fused LLaMA plan, 0 if node-by-node. */
 int lh_last_graph_fused(lh_ctx* ctx);
+/* Timing of a context's lh_graph_compute calls, the measurement SURVEY 8d config 2 names ("hipEvent around each lh_graph_compute"):
+ * device_us = sum over the calls of the time between an event recorded on the stream when the call starts and one recorded behind its last
+ * launch / copy; wall_us = sum of the host time spent inside the calls (validate, match, enqueue, the wait, the pinned copy of the row).
+ * Off by default (two event records per call); lh_ctx_time_computes(ctx, on) zeroes the sums. */
+typedef struct lh_compute_stats {
+    uint64_t calls;
+    double wall_us;
+    double device_us;
+} lh_compute_stats;
+int lh_ctx_time_computes(lh_ctx* ctx, int on);
+int lh_ctx_compute_stats(lh_ctx* ctx, lh_compute_stats* out);
 
 /* ---- convenience layer over the same fused plan executor (harnesses, bench, pipeline stages) ------
  * Describes the weights of llama.Model (llama.go:181-193) + one KV cache (llama.go:173-178) for the

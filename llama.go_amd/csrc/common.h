@@ -108,6 +108,11 @@ struct lh_ctx {
     // the activation rows of a long-prompt GEMM as three bf16 planes (k_gemm_b9); grows, never shrinks
     uint16_t* xs3 = nullptr;
     uint64_t xs3_elems = 0;
+    // lh_ctx_time_computes: events around each lh_graph_compute + host time inside it
+    bool tc_on = false, tc_end = false;
+    hipEvent_t tc_ev0 = nullptr, tc_ev1 = nullptr;
+    uint64_t tc_calls = 0;
+    double tc_wall_us = 0, tc_dev_us = 0;
 };
 
 namespace lh {

@@ -423,6 +423,21 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
     LH_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t total = n_leafs + n_nodes;
     if (total == 0) return LH_OK;
+    // lh_ctx_time_computes: one event in front of everything this call puts on the stream, one behind it (mark_end, in front of the call's
+    // last wait); the sums are taken when the call returns with both recorded
+    struct ComputeTimer {
+        lh_ctx* c; std::chrono::steady_clock::time_point t0;
+        ~ComputeTimer() {
+            if (!c->tc_on || !c->tc_end) return;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->tc_ev0, c->tc_ev1) != hipSuccess) return;
+            c->tc_calls++; c->tc_dev_us += (double)ms * 1e3;
+            c->tc_wall_us += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() / 1e3;
+        }
+    } compute_timer{ctx, tq0};
+    ctx->tc_end = false;
+    if (ctx->tc_on) LH_HIP(ctx, hipEventRecord(ctx->tc_ev0, ctx->stream));
+    auto mark_end = [&]() { if (ctx->tc_on && hipEventRecord(ctx->tc_ev1, ctx->stream) == hipSuccess) ctx->tc_end = true; };
     // ---- validate indices
     for (uint32_t i = 0; i < total; ++i) {
         const lh_tensor& t = T[i];
@@ -472,6 +487,7 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
                 }
             }
             if (!rc) {
+                mark_end();
                 LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 if (timing) fprintf(stderr, "[llamahip] graph_compute N=%u: validate %.1f us, match %.1f, find plan %.1f, enqueue %.1f, wait %.1f\n", m.N, us(tq0, tq1), us(tq1, tq2), us(tq2, tq3), us(tq3, tq4), us(tq4, now()));
                 ctx->last_ptr[total - 1] = p->logits;  // [N][V], the final node's layout (ne0 = V, ne1 = N)
@@ -534,6 +550,7 @@ int lh_graph_compute(lh_ctx* ctx, const lh_tensor* T, uint32_t n_leafs, uint32_t
     // ---- sequential walk (ml.go:1501-1526)
     for (uint32_t i = n_leafs; i < total; ++i)
         if ((rc = run_node(ctx, T, P, i))) return rc;
+    mark_end();
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return LH_OK;
 }
@@ -555,5 +572,22 @@ int lh_node_read(lh_ctx* ctx, uint32_t index, uint64_t off, float* dst, uint64_t
 }
 
 int lh_last_graph_fused(lh_ctx* ctx) { return ctx ? ctx->last_fused : 0; }
+
+int lh_ctx_time_computes(lh_ctx* ctx, int on) {
+    if (!ctx) return LH_EINVAL;
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->tc_ev0) {
+        LH_HIP(ctx, hipEventCreate(&ctx->tc_ev0));
+        LH_HIP(ctx, hipEventCreate(&ctx->tc_ev1));
+    }
+    ctx->tc_on = on != 0; ctx->tc_end = false;
+    ctx->tc_calls = 0; ctx->tc_wall_us = ctx->tc_dev_us = 0;
+    return LH_OK;
+}
+int lh_ctx_compute_stats(lh_ctx* ctx, lh_compute_stats* out) {
+    if (!ctx || !out) return LH_EINVAL;
+    out->calls = ctx->tc_calls; out->wall_us = ctx->tc_wall_us; out->device_us = ctx->tc_dev_us;
+    return LH_OK;
+}
 
 }  // extern "C"

@@ -2102,6 +2102,7 @@ void lh_ctx_destroy(lh_ctx* ctx) {
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->splitk) hipFree(ctx->splitk);
     if (ctx->xs3) hipFree(ctx->xs3);
+    if (ctx->tc_ev0) { hipEventDestroy(ctx->tc_ev0); hipEventDestroy(ctx->tc_ev1); }
     if (ctx->staging) hipHostFree(ctx->staging);
     if (ctx->out_pinned) hipHostFree(ctx->out_pinned);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);

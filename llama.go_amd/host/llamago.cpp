@@ -1195,6 +1195,15 @@ int llamago_QuantizeModelQ8(llama_model* m) {
     if (!rc) m->wtype = ML_TYPE_Q8_0;
     return rc;
 }
+int llamago_TimeComputes(llama_context* c, int on) { return c && c->mlctx && c->mlctx->hip ? lh_ctx_time_computes(c->mlctx->hip, on) : 1; }
+int llamago_ComputeStats(llama_context* c, uint64_t* calls, double* wall_us, double* device_us) {
+    lh_compute_stats st = {};
+    if (!c || !c->mlctx || !c->mlctx->hip || lh_ctx_compute_stats(c->mlctx->hip, &st)) return 1;
+    if (calls) *calls = st.calls;
+    if (wall_us) *wall_us = st.wall_us;
+    if (device_us) *device_us = st.device_us;
+    return 0;
+}
 int llamago_Sync(llama_context* c) { return lh_ctx_sync(c->mlctx->hip) ? halt_rc(lh_last_error(c->mlctx->hip)) : 0; }
 
 }  // extern "C"

@@ -302,6 +302,24 @@ class Context:
             raise MLError(f"llama_GreedyDecode: {self.ml.last_error()}")
         return list(out), lg
 
+    def TimeComputes(self, on=True):
+        """lh_ctx_time_computes: HIP events around every lh_graph_compute of this context; zeroes the sums."""
+        L = self.ml.lib
+        L.llamago_TimeComputes.restype = C.c_int
+        L.llamago_TimeComputes.argtypes = [VP, C.c_int]
+        if L.llamago_TimeComputes(self.h, 1 if on else 0):
+            raise MLError(f"llamago_TimeComputes: {self.ml.last_error()}")
+
+    def ComputeStats(self):
+        """-> {"calls", "wall_us", "device_us"} summed over the lh_graph_compute calls since TimeComputes()."""
+        L = self.ml.lib
+        L.llamago_ComputeStats.restype = C.c_int
+        L.llamago_ComputeStats.argtypes = [VP, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        n, w, d = C.c_uint64(0), C.c_double(0), C.c_double(0)
+        if L.llamago_ComputeStats(self.h, C.byref(n), C.byref(w), C.byref(d)):
+            raise MLError("llamago_ComputeStats failed")
+        return {"calls": int(n.value), "wall_us": float(w.value), "device_us": float(d.value)}
+
     def EnableEmbedding(self):
         """ModelParams.Embedding (llama.go:52): every Eval also leaves row N-1 of `embeddings` in lctx.Embedding (llama.go:414-419)."""
         self.ml.lib.llamago_EnableEmbedding.restype = None

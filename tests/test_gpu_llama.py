@@ -448,6 +448,28 @@ def test_committed_golden_vectors_on_the_gpu(product):
     m.free()
 
 
+def test_compute_timers_count_every_contract_call(product):
+    """lh_ctx_time_computes / lh_ctx_compute_stats: one entry per lh_graph_compute, device time inside host time, sums zeroed by a re-arm."""
+    hp = make_hparams(**SHAPES["small"], ctx=32)
+    m = product.NewSyntheticModel(hp, 5)
+    c = m.NewContext(32, 1)
+    c.Eval([1, 2, 3], 0)                      # timers off: nothing counted
+    assert c.ComputeStats()["calls"] == 0
+    c.TimeComputes(True)
+    c.Eval([1, 2, 3, 4], 0)
+    for i in range(5):
+        c.Eval([7 + i], 4 + i)
+    st = c.ComputeStats()
+    assert st["calls"] == 6
+    assert 0 < st["device_us"] <= st["wall_us"] < 1e6
+    c.TimeComputes(True)
+    assert c.ComputeStats() == {"calls": 0, "wall_us": 0.0, "device_us": 0.0}
+    c.TimeComputes(False)
+    c.Eval([3], 9)
+    assert c.ComputeStats()["calls"] == 0
+    c.free(); m.free()
+
+
 @pytest.mark.parametrize("n_prompt", [1, 3, 8, 20, 70, 130])
 def test_embeddings_of_a_fused_eval_match_oracle(product, oracle, n_prompt):
     """lctx.Embedding (llama.go:381, 414-419): row N-1 of the final norm * weight rows.  The fused plan's lm_head launches never write those
