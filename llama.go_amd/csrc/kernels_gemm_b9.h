@@ -219,4 +219,176 @@ __global__ __launch_bounds__(WN * WM * 64) void k_gemm_b9(const GemmArgs a) {
 #endif
 }
 
+// ---- block-int8 weights, long prompts: k_gemm_q8b3 --------------------------------------------------------------------------------------
+//     Y[n][m] (+ R[n][m]) = sum over quant blocks b of d[m][b] * sum_{k in b} q[m][k] * X[n][k]      (format ours; checker: dequantised fp32 weights)
+// |q| <= 127 is exact in bf16 and X arrives as three exact planes, so a block's inner sum is THREE bf16 MFMAs with exact products, taken into a
+// zeroed partial accumulator and folded into the running one with the block's scale (k_stream_q8b's arithmetic on a tile GEMM): 3 MFMAs of 32
+// clocks per 32 x 32 x 16 block where the dequantising k_gemm_q8 spends 8 of 64.  One slab of the ring = 32 columns = one quant block.
+// Shape: 128 x 256 tiles, eight waves of 128 x 32 (four 32 x 32 tiles each, B operand = the wave's 32 weight rows), NST stages of
+//   X [3][128][32 bf16] (k_gemm_b9's layout) | W [256 rows][32 int8] (16-byte half h of row r at h ^ ((r >> 3) & 1)) = 32 KB,
+// + three buffers [256][4] of scales: a DMA granule holds one row's scales of FOUR slabs, so slab s brings quarter s % 4 of the rows of scale
+// group s / 4 + 1, and a group is complete one slab before its first use.
+// Lane (li = lane & 31: weight row, lh = lane >> 5) holds, per slab, the 16 int8 of columns 16 lh .. 16 lh + 15 (ONE ds_read_b128); k-step
+// st uses bytes 8 st .. 8 st + 7, so X granule 2 lh + st stands on the other side (any pairing of columns inside a block is the same sum).
+// Schedule, per slab and wave: 24 MFMAs in twelve groups of two - tile pair (0, 1) through both k-steps x three planes (low plane first),
+// then pair (2, 3) - each group fenced with sched_barrier(0).  Behind the MFMAs of a group: the two X reads of the group three ahead (a ring
+// of four operand pairs; from group 9 on they come from the NEXT slab), four of the packed FMAs that fold the finished pair's partial sums
+// (pair (2, 3)'s are folded under the next slab's first groups), and from group 8 on - behind "slab kt + 1 has landed" + s_barrier - the next
+// slab's weight / scale reads, its int8 -> bf16 conversion and this wave's DMA pieces for slab kt + NST - 1 into the stage slab kt - 1 left.
+constexpr int Q3_BN = 128, Q3_BM = 256, Q3_XP = Q3_BN * 64, Q3_WOFF = 3 * Q3_XP, Q3_STAGE = Q3_WOFF + Q3_BM * 32;
+__host__ __device__ constexpr size_t gemm_q8b3_lds_bytes(int nst) { return (size_t)nst * Q3_STAGE + 3 * Q3_BM * 16; }
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <int NST>
+__global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
+    static_assert(NST >= 4, "ring depth");
+    constexpr int BN = Q3_BN, BM = Q3_BM, XP_BYTES = Q3_XP, W_OFF = Q3_WOFF, STAGE = Q3_STAGE, S_OFF = NST * Q3_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem_q3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS destinations and the wave-0 branch)
+    const int li = lane & 31, lh = lane >> 5;
+    const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
+    const uint32_t nk = a.K / GBK, nsg = nk / 4;            // slabs, scale groups (the launch requires K % 128 == 0)
+    const uint32_t G = gridDim.x;
+    const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_q3;
+    for (uint32_t wv = v0; wv < total; wv += G) {
+        const uint32_t g = wv / per_group, t = wv % per_group;
+        const uint32_t tm = t / tiles_n, tn = t % tiles_n;
+        const uint32_t n0 = tn * BN, m0 = tm * BM;
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
+        // this wave's DMA pieces of a slab: X row block `wave` of the three planes, W rows 32 wave .. + 31, (wave 0) the slab's quarter of the scales
+        const char* xsrc[3]; const char* wsrc;
+        {
+            const uint32_t row = (uint32_t)wave * 16 + (uint32_t)(lane >> 2), gs = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
+            const uint32_t n = n0 + row, nc = n < a.N ? n : a.N - 1;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) xsrc[pl] = (const char*)(a.xs + (size_t)pl * a.xs_plane + (size_t)nc * a.ldxs) + gs * 16;
+            const uint32_t wr = (uint32_t)wave * 32 + (uint32_t)(lane >> 1), wh = (uint32_t)(lane & 1) ^ ((wr >> 3) & 1u);
+            const uint32_t m = m0 + wr, mc = m < a.M ? m : a.M - 1;
+            wsrc = (const char*)a.w[g] + (size_t)mc * a.K + wh * 16;
+        }
+        auto ssrc = [&](uint32_t qd) {     // (wave 0) this lane's row of scale quarter qd
+            const uint32_t sm = m0 + qd * 64 + (uint32_t)lane, smc = sm < a.M ? sm : a.M - 1;
+            return (const char*)(a.ws[g] + (size_t)smc * nk);
+        };
+        auto dma = [&](uint32_t m0v, const char* sp) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(sp) : "memory", "m0");
+        };
+        // piece pc of slab `slab` (0..2: X planes, 3: W, 4: scales - wave 0 only)
+        auto issue1 = [&](uint32_t slab, int pc) {
+            const uint32_t ks = slab < nk ? slab : nk - 1;                  // past the end: the last slab again (uniform counts; harmless)
+            const uint32_t st = lds0 + (slab % NST) * STAGE;
+            if (pc < 3) dma(st + pc * XP_BYTES + (uint32_t)wave * 1024, xsrc[pc] + (size_t)ks * 64);
+            else if (pc == 3) dma(st + W_OFF + (uint32_t)wave * 1024, wsrc + (size_t)ks * 32);
+            else {
+                const uint32_t sgp = slab / 4 + 1, sgc = sgp < nsg ? sgp : nsg - 1, qd = slab % 4;
+                dma(lds0 + S_OFF + (sgp % 3) * (BM * 16) + qd * 1024, ssrc(qd) + (size_t)sgc * 16);
+            }
+        };
+        f16v acc[4][1], ps[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][0][e] = 0.f; ps[i][e] = 0.f; }
+        const uint32_t xrow = (uint32_t)li * 64, xsw = ((uint32_t)li >> 2) & 3u;
+        const uint32_t wpos = W_OFF + (uint32_t)(wave * 32 + li) * 32 + (((uint32_t)lh ^ (((uint32_t)li >> 3) & 1u)) * 16);
+        const uint32_t spos = S_OFF + (uint32_t)(wave * 32 + li) * 16;
+        u4 xr[4][2];            // ring of X operand pairs
+        u4 wq[2][2];            // [slab parity][k-step] converted weights
+        u4 raw;                 // next slab's 16 int8
+        float dsc[2] = {0.f, 0.f};     // [slab parity] block scale of this lane's weight row
+        auto read_x = [&](uint32_t slab, int grp) {   // group 0..11 of a slab -> ring slot grp % 4
+            const int pr = grp / 6, sp = grp % 6, st = sp / 3, pl = 2 - sp % 3;
+            const char* sb = smem_q3 + (size_t)(slab % NST) * STAGE + pl * XP_BYTES + xrow + (((uint32_t)(2 * lh + st)) ^ xsw) * 16;
+            xr[grp % 4][0] = *(const u4*)(sb + (2 * pr) * 32 * 64);
+            xr[grp % 4][1] = *(const u4*)(sb + (2 * pr + 1) * 32 * 64);
+        };
+        auto read_w = [&](uint32_t slab, int par) {
+            raw = *(const u4*)(smem_q3 + (size_t)(slab % NST) * STAGE + wpos);
+            dsc[par] = *(const float*)(smem_q3 + spos + ((slab / 4) % 3) * (BM * 16) + (slab % 4) * 4);
+        };
+        auto convert = [&](int par, int part) {       // part 0 / 1: k-step's eight int8 -> bf16 (8 conversions + 4 byte-permutes), pinned where it stands
+            if (part > 1) return;
+            const int d0 = (int)(part ? raw.z : raw.x), d1 = (int)(part ? raw.w : raw.y);
+            uint32_t c[8];
+            c[0] = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d0)); c[1] = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d0 >> 8));
+            c[2] = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d0 >> 16)); c[3] = __builtin_bit_cast(uint32_t, (float)(d0 >> 24));
+            c[4] = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d1)); c[5] = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d1 >> 8));
+            c[6] = __builtin_bit_cast(uint32_t, (float)(int)(signed char)(d1 >> 16)); c[7] = __builtin_bit_cast(uint32_t, (float)(d1 >> 24));
+            u4 o = u4{__builtin_amdgcn_perm(c[1], c[0], 0x07060302u), __builtin_amdgcn_perm(c[3], c[2], 0x07060302u), __builtin_amdgcn_perm(c[5], c[4], 0x07060302u), __builtin_amdgcn_perm(c[7], c[6], 0x07060302u)};
+            asm volatile("" : "+v"(o));
+            wq[par][part] = o;
+        };
+        auto fold = [&](int tile, int quarter, float d) {   // acc += d * ps for four of the tile's sixteen values (two packed FMAs)
+            const f2v d2 = {d, d};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 4 * quarter + 2 * h;
+                const f2v p2 = {ps[tile][e], ps[tile][e + 1]}, a2 = {acc[tile][0][e], acc[tile][0][e + 1]};
+                f2v r2 = __builtin_elementwise_fma(p2, d2, a2);
+                asm volatile("" : "+v"(r2));          // (keeps the FMA behind these MFMAs: left alone it sinks to the end of the loop body)
+                acc[tile][0][e] = r2.x; acc[tile][0][e + 1] = r2.y;
+            }
+        };
+        // one slab: multiply out of registers, prepare the next one
+        auto slab_body = [&](uint32_t kt, int par, bool first) {
+            const uint32_t nxt = kt + 1 < nk ? kt + 1 : kt;
+#pragma unroll
+            for (int grp = 0; grp < 12; ++grp) {
+                const int pr = grp / 6, sp = grp % 6, st = sp / 3;
+                if (grp == 8) {
+                    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (NST - 3)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 3)) : "memory");
+                    barrier_lds_only();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tile = 2 * pr + h;
+                    const f16v z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    ps[tile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, xr[grp % 4][h]), __builtin_bit_cast(bf16x8g, wq[par][st]), sp == 0 ? z : ps[tile], 0, 0, 0);
+                }
+                if (grp + 3 < 12) read_x(kt, grp + 3); else read_x(nxt, grp + 3 - 12);
+                if (grp < 4 && !first) { fold(2, grp, dsc[par ^ 1]); fold(3, grp, dsc[par ^ 1]); }          // the previous slab's pair (2, 3)
+                if (grp >= 6 && grp < 10) { fold(0, grp - 6, dsc[par]); fold(1, grp - 6, dsc[par]); }
+                if (grp == 8) read_w(nxt, par ^ 1);
+                if (grp >= 9) convert(par ^ 1, grp - 9);
+                if (grp >= 8 && grp < 11) issue1(kt + NST - 1, grp - 8);
+                if (grp == 11) { issue1(kt + NST - 1, 3); if (wave == 0) issue1(kt + NST - 1, 4); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // prologue: scale group 0, slabs 0 .. NST - 2
+        if (wave == 0) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) dma(lds0 + S_OFF + qd * 1024, ssrc((uint32_t)qd));
+        }
+#pragma unroll
+        for (int j = 0; j < NST - 1; ++j) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) issue1((uint32_t)j, pc);
+            if (wave == 0) issue1((uint32_t)j, 4);
+        }
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (NST - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_x(0, 0); read_x(0, 1); read_x(0, 2);
+        read_w(0, 0);
+        convert(0, 0); convert(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        slab_body(0, 0, true);
+        slab_body(1, 1, false);
+        for (uint32_t kt = 2; kt < nk; kt += 2) {
+            slab_body(kt, 0, false);
+            slab_body(kt + 1, 1, false);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { fold(2, q, dsc[1]); fold(3, q, dsc[1]); }      // the last slab's pair (2, 3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
+        gemm_store<4, 1>(a, acc, a.y[g], a.r[g], n0, m0 + (uint32_t)wave * 32, li, lh, a.ldy);
+    }
+}
+
 }  // namespace lh

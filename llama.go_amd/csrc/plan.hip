@@ -383,6 +383,49 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
     return 0;
 }
 
+// block-int8 weights, prompts beyond 128 rows: k_gemm_q8b3 (kernels_gemm_b9.h) - X split into three bf16 planes by one pass in front, three
+// exact-product MFMAs per quant block, 128 x 256 tiles.  Standalone at 1024 rows (profiles/r05_gemm_q8b3_probe.txt): 13B wq|wk|wv 524 us against
+// k_gemm_q8's 1546, wo 192 / 728, w1|w3 920 / 2566, w2 477 / 1870; 7B 386 / 860, 139 / 280, 569 / 1637, 350 / 732.  One slab of its tile costs
+// 0.53 of a 128 x 128 slab of k_gemm_q8 (1.2 us against 2.27): taken where rounds x that beats k_gemm_q8's own best (split-K included).
+static uint16_t* ensure_xs3(lh_ctx* ctx, uint64_t elems) {
+    if (elems > ctx->xs3_elems) {
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+        if (ctx->xs3) hipFree(ctx->xs3);
+        ctx->xs3 = nullptr; ctx->xs3_elems = 0;
+        if (hipMalloc((void**)&ctx->xs3, elems * 2) != hipSuccess) return nullptr;
+        ctx->xs3_elems = elems;
+    }
+    return ctx->xs3;
+}
+static bool gemm_q8b3_ok(const GemmArgs& a) {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    if (a.N <= 128 || a.K % 128 || a.K < 16 * GBK || a.ldx % 4 || !al(a.x)) return false;
+    for (uint32_t g = 0; g < a.groups; ++g)
+        if (!al(a.w[g]) || !al(a.ws[g])) return false;
+    return true;
+}
+static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name) {
+    auto kern = k_gemm_q8b3<4>;
+    const size_t lds = gemm_q8b3_lds_bytes(4);
+    static bool flags[16] = {};
+    int rc = set_lds_once(ctx, kern, lds, flags);
+    if (rc) return rc;
+    if (g_prepare_only) return 0;
+    uint16_t* xs = ensure_xs3(ctx, (uint64_t)3 * a.N * a.K);
+    if (!xs) LH_FAIL(ctx, LH_ENOMEM, "%s: planes of %u x %u activations", name, a.N, a.K);
+    a.xs = xs; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
+    {
+        TraceScope ts_(ctx->stream, "split3_rows");
+        Split3Args sa = {a.x, xs, a.xs_plane, a.K, a.ldx, a.K};
+        hipLaunchKernelGGL(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
+    }
+    const uint64_t tiles = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups;
+    ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K / 32 * 36 * a.groups);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
 // block-int8 weights, prompts beyond the 64 rows of k_stream_q8b (and shapes it is not built for): dequantising MFMA GEMM (k_gemm_q8), persistent one workgroup per CU
 static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, const float* const* wq, const float* const* wsc, float* const* y,
                          const float* const* r, uint32_t M, uint32_t K, uint32_t n, uint32_t ldy, const char* name) {
@@ -418,6 +461,12 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
         }
     }
     const uint32_t items = tiles * (a.splits ? a.splits : 1);
+    if (gemm_q8b3_ok(a)) {
+        const uint32_t nkf = K / GBK, sp = a.splits ? a.splits : 1;
+        const uint64_t tiles3 = (uint64_t)tn * ((M + 255) / 256) * groups;
+        const double c8 = (double)((items + ncu - 1) / ncu) * (nkf / sp + 8) * bm, c3 = (double)((tiles3 + ncu - 1) / ncu) * (nkf + 8) * 128 * 0.53;
+        if (c3 < c8) { a.splits = 0; a.part = nullptr; return launch_gemm_q8b3(ctx, a, name); }
+    }
     ProfScope ps(ctx->stream, name, (uint64_t)M * K / 32 * 36 * groups);
     int rc;
     static bool flags[3][16] = {};
@@ -849,14 +898,7 @@ static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name) {
     int rc = set_lds_once(ctx, kern, lds, flags);
     if (rc) return rc;
     if (g_prepare_only) return 0;
-    const uint64_t need = (uint64_t)3 * a.N * a.K;
-    if (need > ctx->xs3_elems) {
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->xs3) LH_HIP(ctx, hipFree(ctx->xs3));
-        ctx->xs3 = nullptr; ctx->xs3_elems = 0;
-        LH_HIP(ctx, hipMalloc((void**)&ctx->xs3, need * 2));
-        ctx->xs3_elems = need;
-    }
+    if (!ensure_xs3(ctx, (uint64_t)3 * a.N * a.K)) LH_FAIL(ctx, LH_ENOMEM, "%s: planes of %u x %u activations", name, a.N, a.K);
     a.xs = ctx->xs3; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
     {
         TraceScope ts_(ctx->stream, "split3_rows");

@@ -610,10 +610,11 @@ def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, lay
 
 
 @pytest.mark.parametrize("shape,n_prompt", [("small", 3), ("small", 8), ("small", 16), ("small", 20), ("small", 32), ("small", 33), ("small", 45), ("small", 48), ("small", 100), ("small", 300), ("13B", 72),
-                                            ("13B", 24)])
+                                            ("13B", 24), ("13B", 260), ("small", 129)])
 def test_block_int8_prefill_gemm_matches_dequantised_oracle(product, oracle, shape, n_prompt):
-    """Prompts of >= 32 tokens on a block-int8 model run the dequantising MFMA GEMM (k_gemm_q8: int8 + scale -> fl32(d*q) -> LDS ->
-    exact-f32 MFMA); shorter ones and every decode step run the int8 GEMV stream.  Both must agree with the checker's
+    """Prompts of more than 128 tokens on a block-int8 model run a tile GEMM - k_gemm_q8b3 (int8 x three bf16 planes of the activations,
+    three exact-product MFMAs per quant block) where its 128 x 256 tiles pay, else the dequantising k_gemm_q8 (int8 + scale -> fl32(d*q) ->
+    LDS -> fp32 MFMA); up to 128 tokens k_stream_q8b; single rows the int8 GEMV stream.  Both must agree with the checker's
     dequantise-then-fp32 evaluation, and with each other on the cache they share."""
     kw = dict(SHAPES[shape])
     kw["layers"] = 2 if shape == "small" else 1     # 13B shape: 5120 = 32 x 160 columns -> the 128 x 160 tile variant

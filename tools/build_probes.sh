@@ -10,3 +10,4 @@ cd "$(dirname "$0")/.."
 for p in pk_fma_probe sync_latency_probe; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -Wno-unused-result -o tools/$p tools/$p.hip || exit 1; done
 ls -la tools/stream_mm_check*
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -Illama.go_amd/csrc -Iinclude -DB9_TRACE -o tools/gemm_b9_probe tools/gemm_b9_probe.hip || exit 1   # k_gemm_b9: checked runs, timing against k_gemm_glds, shader clock
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-result -Illama.go_amd/csrc -Iinclude -o tools/gemm_q8b3_probe tools/gemm_q8b3_probe.hip || exit 1   # k_gemm_q8b3: checked runs + timing against k_gemm_q8
