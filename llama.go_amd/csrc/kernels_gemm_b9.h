@@ -247,15 +247,19 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS destinations and the wave-0 branch)
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
-    const uint32_t nk = a.K / GBK, nsg = nk / 4;            // slabs, scale groups (the launch requires K % 128 == 0)
+    // split-K exactly as in k_gemm_glds (few tiles: prompts of a few hundred rows): work item = (tile, K range ks), partial products to
+    // part[group][ks][N][M], k_splitk_reduce adds them in ks order (+ residual).  A range is a whole number of scale groups (4 slabs).
+    const uint32_t splits = a.splits ? a.splits : 1;
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups * splits;
+    const uint32_t nkf = a.K / GBK, nk = nkf / splits, nsg = nk / 4;   // slabs of the matrix, of one work item; its scale groups
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_q3;
     for (uint32_t wv = v0; wv < total; wv += G) {
-        const uint32_t g = wv / per_group, t = wv % per_group;
+        const uint32_t ks = wv % splits, wi = wv / splits;      // K range fastest: the pieces of one tile run side by side
+        const uint32_t g = wi / per_group, t = wi % per_group;
         const uint32_t tm = t / tiles_n, tn = t % tiles_n;
-        const uint32_t n0 = tn * BN, m0 = tm * BM;
+        const uint32_t n0 = tn * BN, m0 = tm * BM, ks0 = ks * nk;
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
         // this wave's DMA pieces of a slab: X row block `wave` of the three planes, W rows 32 wave .. + 31, (wave 0) the slab's quarter of the scales
         const char* xsrc[3]; const char* wsrc;
@@ -263,14 +267,14 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
             const uint32_t row = (uint32_t)wave * 16 + (uint32_t)(lane >> 2), gs = (uint32_t)(lane & 3) ^ ((row >> 2) & 3u);
             const uint32_t n = n0 + row, nc = n < a.N ? n : a.N - 1;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) xsrc[pl] = (const char*)(a.xs + (size_t)pl * a.xs_plane + (size_t)nc * a.ldxs) + gs * 16;
+            for (int pl = 0; pl < 3; ++pl) xsrc[pl] = (const char*)(a.xs + (size_t)pl * a.xs_plane + (size_t)nc * a.ldxs) + gs * 16 + (size_t)ks0 * 64;
             const uint32_t wr = (uint32_t)wave * 32 + (uint32_t)(lane >> 1), wh = (uint32_t)(lane & 1) ^ ((wr >> 3) & 1u);
             const uint32_t m = m0 + wr, mc = m < a.M ? m : a.M - 1;
-            wsrc = (const char*)a.w[g] + (size_t)mc * a.K + wh * 16;
+            wsrc = (const char*)a.w[g] + (size_t)mc * a.K + wh * 16 + (size_t)ks0 * 32;
         }
         auto ssrc = [&](uint32_t qd) {     // (wave 0) this lane's row of scale quarter qd
             const uint32_t sm = m0 + qd * 64 + (uint32_t)lane, smc = sm < a.M ? sm : a.M - 1;
-            return (const char*)(a.ws[g] + (size_t)smc * nk);
+            return (const char*)(a.ws[g] + (size_t)smc * nkf + ks0);
         };
         auto dma = [&](uint32_t m0v, const char* sp) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(sp) : "memory", "m0");
@@ -387,7 +391,8 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { fold(2, q, dsc[1]); fold(3, q, dsc[1]); }      // the last slab's pair (2, 3)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
-        gemm_store<4, 1>(a, acc, a.y[g], a.r[g], n0, m0 + (uint32_t)wave * 32, li, lh, a.ldy);
+        if (splits > 1) gemm_store<4, 1>(a, acc, a.part + ((size_t)(g * splits + ks) * a.N) * a.M, nullptr, n0, m0 + (uint32_t)wave * 32, li, lh, a.M);
+        else gemm_store<4, 1>(a, acc, a.y[g], a.r[g], n0, m0 + (uint32_t)wave * 32, li, lh, a.ldy);
     }
 }
 

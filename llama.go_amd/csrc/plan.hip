@@ -404,7 +404,24 @@ static bool gemm_q8b3_ok(const GemmArgs& a) {
         if (!al(a.w[g]) || !al(a.ws[g])) return false;
     return true;
 }
-static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name) {
+// cost of the launch in units of (slab of a 128 x 128 k_gemm_q8 tile) x 128, and the split-K factor that gives it: a K range is a whole number
+// of scale groups (4 slabs) and an even number of slabs >= 16; the reduce pass as in pick_splitk ((S + 1) x output through HBM + a launch)
+static double gemm_q8b3_cost(const GemmArgs& a, uint32_t ncu, uint32_t* splits_out) {
+    const uint32_t nkf = a.K / GBK;
+    const uint64_t tiles3 = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups;
+    const double unit = 128 * 0.53, us_per_unit = 2.27 / 128.0;
+    double best = (double)((tiles3 + ncu - 1) / ncu) * (nkf + 8) * unit;
+    uint32_t sp = 1;
+    if (a.M % 4 == 0 && a.ldy % 4 == 0)
+        for (uint32_t s2 = 2; s2 <= 16; s2 *= 2) {
+            if (nkf % (4 * s2) || nkf / s2 < 16) break;
+            const double c = (double)((tiles3 * s2 + ncu - 1) / ncu) * (nkf / s2 + 8) * unit + ((double)(s2 + 1) * a.groups * a.N * a.M * 4.0 / 4e6 + 5.0) / us_per_unit;
+            if (c < best * 0.95) { best = c; sp = s2; }
+        }
+    *splits_out = sp;
+    return best;
+}
+static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t splits) {
     auto kern = k_gemm_q8b3<4>;
     const size_t lds = gemm_q8b3_lds_bytes(4);
     static bool flags[16] = {};
@@ -414,14 +431,30 @@ static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name) {
     uint16_t* xs = ensure_xs3(ctx, (uint64_t)3 * a.N * a.K);
     if (!xs) LH_FAIL(ctx, LH_ENOMEM, "%s: planes of %u x %u activations", name, a.N, a.K);
     a.xs = xs; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
+    a.splits = splits > 1 ? splits : 0; a.part = nullptr;
+    if (splits > 1) {
+        const uint64_t need = (uint64_t)a.groups * splits * a.N * a.M;
+        if (need > ctx->splitk_floats) {
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
+            ctx->splitk = nullptr; ctx->splitk_floats = 0; ctx->splitk_gen++;
+            LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
+            ctx->splitk_floats = need;
+        }
+        a.part = ctx->splitk;
+    }
     {
         TraceScope ts_(ctx->stream, "split3_rows");
         Split3Args sa = {a.x, xs, a.xs_plane, a.K, a.ldx, a.K};
         hipLaunchKernelGGL(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
     }
-    const uint64_t tiles = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups;
+    const uint64_t items = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups * (splits > 1 ? splits : 1);
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K / 32 * 36 * a.groups);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(items, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    if (splits > 1) {
+        const uint64_t quads = (uint64_t)a.groups * a.N * (a.M / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+    }
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -463,9 +496,9 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
     const uint32_t items = tiles * (a.splits ? a.splits : 1);
     if (gemm_q8b3_ok(a)) {
         const uint32_t nkf = K / GBK, sp = a.splits ? a.splits : 1;
-        const uint64_t tiles3 = (uint64_t)tn * ((M + 255) / 256) * groups;
-        const double c8 = (double)((items + ncu - 1) / ncu) * (nkf / sp + 8) * bm, c3 = (double)((tiles3 + ncu - 1) / ncu) * (nkf + 8) * 128 * 0.53;
-        if (c3 < c8) { a.splits = 0; a.part = nullptr; return launch_gemm_q8b3(ctx, a, name); }
+        uint32_t sp3 = 1;
+        const double c8 = (double)((items + ncu - 1) / ncu) * (nkf / sp + 8) * bm, c3 = gemm_q8b3_cost(a, ncu, &sp3);
+        if (c3 < c8) return launch_gemm_q8b3(ctx, a, name, sp3);
     }
     ProfScope ps(ctx->stream, name, (uint64_t)M * K / 32 * 36 * groups);
     int rc;
