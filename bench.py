@@ -427,6 +427,18 @@ def main():
                                          "TFLOPs_per_s": round(fl13 / min(ts13) / 1e12, 1), "frac_of_fp32_mfma_peak_157.3": round(fl13 / min(ts13) / 157.3e12, 3),
                                          "note": "llama.Eval of 1024 tokens incl. host graph build and last-row logits D2H; lm_head for the one row Eval reads"}
                 c13.free()
+                if not args.int8:   # the same Eval on the same model with block-int8 weight matrices (config 4's format at config 3's size; k_gemm_q8b3)
+                    m13.QuantizeQ8()
+                    c13 = m13.NewContext(1024, 1)
+                    c13.Eval(toks13, 0)
+                    tq13 = []
+                    for _ in range(2):
+                        torch.cuda.synchronize()
+                        t13 = time.perf_counter()
+                        c13.Eval(toks13, 0)
+                        tq13.append(time.perf_counter() - t13)
+                    result["prefill_13b"]["block_int8_seconds"] = round(min(tq13), 4)
+                    c13.free()
                 m13.free()
             except Exception as e:  # a side measurement must never take the headline line down
                 result["prefill_13b"] = {"error": str(e)}

@@ -255,6 +255,9 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_q3;
+#ifdef B9_TRACE
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (uint32_t wv = v0; wv < total; wv += G) {
         const uint32_t ks = wv % splits, wi = wv / splits;      // K range fastest: the pieces of one tile run side by side
         const uint32_t g = wi / per_group, t = wi % per_group;
@@ -394,6 +397,9 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
         if (splits > 1) gemm_store<4, 1>(a, acc, a.part + ((size_t)(g * splits + ks) * a.N) * a.M, nullptr, n0, m0 + (uint32_t)wave * 32, li, lh, a.M);
         else gemm_store<4, 1>(a, acc, a.y[g], a.r[g], n0, m0 + (uint32_t)wave * 32, li, lh, a.ldy);
     }
+#ifdef B9_TRACE
+    if (a.clk && blockIdx.x == G / 2 && tid == 0) { a.clk[0] = __builtin_amdgcn_s_memtime() - clk_c0; a.clk[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
+#endif
 }
 
 }  // namespace lh
