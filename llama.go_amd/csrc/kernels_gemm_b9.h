@@ -248,10 +248,11 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
     // split-K exactly as in k_gemm_glds (few tiles: prompts of a few hundred rows): work item = (tile, K range ks), partial products to
-    // part[group][ks][N][M], k_splitk_reduce adds them in ks order (+ residual).  A range is a whole number of scale groups (4 slabs).
+    // part[group][ks][N][M], k_splitk_reduce adds them in ks order (+ residual).  A range is a whole number of scale groups (4 slabs); the
+    // ranges of one tile may differ by one group (344 slabs = 86 groups in eight ranges of 11 or 10).
     const uint32_t splits = a.splits ? a.splits : 1;
     const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups * splits;
-    const uint32_t nkf = a.K / GBK, nk = nkf / splits, nsg = nk / 4;   // slabs of the matrix, of one work item; its scale groups
+    const uint32_t nkf = a.K / GBK, ngr = nkf / 4;          // slabs and scale groups of the matrix
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_q3;
@@ -262,7 +263,8 @@ __global__ __launch_bounds__(512) void k_gemm_q8b3(const GemmArgs a) {
         const uint32_t ks = wv % splits, wi = wv / splits;      // K range fastest: the pieces of one tile run side by side
         const uint32_t g = wi / per_group, t = wi % per_group;
         const uint32_t tm = t / tiles_n, tn = t % tiles_n;
-        const uint32_t n0 = tn * BN, m0 = tm * BM, ks0 = ks * nk;
+        const uint32_t gr0 = (uint32_t)(((uint64_t)ks * ngr) / splits), nsg = (uint32_t)(((uint64_t)(ks + 1) * ngr) / splits) - gr0;   // this item's scale groups
+        const uint32_t n0 = tn * BN, m0 = tm * BM, ks0 = 4 * gr0, nk = 4 * nsg;                                                        // first slab, slabs
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
         // this wave's DMA pieces of a slab: X row block `wave` of the three planes, W rows 32 wave .. + 31, (wave 0) the slab's quarter of the scales
         const char* xsrc[3]; const char* wsrc;

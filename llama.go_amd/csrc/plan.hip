@@ -405,17 +405,18 @@ static bool gemm_q8b3_ok(const GemmArgs& a) {
     return true;
 }
 // cost of the launch in units of (slab of a 128 x 128 k_gemm_q8 tile) x 128, and the split-K factor that gives it: a K range is a whole number
-// of scale groups (4 slabs) and an even number of slabs >= 16; the reduce pass as in pick_splitk ((S + 1) x output through HBM + a launch)
+// of scale groups (4 slabs), >= 16 slabs, the ranges of a tile differ by at most one group; the reduce pass as in pick_splitk ((S + 1) x output through HBM + a launch)
 static double gemm_q8b3_cost(const GemmArgs& a, uint32_t ncu, uint32_t* splits_out) {
-    const uint32_t nkf = a.K / GBK;
+    const uint32_t nkf = a.K / GBK, ngr = nkf / 4;
     const uint64_t tiles3 = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups;
     const double unit = 128 * 0.53, us_per_unit = 2.27 / 128.0;
     double best = (double)((tiles3 + ncu - 1) / ncu) * (nkf + 8) * unit;
     uint32_t sp = 1;
     if (a.M % 4 == 0 && a.ldy % 4 == 0)
-        for (uint32_t s2 = 2; s2 <= 16; s2 *= 2) {
-            if (nkf % (4 * s2) || nkf / s2 < 16) break;
-            const double c = (double)((tiles3 * s2 + ncu - 1) / ncu) * (nkf / s2 + 8) * unit + ((double)(s2 + 1) * a.groups * a.N * a.M * 4.0 / 4e6 + 5.0) / us_per_unit;
+        for (uint32_t s2 = 2; s2 <= 16; ++s2) {
+            if (ngr / s2 < 4) break;                                  // a range keeps >= 16 slabs
+            const uint32_t longest = 4 * ((ngr + s2 - 1) / s2);
+            const double c = (double)((tiles3 * s2 + ncu - 1) / ncu) * (longest + 8) * unit + ((double)(s2 + 1) * a.groups * a.N * a.M * 4.0 / 4e6 + 5.0) / us_per_unit;
             if (c < best * 0.95) { best = c; sp = s2; }
         }
     *splits_out = sp;
