@@ -52,10 +52,13 @@ __global__ __launch_bounds__(WN * WM * 64) void k_gemm_b9(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WM, wm = wave % WM;
     const uint32_t tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
-    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups;
+    // split-K as in k_gemm_glds (launches whose tiles fill the CUs badly: 160 tiles of the 13B wo / w2, 128 of the 7B ones): work item = (tile,
+    // slab range ks), partial products to part[group][ks][N][M], k_splitk_reduce adds them in ks order (+ residual); ranges differ by <= 1 slab
+    const uint32_t splits = a.splits ? a.splits : 1;
+    const uint32_t per_group = tiles_n * tiles_m, total = per_group * a.groups * splits;
     const uint32_t ldw = a.ldw ? a.ldw : a.K;
     const int li = lane & 31, lh = lane >> 5;
-    const uint32_t nk = a.K / GBK;
+    const uint32_t nkf = a.K / GBK;
     // persistent workgroups, one per CU; the workgroups of one XCD run consecutive tiles, n fastest (k_gemm_glds's order: a weight panel meets in one L2)
     const uint32_t G = gridDim.x;
     const uint32_t v0 = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
@@ -63,9 +66,11 @@ __global__ __launch_bounds__(WN * WM * 64) void k_gemm_b9(const GemmArgs a) {
     const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     for (uint32_t wv = v0; wv < total; wv += G) {
-        const uint32_t g = wv / per_group, t = wv % per_group;
+        const uint32_t ks = wv % splits, wi = wv / splits;      // K range fastest: the pieces of one tile run side by side
+        const uint32_t g = wi / per_group, t = wi % per_group;
         const uint32_t tm = t / tiles_n, tn = t % tiles_n;
         const uint32_t n0 = tn * BN, m0 = tm * BM;
+        const uint32_t sl0 = (uint32_t)(((uint64_t)ks * nkf) / splits), nk = (uint32_t)(((uint64_t)(ks + 1) * nkf) / splits) - sl0;   // first slab, slabs
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous tile's stages
         // piece p of a slab is fetched by wave p % NWV: this lane's source pointer and LDS offset for each of its pieces
         const char* src[PPW];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(WN * WM * 64) void k_gemm_b9(const GemmArgs a) {
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) dstS[pp] = (uint32_t)__builtin_amdgcn_readfirstlane((int)dst[pp]);
         auto issue1 = [&](uint32_t slab, int pp) {
-            const uint32_t ks = slab < nk ? slab : nk - 1;                    // past the end: the last slab again (keeps the counts uniform; harmless)
+            const uint32_t ks = sl0 + (slab < nk ? slab : nk - 1);            // past the end: the last slab again (keeps the counts uniform; harmless)
             const uint32_t st = lds0 + (slab % NST) * STAGE;
             const char* sp = src[pp] + (size_t)ks * kstep[pp];
             const uint32_t m0v = st + dstS[pp];
@@ -209,9 +214,10 @@ __global__ __launch_bounds__(WN * WM * 64) void k_gemm_b9(const GemmArgs a) {
             step(1, kt + 1 < nk ? kt + 1 : kt, 0, true, kt + NST);      // second step; prepares the first step of slab kt + 1
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMA
-        float* Y = a.y[g];
-        const float* R = a.r[g];
-        if (a.epi != GEMM_EPI_STORE) gemm_store_fused<TN, TM>(a, acc, g, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
+        float* Y = splits > 1 ? a.part + ((size_t)(g * splits + ks) * a.N) * a.M : a.y[g];
+        const float* R = splits > 1 ? nullptr : a.r[g];
+        if (splits > 1) gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, a.M);
+        else if (a.epi != GEMM_EPI_STORE) gemm_store_fused<TN, TM>(a, acc, g, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh);
         else gemm_store<TN, TM>(a, acc, Y, R, n0 + wn * TN * 32, m0 + wm * TM * 32, li, lh, a.ldy);
     }
 #ifdef B9_TRACE   // tools/gemm_b9_probe.hip: shader clocks and 100 MHz ticks one workgroup spent here

@@ -925,7 +925,7 @@ static int gemm_q8b_split(lh_ctx* ctx, const float* wq, const float* wsc, const 
 static bool gemm_b9_ok(const GemmArgs& a) {
     return a.N > 128 && !a.causal && a.splits <= 1 && gemm_dma_ok(a) && a.K >= 16 * GBK && a.K % 8 == 0;
 }
-static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name) {
+static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t splits) {
     auto kern = k_gemm_b9<1, 8, 4, 1, 2>;
     const size_t lds = 2 * gemm_b9_stage_bytes(128, 256);
     static bool flags[16] = {};
@@ -934,14 +934,30 @@ static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name) {
     if (g_prepare_only) return 0;
     if (!ensure_xs3(ctx, (uint64_t)3 * a.N * a.K)) LH_FAIL(ctx, LH_ENOMEM, "%s: planes of %u x %u activations", name, a.N, a.K);
     a.xs = ctx->xs3; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
+    a.splits = splits > 1 ? splits : 0; a.part = nullptr;
+    if (splits > 1) {
+        const uint64_t need = (uint64_t)a.groups * splits * a.N * a.M;
+        if (need > ctx->splitk_floats) {
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->splitk) LH_HIP(ctx, hipFree(ctx->splitk));
+            ctx->splitk = nullptr; ctx->splitk_floats = 0; ctx->splitk_gen++;
+            LH_HIP(ctx, hipMalloc((void**)&ctx->splitk, need * 4));
+            ctx->splitk_floats = need;
+        }
+        a.part = ctx->splitk;
+    }
     {
         TraceScope ts_(ctx->stream, "split3_rows");
         Split3Args sa = {a.x, ctx->xs3, a.xs_plane, a.K, a.ldx, a.K};
         hipLaunchKernelGGL(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
     }
-    const uint64_t tiles = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups;
+    const uint64_t items = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups * (splits > 1 ? splits : 1);
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4 * a.groups);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(items, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    if (splits > 1) {
+        const uint64_t quads = (uint64_t)a.groups * a.N * (a.M / 4);
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+    }
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -979,9 +995,17 @@ int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, 
     const double c128 = cost(128, 1.0), c160 = cost(160, 1.03), c64 = cost(64, 1.10);
     if (gemm_b9_ok(a)) {
         const uint64_t tiles9 = (uint64_t)tn * ((a.M + 255) / 256) * a.groups;
+        const uint32_t nkf = a.K / GBK;
         const double unit = may_split ? 2.0 * 128 * GBK / (157.3e6 / 256.0) : 1.0;      // cost() is in microseconds when split-K is on the table
-        const double c9 = (double)((tiles9 + ncu - 1) / ncu) * (a.K / GBK + 8) * 256 * 0.62 * unit;
-        if (c9 < 0.97 * std::min(c128, std::min(c160, c64))) return launch_gemm_b9(ctx, a, name);
+        double c9 = (double)((tiles9 + ncu - 1) / ncu) * (nkf + 8) * 256 * 0.62 * unit;
+        uint32_t s9 = 1;
+        if (may_split)      // (cost in microseconds: the reduce pass as in pick_splitk)
+            for (uint32_t s2 = 2; s2 <= 8; ++s2) {
+                if (nkf / s2 < 16) break;
+                const double c = (double)((tiles9 * s2 + ncu - 1) / ncu) * ((nkf + s2 - 1) / s2 + 8) * 256 * 0.62 * unit + (double)(s2 + 1) * a.groups * n * a.M * 4.0 / 4e6 + 5.0;
+                if (c < c9 * 0.95) { c9 = c; s9 = s2; }
+            }
+        if (c9 < 0.97 * std::min(c128, std::min(c160, c64))) return launch_gemm_b9(ctx, a, name, s9);
     }
     if (c160 < c128 && c160 <= c64) return launch_gemm<4, 1, 1, 5>(ctx, a, name);
     if (c64 < c128) return launch_gemm<2, 2, 2, 1>(ctx, a, name);
