@@ -399,7 +399,7 @@ static uint16_t* ensure_xs3(lh_ctx* ctx, uint64_t elems) {
 }
 static bool gemm_q8b3_ok(const GemmArgs& a) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
-    if (a.N <= 128 || a.K % 128 || a.K < 16 * GBK || a.ldx % 4 || !al(a.x)) return false;
+    if (a.N <= 64 || a.K % 128 || a.K < 16 * GBK || a.ldx % 4 || !al(a.x)) return false;
     for (uint32_t g = 0; g < a.groups; ++g)
         if (!al(a.w[g]) || !al(a.ws[g])) return false;
     return true;
@@ -1517,7 +1517,8 @@ static bool q8b_shape_ok(lh_ctx* ctx, const ModelDesc& m) {
     if (m.last_stage() && (m.V % 16 || (m.V / 16 + ncu - 1) / ncu > 8)) return false;
     return true;
 }
-static constexpr uint32_t Q8B_PROMPT_ROWS = 2 * STREAM_ROWS_Q8;   // a prompt takes up to two 64-row passes (beyond: the tile GEMM, one pass)
+static constexpr uint32_t Q8B_PROMPT_ROWS = 88;   // a prompt takes up to two 64-row passes; from 89 rows the tile GEMM k_gemm_q8b3 (one 128-row tile: 9.0-9.8 ms flat over
+                                                  // 65..128 rows on 7B) is ahead of them (8.6 ms at 65 rows, 8.9 at 80, 9.75 at 96, 11.4 at 128: profiles/r05_gemm_q8b3_probe.txt)
 static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n_min, bool batch_rows = true) {
     return n >= n_min && n <= (batch_rows ? STREAM_ROWS_Q8 : Q8B_PROMPT_ROWS) && q8b_shape_ok(ctx, m);
 }
