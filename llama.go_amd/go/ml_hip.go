@@ -58,6 +58,15 @@ func (ctx *Context) ReleaseContextHIP() {
 	ctx.hip.ctx = nil
 }
 
+// TimeComputesHIP arms (or disarms) the library's timers around every GraphCompute of this context - HIP events on its stream and the host clock
+// inside lh_graph_compute (SURVEY 8d config 2) - and zeroes the sums; ComputeStatsHIP returns them: calls, host microseconds, device microseconds.
+func (ctx *Context) TimeComputesHIP(on int) { C.lh_ctx_time_computes(ctx.hip.ctx, C.int(on)) }
+func (ctx *Context) ComputeStatsHIP() (calls uint64, wallUs, deviceUs float64) {
+	var st C.lh_compute_stats
+	C.lh_ctx_compute_stats(ctx.hip.ctx, &st)
+	return uint64(st.calls), float64(st.wall_us), float64(st.device_us)
+}
+
 // The model is loaded before any pod exists (llama.go:975, server.go:45 shares it): weights are registered through one package-level context.
 var (
 	modelOnce sync.Once
