@@ -167,11 +167,13 @@ __global__ __launch_bounds__(TH) void k_stream_q8b(const StreamArgs a) {
     const uint32_t units = pairs ? tiles_per_mat : T, um = pairs ? 2u : 1u;
     const uint32_t S = a.ksplit > 1 ? a.ksplit : 1u, bg = (uint32_t)blockIdx.x / S, ks = (uint32_t)blockIdx.x - bg * S, ng = (uint32_t)gridDim.x / S;
     if (bg >= ng) return;
-    const uint32_t t0 = um * (uint32_t)(((uint64_t)bg * units) / ng), t1 = um * (uint32_t)(((uint64_t)(bg + 1) * units) / ng);
+    // (32-bit arithmetic: the 64-bit divisions that stood here and a division per DMA piece below were half of the ~1100 instructions in front of
+    //  the first DMA; removing them measured NOTHING - the 4.4 us to the first barrier are the first chunk's way from HBM, not this code)
+    const uint32_t t0 = um * (bg * units / ng), t1 = um * ((bg + 1) * units / ng);
     if (t1 <= t0) return;
     const uint32_t nt = t1 - t0;
-    const uint32_t nch_all = a.K / KC, ch0 = (uint32_t)(((uint64_t)ks * nch_all) / S);
-    const uint32_t nch = (uint32_t)(((uint64_t)(ks + 1) * nch_all) / S) - ch0;
+    const uint32_t nch_all = a.K / KC, ch0 = ks * nch_all / S;
+    const uint32_t nch = (ks + 1) * nch_all / S - ch0;
     const uint32_t kbase = ch0 * KC;
     if (nch == 0) return;
     const uint32_t r16 = (uint32_t)lane & 15, slot = (uint32_t)lane >> 4;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(TH) void k_stream_q8b(const StreamArgs a) {
             const uint32_t v = t0 + ts;
             uint32_t g, tile;
             if (pairs) { g = v & 1u; tile = v >> 1; }
-            else { g = v / tiles_per_mat; tile = v - g * tiles_per_mat; }
+            else { g = (v >= tiles_per_mat ? 1u : 0u) + (v >= 2 * tiles_per_mat ? 1u : 0u); tile = v - g * tiles_per_mat; }   // (<= 3 matrices: no division)
             if (scales) return (const char*)((g == 0 ? a.ws[0] : (g == 1 ? a.ws[1] : a.ws[2])) + (size_t)tile * 16 * (a.K / 32) + kbase / 32);
             return (const char*)(g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2])) + (size_t)tile * 16 * a.K + kbase;
         };
