@@ -306,8 +306,8 @@ __device__ __forceinline__ void stream_store_split3(const StreamArgs& a, uint32_
 // the MFMA waves are dealt as 2 K-groups x 2 column halves, MFMA wave w holds the sums of K-group w >> 1 for column tiles
 // (w & 1) NCT / 2 + c; two partials per tile meet instead of four.
 // TR (k_stream_q8b): the MFMA was issued transposed - a lane's four results are tokens 4 slot + i of ONE weight row (lane & 15).
-// NB > 0 (k_stream_q8b, equal waves): wave w holds the sums over quant block w % NB of every chunk for the tiles t with
-// t % (waves / NB) == w / NB; NB partials per tile meet.
+// NB > 0 (k_stream_q8b, k_stream_b9: equal waves): wave w holds the sums over quant / k-block w % NB of every chunk for the column tiles
+// ((w / NB) % CS) NCT / CS + c of the tiles t with t % (waves / (NB CS)) == w / (NB CS); NB partials per tile meet.
 template <int MAXT, int NCT, int CS = 1, bool TR = false, int NB = 0, typename AccFn>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_raw, uint32_t lds_floats, const float* scales, uint32_t t0, uint32_t nt, uint32_t ks,
                                                 uint32_t tiles_per_mat, AccFn&& acc_of) {
@@ -320,8 +320,8 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
     };
     constexpr int NC = NCT * 16, NKG = NB > 0 ? NB : 4 / CS, NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
-    const uint32_t TGX = NB > 0 ? ((uint32_t)blockDim.x >> 6) / (uint32_t)NB : 1u;   // tile groups of an equal-waves workgroup
-    static_assert(CS == 1 || (CS == 2 && NCT % 2 == 0), "column split");
+    const uint32_t TGX = NB > 0 ? ((uint32_t)blockDim.x >> 6) / (uint32_t)(NB * CS) : 1u;   // tile groups of an equal-waves workgroup
+    static_assert(CS == 1 || (NB == 0 && CS == 2 && NCT % 2 == 0) || (NB > 0 && NCT % CS == 0), "column split");
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = (uint32_t)NKG * NC * 16;
     const uint32_t batch = (lds_floats / TILE_FLOATS) & ~1u;   // even: a pair never straddles two batches
@@ -330,8 +330,9 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
     const uint32_t egrp = (uint32_t)tid / (4u * NC), negrp = (uint32_t)blockDim.x / (4u * NC), etid = (uint32_t)tid - egrp * (4u * NC);
     const uint32_t col = etid >> 2, quad = etid & 3;
     const float nscale = (scales && col < (uint32_t)NC) ? scales[col] : 1.0f;
-    const uint32_t kg = NB > 0 ? (uint32_t)wave % (uint32_t)NKG : (CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4)), cbase = CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u;
-    const uint32_t tgw = NB > 0 ? (uint32_t)wave / (uint32_t)NKG : 0u;
+    const uint32_t kg = NB > 0 ? (uint32_t)wave % (uint32_t)NKG : (CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4));
+    const uint32_t cbase = NB > 0 ? (((uint32_t)wave / (uint32_t)NKG) % (uint32_t)CS) * NCW : (CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u);
+    const uint32_t tgw = NB > 0 ? (uint32_t)wave / (uint32_t)(NKG * CS) : 0u;
     auto tile_sum = [&](uint32_t slot_in_batch) {
         const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
         f4 s = *(const f4*)p;

@@ -120,12 +120,15 @@ constexpr int stream_q8b_xr(int nct, uint32_t n) { return (nct == 1 && n <= 8) ?
 // passed, 3 loop end, 6 epilogue start, 7 end; laps 1 computing, 4 waiting for its DMAs, 5 at barriers + issuing).  Nothing of it exists in the
 // product build.  (The timing-only ablation builds that found the compiler's vmcnt(0) - profiles/r05_q8b_ablation.txt - are in the git history.)
 #ifdef Q8B_TRACE
-#define Q8B_TR_DECL unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlap = 0; const bool trace_on = a.trace != nullptr && blockIdx.x == gridDim.x / 2
+#ifndef Q8B_TRACE_BLOCK
+#define Q8B_TRACE_BLOCK (gridDim.x / 2)
+#endif
+#define Q8B_TR_DECL unsigned long long tstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlap = 0; const bool trace_on = a.trace != nullptr && blockIdx.x == Q8B_TRACE_BLOCK; const unsigned long long tclk0 = __builtin_amdgcn_s_memtime()
 #define Q8B_TR_NOW() (__builtin_amdgcn_sched_barrier(0), tlap = __builtin_amdgcn_s_memrealtime(), __builtin_amdgcn_sched_barrier(0), tlap)
 #define Q8B_STAMP(i) do { if (trace_on && !tstamp[i]) tstamp[i] = Q8B_TR_NOW(); } while (0)
 #define Q8B_LAP_START() unsigned long long tl0 = Q8B_TR_NOW()
 #define Q8B_LAP(i) do { const unsigned long long tn = Q8B_TR_NOW(); tstamp[i] += tn - tl0; tl0 = tn; } while (0)
-#define Q8B_TR_STORE(nwv) do { if (trace_on && lane == 0 && (wave == 0 || wave == (nwv) - 1)) for (int i_ = 0; i_ < 8; ++i_) a.trace[(wave ? 8 : 0) + i_] = tstamp[i_]; } while (0)
+#define Q8B_TR_STORE(nwv) do { if (trace_on && lane == 0 && (wave == 0 || wave == (nwv) - 1)) { for (int i_ = 0; i_ < 8; ++i_) a.trace[(wave ? 8 : 0) + i_] = tstamp[i_]; if (wave == 0) a.trace[16] = __builtin_amdgcn_s_memtime() - tclk0; } } while (0)
 #else
 #define Q8B_TR_DECL
 #define Q8B_STAMP(i)
