@@ -308,7 +308,11 @@ __device__ __forceinline__ void stream_store_split3(const StreamArgs& a, uint32_
 // TR (k_stream_q8b): the MFMA was issued transposed - a lane's four results are tokens 4 slot + i of ONE weight row (lane & 15).
 // NB > 0 (k_stream_q8b, k_stream_b9: equal waves): wave w holds the sums over quant / k-block w % NB of every chunk for the column tiles
 // ((w / NB) % CS) NCT / CS + c of the tiles t with t % (waves / (NB CS)) == w / (NB CS); NB partials per tile meet.
-template <int MAXT, int NCT, int CS = 1, bool TR = false, int NB = 0, typename AccFn>
+// TS = 2 (k_stream_b9, wave-specialised): MFMA wave w = 2 K-group + part holds the sums of its K-group for the tiles [0, ceil(MAXT / 2)) (part 0) or
+// [ceil(MAXT / 2), MAXT) (part 1) and all column tiles; two partials per tile meet.
+// TS = 3 (k_stream_b9 on 32 x 32 x 16 MFMAs): MFMA wave w holds K-group w of every tile in a layout of its own; acc_of(t, base) stores the wave's sums
+// of tile t, element (token c, row r) at base[c * 16 + r]; four partials per tile meet.
+template <int MAXT, int NCT, int CS = 1, bool TR = false, int NB = 0, int TS = 1, typename AccFn>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_raw, uint32_t lds_floats, const float* scales, uint32_t t0, uint32_t nt, uint32_t ks,
                                                 uint32_t tiles_per_mat, AccFn&& acc_of) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -319,9 +323,11 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         if (pairs) { *g = v & 1u; *tile = v >> 1; }
         else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
     };
-    constexpr int NC = NCT * 16, NKG = NB > 0 ? NB : 4 / CS, NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
-    const uint32_t TGX = NB > 0 ? ((uint32_t)blockDim.x >> 6) / (uint32_t)(NB * CS) : 1u;   // tile groups of an equal-waves workgroup
+    constexpr int NC = NCT * 16, NKG = NB > 0 ? NB : (TS == 2 ? 2 : 4 / CS), NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
+    const uint32_t TGX = NB > 0 ? ((uint32_t)blockDim.x >> 6) / (uint32_t)(NB > 0 ? NB * CS : 1) : 1u;   // tile groups of an equal-waves workgroup
     static_assert(CS == 1 || (NB == 0 && CS == 2 && NCT % 2 == 0) || (NB > 0 && NCT % CS == 0), "column split");
+    static_assert(TS == 1 || ((TS == 2 || TS == 3) && NB == 0 && CS == 1), "tile split");
+    constexpr uint32_t TS0 = (MAXT + 1) / 2;    // TS = 2: first tile of part 1
     float* part = (float*)smem_raw;
     constexpr uint32_t TILE_FLOATS = (uint32_t)NKG * NC * 16;
     const uint32_t batch = (lds_floats / TILE_FLOATS) & ~1u;   // even: a pair never straddles two batches
@@ -330,9 +336,10 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
     const uint32_t egrp = (uint32_t)tid / (4u * NC), negrp = (uint32_t)blockDim.x / (4u * NC), etid = (uint32_t)tid - egrp * (4u * NC);
     const uint32_t col = etid >> 2, quad = etid & 3;
     const float nscale = (scales && col < (uint32_t)NC) ? scales[col] : 1.0f;
-    const uint32_t kg = NB > 0 ? (uint32_t)wave % (uint32_t)NKG : (CS == 2 ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4));
+    const uint32_t kg = NB > 0 ? (uint32_t)wave % (uint32_t)NKG : ((CS == 2 || TS == 2) ? (uint32_t)(wave - 4) >> 1 : (uint32_t)(wave - 4));
+    const uint32_t tpart = (uint32_t)(wave - 4) & 1u;
     const uint32_t cbase = NB > 0 ? (((uint32_t)wave / (uint32_t)NKG) % (uint32_t)CS) * NCW : (CS == 2 ? ((uint32_t)(wave - 4) & 1u) * NCW : 0u);
-    const uint32_t tgw = NB > 0 ? (uint32_t)wave / (uint32_t)(NKG * CS) : 0u;
+    const uint32_t tgw = NB > 0 ? (uint32_t)wave / (uint32_t)(NKG * CS > 0 ? NKG * CS : 1) : 0u;
     auto tile_sum = [&](uint32_t slot_in_batch) {
         const float* p = part + (size_t)slot_in_batch * TILE_FLOATS + (size_t)col * 16 + quad * 4;
         f4 s = *(const f4*)p;
@@ -348,7 +355,10 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
         if (NB > 0 || wave >= 4) {
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt && (NB == 0 || (uint32_t)t % TGX == tgw)) {
+                if constexpr (TS == 3) {
+                    if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt) acc_of(t, part + (size_t)(t - tb) * TILE_FLOATS + (size_t)kg * NC * 16);
+                } else
+                if ((uint32_t)t >= tb && (uint32_t)t < tb + batch && (uint32_t)t < nt && (NB == 0 || (uint32_t)t % TGX == tgw) && (TS != 2 || ((uint32_t)t >= TS0) == (tpart != 0))) {
 #pragma unroll
                     for (int c = 0; c < NCW; ++c) {
                         const f4m v = acc_of(t, c);

@@ -45,7 +45,9 @@ struct Plan {
     float *xa = nullptr, *xb = nullptr, *h = nullptr, *qraw = nullptr, *kraw = nullptr, *vraw = nullptr, *q = nullptr, *attn = nullptr;
     float *a1 = nullptr, *a3 = nullptr, *g = nullptr, *logits = nullptr;
     uint16_t* s3 = nullptr;                   // block-int8 plans: the activations of the int8 matmuls as three bf16 planes each (kernels_stream_q8b.h):
-                                              // [3][n_cap][d] normalised rows, [3][n_cap][d] merged attention heads, [3][n_cap][F] gated rows
+                                              // [3][s3_rows][d] normalised rows, [3][s3_rows][d] merged attention heads, [3][s3_rows][F] gated rows
+                                              // (fp32 plans: up to the 64 rows k_stream_b9 takes, kernels_stream_b9.h)
+    uint32_t s3_rows = 0;
     float* emb = nullptr;                     // LH_T_OUTPUT on llama.Eval's `embeddings`: the final norm rows [emb_cap][d]
     uint32_t emb_cap = 0;
     float* attn_part = nullptr;               // split-T decode attention partials [H][chunks][hd + 2] (plans with ctx > 256)

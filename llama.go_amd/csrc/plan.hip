@@ -10,6 +10,7 @@
 #include "kernels_sample.h"
 #include "kernels_stream.h"
 #include "kernels_stream_q8b.h"
+#include "kernels_stream_b9.h"
 #include "kernels_gemm_b9.h"
 #include "kernels_rows.h"
 #include <math.h>
@@ -629,6 +630,7 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // 65..96 rows (round 3): five / six column tiles on the same half-length chunks (2 x (6 + 6) x 16 x 68 floats = 104 KB; 6 x 6 accumulator tiles =
 // 144 registers of the MFMA waves).  The tile GEMM's single row of 128-row tiles cost 17.6 ms at 65 rows against 10.2 ms at 64.
 static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 64, BATCH_ROWS_MAX = 64;
+static constexpr uint32_t B9S_MIN_ROWS = 49, B9S_MAX_ROWS = 64;   // fp32 on k_stream_b9 (see b9s_shape_ok)
 static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
@@ -865,7 +867,55 @@ static int launch_stream_q8b_maxt(lh_ctx* ctx, const StreamArgs& a, const char* 
         default: return ST_NA;
     }
 }
-// groups (<= 3) int8 matrices of equal shape times the same activation planes in ONE launch; fused: the epilogue (RoPE + cache append | silu * mul)
+// ---- k_stream_b9 (kernels_stream_b9.h, round 6): fp32 weights x the same three bf16 planes, nine exact products per weight on the bf16 matrix pipe.
+// Wave-specialised like k_stream_dma (four loader waves, four MFMA waves); up to four column tiles (64 rows), 64-column chunks, as many images
+// as fit (<= 4).  Eight row tiles next to four column tiles are not built (the MFMA waves' 4 x 4 accumulator tiles + operands spill).
+// Eight of the nine products: xl * wl (<= 2^-32 of its product, far below the fp32 accumulator's own rounding) is dropped - against an f64 product max and
+// rms error are unchanged to four digits (tools/b9s_probe, profiles/r06_stream_b9_probe.txt: 7B w1|w3 at 64 rows 1.102e-05 / 6.295e-07 with nine and
+// with eight), and the kernel is power-bound (the chip holds 1.6-1.9 GHz under it), so an MFMA saved is time saved: 92.2 -> 88.0 us.  Six products
+// (also xm * wl and xl * wm, 2^-24 each) measured 79.8 us at rms 6.311e-07 - not taken: those terms are the size of an fp32 product's own rounding.
+static constexpr int B9S_PRODUCTS = 8;
+template <int MAXT, int NCT>
+static int launch_stream_b9(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    constexpr int NIMG = stream_b9_nimg(MAXT, NCT, 4);
+    if constexpr (NIMG < 2 || (MAXT >= 8 && NCT >= 4)) return ST_NA;
+    else {
+        static bool flags[16] = {};
+        auto kern = k_stream_b9<MAXT, NCT, NIMG, B9S_PRODUCTS>;
+        const size_t lds = std::max<size_t>((size_t)NIMG * stream_b9_image_bytes(MAXT, NCT), 82 * 1024);   // one workgroup per CU
+        int rc = set_lds_once(ctx, kern, lds, flags);
+        if (rc) return rc;
+        if (g_prepare_only) return 0;
+        const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
+        ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(B9S_TH), lds, ctx->stream, a);
+        LH_HIP(ctx, hipGetLastError());
+        return 0;
+    }
+}
+template <int MAXT>
+static int launch_stream_b9_n(lh_ctx* ctx, const StreamArgs& a, const char* name) {
+    if (a.K % B9S_KC || a.K / B9S_KC < (a.ksplit > 1 ? a.ksplit : 1u)) return ST_NA;
+    if (a.n <= 16) return launch_stream_b9<MAXT, 1>(ctx, a, name);
+    if (a.n <= 32) return launch_stream_b9<MAXT, 2>(ctx, a, name);
+    if (a.n <= 48) return launch_stream_b9<MAXT, 3>(ctx, a, name);
+    if (a.n <= 64) return launch_stream_b9<MAXT, 4>(ctx, a, name);
+    return ST_NA;
+}
+static int launch_stream_b9_maxt(lh_ctx* ctx, const StreamArgs& a, const char* name, uint32_t maxt) {
+    switch (maxt) {
+        case 1: return launch_stream_b9_n<1>(ctx, a, name);
+        case 2: return launch_stream_b9_n<2>(ctx, a, name);
+        case 3: return launch_stream_b9_n<3>(ctx, a, name);
+        case 4: return launch_stream_b9_n<4>(ctx, a, name);
+        case 5: case 6: return launch_stream_b9_n<6>(ctx, a, name);
+        case 7: case 8: return launch_stream_b9_n<8>(ctx, a, name);
+        default: return ST_NA;
+    }
+}
+static bool stream_b9_built(uint32_t maxt, uint32_t n) { return maxt >= 1 && maxt <= 8 && n >= 1 && n <= 64 && !(maxt > 6 && n > 48); }
+// groups (<= 3) matrices of equal shape - block-int8 (wsc: their scale planes) or fp32 (wsc[g] == nullptr: k_stream_b9) - times the same activation
+// planes in ONE launch; fused: the epilogue (RoPE + cache append | silu * mul)
 static int gemm_q8b_group(lh_ctx* ctx, const uint16_t* xs, uint64_t xs_plane, uint32_t ldxs, uint32_t groups, const float* const* wq, const float* const* wsc, float* const* y,
                           const float* const* r, uint32_t M, uint32_t K, uint32_t n, uint32_t ldy, const char* name, const StreamArgs* fused = nullptr) {
     if (n == 0 || n > STREAM_ROWS_Q8 || groups > 3 || M % 16 || K % 128 || ldxs % 8 || ldy % 4 || ((uintptr_t)xs & 15) || (xs_plane * 2) % 16) return ST_NA;
@@ -880,7 +930,7 @@ static int gemm_q8b_group(lh_ctx* ctx, const uint16_t* xs, uint64_t xs_plane, ui
         a.w[g] = wq[g]; a.ws[g] = wsc[g]; a.y[g] = y ? y[g] : nullptr; a.r[g] = r ? r[g] : nullptr;
         if (((uintptr_t)wq[g] & 15) || ((uintptr_t)a.y[g] & 15) || (a.r[g] && ((uintptr_t)a.r[g] & 15)) || ((uintptr_t)a.ws[g] & 15)) return ST_NA;
     }
-    return launch_stream_q8b_maxt(ctx, a, name, maxt);
+    return a.ws[0] ? launch_stream_q8b_maxt(ctx, a, name, maxt) : launch_stream_b9_maxt(ctx, a, name, maxt);
 }
 // One matrix as groups of S workgroups that split the contraction (a workgroup then holds S times the rows for a 1 / S of K: the single-tile
 // matrices wo and w2 read S times less of X out of L2 and run S times fewer, longer chunk loops), k_stream_reduce_norm adds the S partials +
@@ -891,7 +941,7 @@ static int gemm_q8b_split(lh_ctx* ctx, const float* wq, const float* wsc, const 
                           const float* resid, float* y, const float* gamma, float* h, uint16_t* hs, uint64_t hs_plane, const char* name) {
     if (n == 0 || n > STREAM_ROWS_Q8 || M % 16 || M > 8192 || M % 4 || K % 128 || ldxs % 8 || ((uintptr_t)xs & 15) || (xs_plane * 2) % 16) return ST_NA;
     if ((((uintptr_t)wq | (uintptr_t)y | (uintptr_t)resid | (uintptr_t)gamma | (uintptr_t)h | (uintptr_t)hs | (uintptr_t)wsc) & 15)) return ST_NA;
-    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, nchunks = K / (K % 256 == 0 ? 256u : 128u);
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, nchunks = wsc ? K / (K % 256 == 0 ? 256u : 128u) : K / (uint32_t)B9S_KC;
     uint32_t S = 4;
     while (S > 1 && (nchunks < 2 * S || ncu / S == 0)) S >>= 1;
     const uint32_t ngrp = ncu / S, maxt = (M / 16 + ngrp - 1) / ngrp;
@@ -907,7 +957,7 @@ static int gemm_q8b_split(lh_ctx* ctx, const float* wq, const float* wsc, const 
     StreamArgs a = {};
     a.xs = xs; a.xs_plane = xs_plane; a.ldxs = ldxs; a.groups = 1; a.M = M; a.K = K; a.n = n; a.ldy = M; a.w[0] = wq; a.ws[0] = wsc; a.y[0] = ctx->splitk;
     a.ksplit = S; a.ysplit = (uint64_t)n * M;
-    const int rs = launch_stream_q8b_maxt(ctx, a, name, maxt);
+    const int rs = wsc ? launch_stream_q8b_maxt(ctx, a, name, maxt) : launch_stream_b9_maxt(ctx, a, name, maxt);
     if (rs) return rs;
     if (g_prepare_only) return 0;
     StreamReduceArgs r = {};
@@ -1176,10 +1226,11 @@ int plan_ensure_rows(Plan* p, uint32_t n) {
     if (n > 1) { rc |= re(&p->qraw, nd); rc |= re(&p->kraw, nd); rc |= re(&p->vraw, nd); rc |= re(&p->a1, nf); rc |= re(&p->a3, nf); }
     if (m.last_stage()) rc |= re(&p->logits, (size_t)n * m.V);
     if (rc) return LH_EHIP;
-    if (m.wtype == 7 && n > 1) {
+    if (n > 1 && (m.wtype == 7 || m.wtype == 0)) {   // the activations as planes: every row of a block-int8 plan, up to k_stream_b9's 64 rows of an fp32 one
         if (p->s3) LH_HIP(ctx, hipFree(p->s3));
         p->s3 = nullptr;
-        LH_HIP(ctx, hipMalloc((void**)&p->s3, (size_t)3 * n * (2 * (size_t)m.d + m.F) * 2));
+        p->s3_rows = m.wtype == 7 ? n : std::min<uint32_t>(n, B9S_MAX_ROWS);
+        LH_HIP(ctx, hipMalloc((void**)&p->s3, (size_t)3 * p->s3_rows * (2 * (size_t)m.d + m.F) * 2));
     }
     if (p->tokens_dev) LH_HIP(ctx, hipFree(p->tokens_dev));
     LH_HIP(ctx, hipMalloc((void**)&p->tokens_dev, (size_t)n * 4));
@@ -1517,6 +1568,21 @@ static bool q8b_shape_ok(lh_ctx* ctx, const ModelDesc& m) {
     if (m.last_stage() && (m.V % 16 || (m.V / 16 + ncu - 1) / ncu > 8)) return false;
     return true;
 }
+// fp32 weights on k_stream_b9 (round 6): the same layer schedule over planes, from four column tiles on (49..64 rows), where k_stream_dma's fp32-input
+// MFMAs are the bound.  Inside the model (profiles/r06_pods64_kernel_trace_*.txt): w1|w3 112.7 -> 86.9 us, wo + w2 82 -> 73; at 33..48 rows the
+// fp32 kernel is level or ahead (48 pods 6.99 against 7.08 ms per tick), and the standalone probe overstates ITS times by a quarter (random mantissas);
+// every launch of the layer must have an instantiation (the output matrix may fall back to the fp32 rows the last reduce pass also writes).
+static bool b9s_shape_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n) {
+    const uint32_t ncu = (uint32_t)ctx->ds->num_cu, d = m.d, F = m.F;
+    if (m.wtype != 0 || ncu < 4 || n < 2 || n > B9S_MAX_ROWS || d > 8192 || d % 128 || F % 128 || m.hd % 4 || d % m.hd) return false;
+    auto split_maxt = [&](uint32_t K) {   // gemm_q8b_split's group size for a contraction of K columns
+        uint32_t S = 4;
+        while (S > 1 && (K / (uint32_t)B9S_KC < 2 * S || ncu / S == 0)) S >>= 1;
+        const uint32_t ngrp = ncu / S;
+        return (d / 16 + ngrp - 1) / ngrp;
+    };
+    return stream_b9_built((3 * d / 16 + ncu - 1) / ncu, n) && stream_b9_built(2 * ((F / 16 + ncu - 1) / ncu), n) && stream_b9_built(split_maxt(d), n) && stream_b9_built(split_maxt(F), n);
+}
 static constexpr uint32_t Q8B_PROMPT_ROWS = 88;   // a prompt takes up to two 64-row passes; from 89 rows the tile GEMM k_gemm_q8b3 (one 128-row tile: 9.0-9.8 ms flat over
                                                   // 65..128 rows on 7B) is ahead of them (8.6 ms at 65 rows, 8.9 at 80, 9.75 at 96, 11.4 at 128: profiles/r05_gemm_q8b3_probe.txt)
 static bool q8_stream_ok(lh_ctx* ctx, const ModelDesc& m, uint32_t n, uint32_t n_min, bool batch_rows = true) {
@@ -1542,15 +1608,16 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
     lh_ctx* ctx = p->ctx;
     const ModelDesc& m = p->md;
     const uint32_t d = m.d, F = m.F;
-    if (!q8b_shape_ok(ctx, m)) return ST_NA;
+    if (!(m.wtype == 7 ? q8b_shape_ok(ctx, m) : b9s_shape_ok(ctx, m, n))) return ST_NA;
+    if (!p->s3 || n > p->s3_rows) return ST_NA;
     const BatchRow* rows = bc ? bc->rows : nullptr;
     const float scale = (float)(1.0 / sqrt((double)m.d / (double)m.H));
-    const uint64_t pd = (uint64_t)p->n_cap * d, pf = (uint64_t)p->n_cap * F;   // plane strides (elements)
+    const uint64_t pd = (uint64_t)p->s3_rows * d, pf = (uint64_t)p->s3_rows * F;   // plane strides (elements)
     uint16_t* hs = p->s3;
     uint16_t* as = hs + 3 * pd;
     uint16_t* gs = as + 3 * pd;
     int rc;
-#define Q8B_TRY(expr, what) do { if ((rc = (expr))) { if (rc == ST_NA) LH_FAIL(ctx, LH_ESHAPE, "block-int8 Eval of %u rows: no launch for %s (embd %u, ff %u)", n, what, d, F); return rc; } } while (0)
+#define Q8B_TRY(expr, what) do { if ((rc = (expr))) { if (rc == ST_NA) LH_FAIL(ctx, LH_ESHAPE, "Eval of %u rows over activation planes: no launch for %s (embd %u, ff %u, weight type %u)", n, what, d, F, m.wtype); return rc; } } while (0)
     bool h_ready = false;
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
@@ -1565,7 +1632,7 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8) {   // (a prompt of 65..128 tokens: two passes over the weights, still 1.5x faster than the tile GEMM)
                 const uint32_t nb = std::min(STREAM_ROWS_Q8, n - b0);
                 fq.q_out = p->q + (size_t)b0 * d; fq.past = past + b0;
-                Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)b0 * d, pd, d, 3, wqkv, sqkv, nullptr, nullptr, d, d, nb, d, "q8b_wqkv_rope", &fq), "wq|wk|wv");
+                Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)b0 * d, pd, d, 3, wqkv, sqkv, nullptr, nullptr, d, d, nb, d, m.wtype == 7 ? "q8b_wqkv_rope" : "b9s_wqkv_rope", &fq), "wq|wk|wv");
             }
         }
         if (rows) {   // rows of different streams: one query each, against its own cache up to its own position
@@ -1577,6 +1644,10 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             if ((rc = attention_flash(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
             Split3Args sa = {p->attn, as, pd, d, d, d};
             if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); hipLaunchKernelGGL(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
+        } else if (n >= 32 && m.hd % 32 == 0) {   // other head sizes: batched MFMA GEMMs over heads with a score tensor (as plan_eval's fp32 route does)
+            if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
+            Split3Args sa = {p->attn, as, pd, d, d, d};
+            if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); hipLaunchKernelGGL(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
         } else {
             AttnArgs a = {};
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
@@ -1586,7 +1657,7 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
         // wo + residual + RMSNorm * ffn_norm -> planes   (llama.go:336-351)
         for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8)
             Q8B_TRY(gemm_q8b_split(ctx, L.wo, L.s_wo, as + (size_t)b0 * d, pd, d, d, d, std::min(STREAM_ROWS_Q8, n - b0), x + (size_t)b0 * d, p->xb + (size_t)b0 * d, L.ffn_norm, nullptr,
-                                   hs + (size_t)b0 * d, pd, "q8b_wo_ksplit"), "wo");
+                                   hs + (size_t)b0 * d, pd, m.wtype == 7 ? "q8b_wo_ksplit" : "b9s_wo_ksplit"), "wo");
         {   // w1|w3 -> silu(w1 h) * (w3 h) -> planes   (llama.go:354-361)
             const float* w13[2] = {L.w1, L.w3};
             const float* s13[2] = {L.s_w1, L.s_w3};
@@ -1594,7 +1665,7 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             fa.epi = ST_EPI_SILU_MUL; fa.ys = gs; fa.ys_plane = pf; fa.ldys = F;
             for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8) {
                 fa.ys = gs + (size_t)b0 * F;
-                Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)b0 * d, pd, d, 2, w13, s13, nullptr, nullptr, F, d, std::min(STREAM_ROWS_Q8, n - b0), F, "q8b_w1w3_silu", &fa), "w1|w3");
+                Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)b0 * d, pd, d, 2, w13, s13, nullptr, nullptr, F, d, std::min(STREAM_ROWS_Q8, n - b0), F, m.wtype == 7 ? "q8b_w1w3_silu" : "b9s_w1w3_silu", &fa), "w1|w3");
             }
         }
         {   // w2 + residual (+ the next layer's first norm, or the final norm, on the reduce pass)   (llama.go:363-372)
@@ -1603,7 +1674,7 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             const float* next_gamma = !last ? m.layers[il + 1].attn_norm : (m.last_stage() ? m.norm : nullptr);
             for (uint32_t b0 = 0; b0 < n; b0 += STREAM_ROWS_Q8)
                 Q8B_TRY(gemm_q8b_split(ctx, L.w2, L.s_w2, gs + (size_t)b0 * F, pf, F, d, F, std::min(STREAM_ROWS_Q8, n - b0), p->xb + (size_t)b0 * d, y + (size_t)b0 * d, next_gamma,
-                                       (last && m.last_stage()) ? p->h + (size_t)b0 * d : nullptr, next_gamma ? hs + (size_t)b0 * d : nullptr, pd, "q8b_w2_ksplit"), "w2");
+                                       (last && m.last_stage()) ? p->h + (size_t)b0 * d : nullptr, next_gamma ? hs + (size_t)b0 * d : nullptr, pd, m.wtype == 7 ? "q8b_w2_ksplit" : "b9s_w2_ksplit"), "w2");
             h_ready = next_gamma != nullptr;
         }
         x = p->xa;
@@ -1614,7 +1685,16 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
         const float* wv = m.output; const float* sv = m.s_output; float* yv = p->logits + (size_t)r0 * m.V;
         for (uint32_t b0 = 0; b0 < nr; b0 += STREAM_ROWS_Q8) {
             float* yb = yv + (size_t)b0 * m.V;
-            Q8B_TRY(gemm_q8b_group(ctx, hs + (size_t)(r0 + b0) * d, pd, d, 1, &wv, &sv, &yb, nullptr, m.V, d, std::min(STREAM_ROWS_Q8, nr - b0), m.V, "q8b_lmhead"), "lm_head");
+            const uint32_t nb = std::min(STREAM_ROWS_Q8, nr - b0);
+            rc = gemm_q8b_group(ctx, hs + (size_t)(r0 + b0) * d, pd, d, 1, &wv, &sv, &yb, nullptr, m.V, d, nb, m.V, m.wtype == 7 ? "q8b_lmhead" : "b9s_lmhead");
+            if (rc == ST_NA && m.wtype == 0) {   // fp32 output matrix without a k_stream_b9 launch (eight row tiles next to four column tiles): the fp32 rows
+                if (nb == 1) {
+                    GemvArgs ga = {};
+                    ga.w[0] = m.output; ga.M = m.V; ga.K = d; ga.x = p->h + (size_t)(r0 + b0) * d; ga.y = yb;
+                    rc = gemv<PRO_PLAIN, EPI_STORE, MAP_SINGLE>(ctx, ga, "gemv_lmhead_row", 0);
+                } else rc = gemm_small_n(ctx, m.output, p->h + (size_t)(r0 + b0) * d, yb, nullptr, m.V, d, nb, d, m.V, "gemm_lmhead");
+            }
+            Q8B_TRY(rc, "lm_head");
         }
     }
     LH_HIP(ctx, hipGetLastError());
@@ -1823,6 +1903,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const int rs = eval_q8b_layers(p, x, x_out_dev, n, past, last_row_only, bc);
         if (rs == ST_NA) LH_FAIL(ctx, LH_ESHAPE, "block-int8 Eval of %u rows: the plan's shape has no k_stream_q8b launch", n);
         return rs;
+    }
+    static const int b9s_min = getenv("LLAMAHIP_B9S_MIN") ? atoi(getenv("LLAMAHIP_B9S_MIN")) : (int)B9S_MIN_ROWS;   // (A/B switch of round 6's measurements: 65 = off)
+    if (m.wtype == 0 && (int)n >= b9s_min && n <= B9S_MAX_ROWS) {   // fp32, 33..64 rows: the same schedule over planes on k_stream_b9 (nine exact bf16 products)
+        const int rs = eval_q8b_layers(p, x, x_out_dev, n, past, last_row_only, bc);
+        if (rs != ST_NA) return rs;   // (ST_NA comes back before anything is enqueued: the fp32-MFMA route below takes the Eval)
     }
     bool h_ready = false;   // p->h already holds this layer's RMSNorm * attn_norm rows (written by the previous layer's w2 reduce pass)
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {

@@ -1,6 +1,6 @@
 // tools/b9s_probe.hip — k_stream_b9 (csrc/kernels_stream_b9.h: fp32 weights on the bf16 matrix pipe through the lossless 3 x 3 split) against a
 // double-precision host product, timed beside k_stream_dma (fp32-input MFMA) on the same matrices.
-// usage: b9s_probe M K N [NX [groups [epi [ksplit]]]]      (7B: w1|w3 = 11008 4096 n 64 2 1, wq|wk|wv = 4096 4096 n 64 3, wo = 4096 4096 n 64 1 0 4, w2 = 4096 11008 n 64 1 0 4)
+// usage: b9s_probe M K N [- [groups [epi [ksplit]]]]      (7B: w1|w3 = 11008 4096 n 64 2 1, wq|wk|wv = 4096 4096 n 64 3, wo = 4096 4096 n 64 1 0 4, w2 = 4096 11008 n 64 1 0 4)
 // env: B9S_IMAGES (cap of the weight ring's depth), B9S_SKIP_CHECK, B9S_COPIES
 // Timing rotates over enough copies of the weights to exceed the 256 MB Infinity Cache (a re-read matrix would come out of it).
 #define Q8B_TRACE
@@ -31,29 +31,24 @@ template <typename F> static double time_us(F&& launch, int ncopies) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 1e3 / reps;
 }
-template <int MAXT, int NCT, int NW, int NX> static void run_b(const Copies& c, int nCU, double wbytes) {
-    if constexpr (NW >= 2) {
-    constexpr int CS = stream_b9_cs(MAXT, NCT);
-    const size_t lds = stream_b9_lds_bytes(MAXT, NCT, NW, NX);
-    auto kern = k_stream_b9<MAXT, NCT, CS, NW, NX, (NX >= 3), B9S_NPROD>;
+template <int MAXT, int NCT, int NIMG> static void run_b(const Copies& c, int nCU, double wbytes) {
+    if constexpr (NIMG >= 2 && NCT <= 4) {
+    const size_t lds = (size_t)NIMG * stream_b9_image_bytes(MAXT, NCT);
+    auto kern = k_stream_b9<MAXT, NCT, NIMG, B9S_NPROD>;
     const size_t req = std::max<size_t>(lds, 82 * 1024);
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)req));
     const uint32_t S = c.a[0].ksplit > 1 ? c.a[0].ksplit : 1;
     const double us = time_us([&](int i) { hipLaunchKernelGGL(kern, dim3(nCU / S * S), dim3(B9S_TH), req, 0, c.a[i]); }, (int)c.a.size());
-    printf("k_stream_b9<%d,%d,cs %d,nw %d,nx %d> %d products" B9S_TAG "%s: %.2f us per launch, %.1f GB/s of weight bytes (LDS %zu B)\n", MAXT, NCT, CS, NW, NX, B9S_NPROD, S > 1 ? " K-split" : "", us,
+    printf("k_stream_b9<%d,%d,%d images> %d products" B9S_TAG "%s: %.2f us per launch, %.1f GB/s of weight bytes (LDS %zu B)\n", MAXT, NCT, NIMG, B9S_NPROD, S > 1 ? " K-split" : "", us,
            wbytes / us / 1e3, lds);
-    { unsigned long long tr[17]; CK(hipMemcpy(tr, c.a[0].trace, sizeof tr, hipMemcpyDeviceToHost));
-      printf("   shader clock of the traced workgroup: %.0f MHz (s_memtime / s_memrealtime over wave 0's life)\n", (double)tr[16] / ((double)(tr[7] - tr[0]) / 100.0));
-      for (int w = 0; w < 2; ++w) { const int b = w * 8; auto us_ = [&](int i) { return (double)(tr[b + i] - tr[b]) / 100.0; };
-        printf("   wave %2d (us from its start): first barrier passed %.2f | loop end %.2f | epilogue start %.2f end %.2f | in the loop: waiting for its DMAs %.2f, at barriers + issuing %.2f, computing %.2f\n",
-               w ? B9S_TH / 64 - 1 : 0, us_(2), us_(3), us_(6), us_(7), tr[b + 4] / 100.0, tr[b + 5] / 100.0, tr[b + 1] / 100.0); } }
-    } else printf("k_stream_b9<%d,%d>: the rings do not fit\n", MAXT, NCT);
+    { unsigned long long tr[2]; CK(hipMemcpy(tr, c.a[0].trace, sizeof tr, hipMemcpyDeviceToHost));
+      printf("   one workgroup's life: %.1f us, %.0f shader clocks -> %.0f MHz\n", tr[1] / 100.0, (double)tr[0], (double)tr[0] / (tr[1] / 100.0)); }
+    } else printf("k_stream_b9<%d,%d>: not built (more than four column tiles, or two images do not fit)\n", MAXT, NCT);
 }
-template <int MAXT, int NCT, int NX> static void run_bk(const Copies& c, int nCU, double wbytes) {
-    if (g_nimg == 2) run_b<MAXT, NCT, stream_b9_nw(MAXT, NCT, NX, 2), NX>(c, nCU, wbytes);
-    else if (g_nimg == 3) run_b<MAXT, NCT, stream_b9_nw(MAXT, NCT, NX, 3), NX>(c, nCU, wbytes);
-    else if (g_nimg == 4) run_b<MAXT, NCT, stream_b9_nw(MAXT, NCT, NX, 4), NX>(c, nCU, wbytes);
-    else run_b<MAXT, NCT, stream_b9_nw(MAXT, NCT, NX, 6), NX>(c, nCU, wbytes);
+template <int MAXT, int NCT> static void run_bk(const Copies& c, int nCU, double wbytes) {
+    if (g_nimg == 2) run_b<MAXT, NCT, stream_b9_nimg(MAXT, NCT <= 4 ? NCT : 4, 2)>(c, nCU, wbytes);
+    else if (g_nimg == 3) run_b<MAXT, NCT, stream_b9_nimg(MAXT, NCT <= 4 ? NCT : 4, 3)>(c, nCU, wbytes);
+    else run_b<MAXT, NCT, stream_b9_nimg(MAXT, NCT <= 4 ? NCT : 4, 4)>(c, nCU, wbytes);
 }
 // the fp32-MFMA kernel of the product on the same launch (plain fp32 rows as activations)
 template <int MAXT, int NCT> static void run_dma(const Copies& c, int nCU, double wbytes) {
@@ -69,7 +64,7 @@ template <int MAXT, int NCT> static void run_dma(const Copies& c, int nCU, doubl
     }
 }
 template <int MAXT, int NCT> static void run(const Copies& cb, const Copies& ca, int nCU, double wbytes) {
-    if (g_kc == 3) run_bk<MAXT, NCT, 3>(cb, nCU, wbytes); else run_bk<MAXT, NCT, 2>(cb, nCU, wbytes);   // (argv[4]: plane images)
+    run_bk<MAXT, NCT>(cb, nCU, wbytes);
     if (!getenv("B9S_NO_DMA")) run_dma<MAXT, NCT>(ca, nCU, wbytes);
 }
 int main(int argc, char** argv) {
@@ -102,8 +97,8 @@ int main(int argc, char** argv) {
         a.xs = dXs; a.xs_plane = (uint64_t)NP * K; a.ldxs = K;
         if (i == 0) { CK(hipMalloc(&a.trace, 256)); CK(hipMemset(a.trace, 0, 256)); } else a.trace = nullptr;
         cb.a.push_back(a);
-        for (uint32_t g = 0; g < G; ++g) a.y[g] = dY1 + (size_t)g * N * M;
         a.trace = nullptr;
+        for (uint32_t g = 0; g < G; ++g) a.y[g] = dY1 + (size_t)g * N * M;
         ca.a.push_back(a);
     }
     float* dP = nullptr; float* dP1 = nullptr;

@@ -1,3 +1,6 @@
+// tools/kernels_stream_b9_m32.h — the build of csrc/kernels_stream_b9.h with the 32 x 32 x 16 MFMA waves (M32), kept out of the product: correct, 80 % of the matrix pipe's
+// clocks busy - and SLOWER than the 16 x 16 x 32 build, because the chip is power-bound under it (1619 MHz; profiles/r06_stream_b9_probe.txt).
+
 // csrc/kernels_stream_b9.h — fp32 weights, 17..64 token rows per weight pass, on the bf16 matrix pipe with EXACT products (round 6).
 //     Y_g[c][m] (+ R_g[c][m]) = sum_k X[c][k] * W_g[m][k]        (ComputeForwardMulMatFP32, pkg/ml/ml.go:1976-2098)
 // The rows are a short prompt's tokens (server.Do feeds the prompt as ONE Eval, pkg/server/server.go:185-192) or the pods of a tick
@@ -73,9 +76,19 @@ __host__ __device__ constexpr int stream_b9_nimg(int maxt, int nct, int cap) {
 // CSP: the two MFMA waves of a k-block halve the COLUMN tiles (every tile each) instead of the tiles - for odd tile counts (wq|wk|wv of 7B: three
 // tiles per workgroup, which halved by tiles leave two SIMDs two thirds of the work); both waves then split the same weight fragments.
 __host__ __device__ constexpr bool stream_b9_csp(int maxt, int nct) { return (maxt & 1) && nct % 2 == 0; }
-template <int MAXT, int NCT, int NIMG, int NPROD = 9, bool CSP = stream_b9_csp(MAXT, NCT)>
+// M32 (even tile and column-tile counts): the MFMA waves multiply on v_mfma_f32_32x32x16_bf16 - MFMA wave w takes k-step w (16 columns) of every
+// chunk for ALL tile pairs (32 weight rows = B) x column-tile pairs (32 tokens = A).  Why: with one MFMA wave per SIMD an MFMA blocks its own wave's
+// issue for ~13 of its 16 clocks and every filler instruction behind it costs 4 more (tools/mfma_chain_probe: 17.0 / 21.1 / 25.1 / 33.1 clocks per
+// 16 x 16 x 32 MFMA with 1 / 2 / 3 / 4 vector instructions behind it) - the 16 x 16 x 32 build's 1.6 fillers per MFMA made its period 2900 clocks where
+// the matrix pipe needs 1728.  A 32-clock 32 x 32 x 16 MFMA does twice the work per issue: the same 155 vector instructions and 12 + 6 LDS reads of
+// a period stand behind 54 MFMAs instead of 108.
+__host__ __device__ constexpr bool stream_b9_m32(int maxt, int nct) { return maxt % 2 == 0 && nct % 2 == 0 && maxt * nct <= 24; }
+typedef float f16m __attribute__((ext_vector_type(16)));
+template <int MAXT, int NCT, int NIMG, int NPROD = 9, bool CSP = stream_b9_csp(MAXT, NCT), bool M32 = stream_b9_m32(MAXT, NCT)>
 __global__ __launch_bounds__(B9S_TH) void k_stream_b9(const StreamArgs a) {
     constexpr int KC = B9S_KC;
+    static_assert(!M32 || (MAXT % 2 == 0 && NCT % 2 == 0 && !CSP), "32 x 32 tiles: pairs of row tiles and of column tiles");
+    constexpr int RP = M32 ? MAXT / 2 : 1, CPN = M32 ? NCT / 2 : 1;   // M32: pairs of row tiles, of column tiles
     static_assert(NIMG >= 2 && NIMG <= 5, "ring");
     static_assert(NCT >= 1 && NCT <= 4, "column tiles");
     static_assert(NPROD == 9 || NPROD == 8 || NPROD == 6, "products");
@@ -109,7 +122,8 @@ __global__ __launch_bounds__(B9S_TH) void k_stream_b9(const StreamArgs a) {
 #ifdef Q8B_TRACE   // tools/b9s_probe: shader clocks and 100 MHz ticks of one workgroup's life (what the chip clocks at under this kernel)
     const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    f4m acc[TPW][NCW];
+    f4m acc[M32 ? 1 : TPW][M32 ? 1 : NCW];
+    f16m acc32[RP][CPN];
     if (wave < 4) {
         // ---- loader waves: piece q = 4 j + wave of a chunk (the tiles' weight rows, then the three planes); a piece's lanes sit in ONE 16-row
         // tile / one plane, so its first row is a uniform resource base and the lane keeps (row) * pitch + its swizzled granule
@@ -163,6 +177,130 @@ __global__ __launch_bounds__(B9S_TH) void k_stream_b9(const StreamArgs a) {
         }
         __builtin_amdgcn_s_barrier();           // the MFMA waves' extra period (the last chunk's MFMAs)
         wait_vm<0>();                           // the clamped tail requests
+    } else if constexpr (M32) {
+        // ---- MFMA waves on 32 x 32 x 16: wave w - 4 = k-step of the chunk
+        const uint32_t ksw = (uint32_t)(wave - 4), l31 = (uint32_t)lane & 31u, kh = (uint32_t)lane >> 5;
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+#pragma unroll
+            for (int c = 0; c < CPN; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc32[i][c][v] = 0.f;
+        uint32_t woff[RP], xoff[CPN];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const uint32_t row = (uint32_t)i * 32 + l31;
+            woff[i] = row * (KC * 4) + (((ksw * 4 + kh * 2) ^ (row & 15u)) * 16);   // the fragment's first granule (8 floats of one row); the second at position ^ 1
+        }
+#pragma unroll
+        for (int c = 0; c < CPN; ++c) {
+            const uint32_t row = (uint32_t)c * 32 + l31;
+            xoff[c] = W_BYTES + (row * GRX + ((ksw * 2 + kh) ^ xswz(row))) * 16;
+        }
+        auto image = [&](uint32_t ch) { return (const char*)(smem_raw + (size_t)(ch % NIMG) * IMG_BYTES); };
+        u4 wsp[RP][3], spare[3];                // this chunk's weight fragments (32 rows x 16 columns) as three bf16 pieces each; the fragment being prepared
+        u4 xa[CPN][3], xb[CPN][3];              // two operand sets of the planes (32 tokens x 16 columns), swapped by name
+        float raw[RP][8];
+        uint32_t s1[8], s2[8];
+        constexpr int P0 = (B9S_ABLATE & 4) ? 8 : (NPROD == 9 ? 0 : (NPROD == 8 ? 1 : 3));
+        constexpr int NMT = (9 - P0) * CPN, NMF = NMT * RP, NDS = 2 * RP + 3 * CPN;
+        auto ds_slot = [&](int e, const char* im, u4 (&xn)[CPN][3]) {
+            if (e < 2 * RP) {
+                const f4 v = *(const f4*)(im + (woff[e >> 1] ^ ((e & 1) ? 16u : 0u)));
+                raw[e >> 1][4 * (e & 1)] = v.x; raw[e >> 1][4 * (e & 1) + 1] = v.y; raw[e >> 1][4 * (e & 1) + 2] = v.z; raw[e >> 1][4 * (e & 1) + 3] = v.w;
+            } else {
+                const int c = (e - 2 * RP) / 3, pl = (e - 2 * RP) % 3;
+                xn[c][pl] = *(const u4*)(im + xoff[c] + (size_t)pl * XP_BYTES);
+            }
+        };
+        // filler atoms of two vector instructions each.  Fragment i: 16 half-splits (and, subtract) of its eight weights, then 6 pairs of byte-permutes
+        // into `spare`; behind fragment i's last MFMA 6 pairs of moves `spare` -> wsp[i]
+        auto half_split = [&](int i, int h) {   // h = 2 f: first half of weight f (its low 16 significand bits), 2 f + 1: second half
+            const int f = h >> 1;
+            if constexpr ((B9S_ABLATE & 2) != 0) return;
+            if (!(h & 1)) {
+                const uint32_t hb = __builtin_bit_cast(uint32_t, raw[i][f]) & 0xffff0000u;
+                s1[f] = __builtin_bit_cast(uint32_t, __fsub_rn(raw[i][f], __builtin_bit_cast(float, hb)));
+                asm volatile("" : "+v"(s1[f]));   // (an empty asm that "uses" the result: without it the optimiser sinks the arithmetic out of its slot, below the fences)
+            } else {
+                const uint32_t mb = s1[f] & 0xffff0000u;
+                s2[f] = __builtin_bit_cast(uint32_t, __fsub_rn(__builtin_bit_cast(float, s1[f]), __builtin_bit_cast(float, mb)));
+                asm volatile("" : "+v"(s2[f]));
+            }
+        };
+        auto perm_pair = [&](int i, int k2) {   // dwords 2 k2, 2 k2 + 1 of the twelve
+#pragma unroll
+            for (int k = 2 * k2; k < 2 * k2 + 2; ++k) {
+                const int pl = k >> 2, d = k & 3;
+                const uint32_t lo = pl == 0 ? __builtin_bit_cast(uint32_t, raw[i][2 * d]) : (pl == 1 ? s1[2 * d] : s2[2 * d]);
+                const uint32_t hi = pl == 0 ? __builtin_bit_cast(uint32_t, raw[i][2 * d + 1]) : (pl == 1 ? s1[2 * d + 1] : s2[2 * d + 1]);
+                spare[pl][d] = (B9S_ABLATE & 2) ? lo : __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+            }
+            asm volatile("" : "+v"(spare[(2 * k2) >> 2]));
+        };
+        auto move_pair = [&](int i, int k2) {
+#pragma unroll
+            for (int k = 2 * k2; k < 2 * k2 + 2; ++k) wsp[i][k >> 2][k & 3] = spare[k >> 2][k & 3];
+            asm volatile("" : "+v"(wsp[i][(2 * k2) >> 2]));
+        };
+        // atom a of fragment i's slot range: [6 move pairs of fragment i - 1 (i > 0)] [16 half-splits] [6 permute pairs]
+        auto atom = [&](int i, int a) {
+            const int nmv = i > 0 ? 6 : 0;
+            if (a < nmv) move_pair(i - 1, a);
+            else if (a < nmv + 16) half_split(i, a - nmv);
+            else perm_pair(i, a - nmv - 16);
+        };
+        // One period, scheduled BY HAND: the operands of chunk ch are in registers (wsp, xc); behind every MFMA, fenced by sched_barrier(0), one
+        // LDS read of chunk ch + 1's operands while there are any (fragments first), and fragment i's atoms dealt evenly over the MFMAs of row pair i
+        // from slot S0 on (the fragment's way from LDS).  (No branch on "is there a next chunk": behind the last one the reads take whatever the
+        // ring's next image holds - the loader's clamped tail requests - and the fragments made of it are never multiplied.)
+        auto period = [&](uint32_t ch, const u4 (&xc)[CPN][3], u4 (&xn)[CPN][3]) {
+            const char* im = image(ch + 1);
+            constexpr int PX[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0}, PW[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const int na = (i > 0 ? 6 : 0) + 22, S0 = i == 0 ? (NMT >= 12 ? 4 : 1) : 0, nsl = NMT - S0;
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    const int q = P0 + m / CPN, c = m % CPN, e = i * NMT + m;
+                    acc32[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xc[c][PX[q]]), __builtin_bit_cast(bf16x8, wsp[i][PW[q]]), acc32[i][c], 0, 0, 0);
+                    if (e < NDS) ds_slot(e, im, xn);
+                    else if (NDS > NMF && e == NMF - 1) {
+#pragma unroll
+                        for (int r = NMF; r < NDS; ++r) ds_slot(r, im, xn);
+                    }
+                    if (m >= S0) {
+#pragma unroll
+                        for (int at = (m - S0) * na / nsl; at < (m - S0 + 1) * na / nsl; ++at) atom(i, at);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 6; ++k2) move_pair(RP - 1, k2);   // the last fragment (behind its last MFMA)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        barrier_lds_only();                     // barrier 0: chunk 0 is in image 0
+#pragma unroll
+        for (int e = 0; e < NDS; ++e) ds_slot(e, smem_raw, xa);
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+#pragma unroll
+            for (int h = 0; h < 16; ++h) half_split(i, h);
+#pragma unroll
+            for (int k2 = 0; k2 < 6; ++k2) perm_pair(i, k2);
+#pragma unroll
+            for (int k2 = 0; k2 < 6; ++k2) move_pair(i, k2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        for (uint32_t ch = 0; ch < nch; ch += 2) {   // two chunks per trip: the operand sets swap by name
+            barrier_lds_only();                 // barrier ch + 1
+            period(ch, xa, xb);
+            if (ch + 1 < nch) {
+                barrier_lds_only();             // barrier ch + 2
+                period(ch + 1, xb, xa);
+            }
+        }
     } else {
         // ---- MFMA waves
         const uint32_t cw = (uint32_t)(wave - 4), kb = cw >> 1, part = cw & 1u, tb = CSP ? 0u : part * T0, cb = CSP ? part * NCW : 0u;
@@ -287,7 +425,17 @@ __global__ __launch_bounds__(B9S_TH) void k_stream_b9(const StreamArgs a) {
 #ifdef Q8B_TRACE
     if (a.trace && blockIdx.x == gridDim.x / 2 && tid == 256) { a.trace[0] = __builtin_amdgcn_s_memtime() - clk_c0; a.trace[1] = __builtin_amdgcn_s_memrealtime() - clk_r0; }
 #endif
-    if constexpr (CSP) stream_epilogue<MAXT, NCT, 2, true>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
+    if constexpr (M32) {
+        // MFMA wave w - 4 holds k-step w - 4 of every tile: lane (row n = lane & 31 of the pair, kh) value v = token 8 (v >> 2) + 4 kh + (v & 3) of the column pair
+        stream_epilogue<MAXT, NCT, 1, true, 0, 3>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, float* base) {
+            const uint32_t n = (uint32_t)lane & 31u, kh2 = (uint32_t)lane >> 5;
+            if ((n >> 4) != (uint32_t)(t & 1)) return;
+#pragma unroll
+            for (int c = 0; c < CPN; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) base[((uint32_t)c * 32 + 8 * (v >> 2) + 4 * kh2 + (v & 3)) * 16 + (n & 15u)] = acc32[t >> 1][c][v];
+        });
+    } else if constexpr (CSP) stream_epilogue<MAXT, NCT, 2, true>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat, [&](int t, int c) { return acc[t][c]; });
     else stream_epilogue<MAXT, NCT, 1, true, 0, 2>(a, smem_raw, (uint32_t)((size_t)NIMG * IMG_BYTES / 4), nullptr, t0, nt, ks, tiles_per_mat,
                                                    [&](int t, int c) { return acc[t >= T0 ? t - T0 : t][c]; });
 }
