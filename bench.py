@@ -10,17 +10,24 @@ random-init weights from the counter-based generator (seed 1234, generated direc
 token ids evaluated as one prefill, then greedy decode at positions P = 8, 9, ...  A "step" is one pass of the hot path
 (llama.Eval with N = 1: 32 x [rmsnorm, wq|wk|wv, rope, attention, wo, rmsnorm, w1|w3, silu*mul, w2] + lm_head) per stream.
 
-N = 1: one stream; steps run device-resident (argmax on the GPU feeds the next step, hipGraph replay).
-N > 1: layers are sharded in contiguous blocks over the ranks (SURVEY §8e); `--pods` independent streams (server.go:88-101;
-       default 4 N) keep the pipeline full: they form N groups of 4, a group takes a tick on one rank as ONE 4-row pass over
-       that rank's weights (lh_batch), and in one step every stream advances one token, so per-GPU work per step is constant
-       (scaling: weak) and value = pods*K tokens / time.  The residual rows [4 x 4096 f32] hop rank r -> r+1 and the token ids
-       return from the last rank to rank 0 as RCCL send/recv issued by the library itself (lh_pipeline_run: schedule, stages
-       and p2p all below the C-ABI); torch.distributed (gloo) only carries the control plane here: the 128-byte RCCL ids, the
-       barriers around the timed regions and the max-over-ranks of the times.  The SAME invocation then times the second curve
-       of SURVEY §8e - one greedy stream walking through the stages - as the side object "single_stream", and checks stream 0's
-       ids against the committed single-GPU ids (tests/golden/7b_seed1234_ids.json) -> "parity".  `--pods P` overrides the
-       stream count of the first phase.  Started without torch.distributed.run, `--gpus N` spawns its own N ranks.  A rank
+N = 1: one stream on the CONTRACT ROUTE: every step is one llama.Eval of one token = one ml_GraphCompute = one
+       lh_graph_compute (the drop-in boundary; the fused plan replays a captured hipGraph inside it) + the host argmax of its logits row,
+       driven by the host library's own loop (llamago_GreedyContinue).  `value` = steps / the time between HIP events recorded on the stream
+       when each lh_graph_compute starts and behind its last launch (lh_ctx_time_computes), the measurement SURVEY §8d names for this config;
+       the same K steps' whole-loop wall rate (host graph build, flatten, match, logits read, argmax included) stands beside it as
+       "eval_per_token_loop", and the device-resident loop (argmax on the GPU feeds the next step, no host round trip: rounds 1-5's
+       `value`, an extension of the boundary) as "resident_loop".
+N > 1: layers are sharded in contiguous blocks over the ranks.  `value` = N independent greedy streams (server.go:88-101:
+       the reference's --pods), ONE ROW PER WEIGHT PASS: N groups of one stream keep every rank busy every tick, a tick is the
+       batch-1 decode step of N = 1 on the rank's L / N layers, and every token reads every weight exactly once - exactly like the
+       N = 1 line, so value(N) / (N x value(1)) is the layer shard's efficiency with no footnote (scaling: weak; per-GPU work per
+       step constant).  The residual row [4096 f32] hops rank r -> r+1 and the token ids return from the last rank to rank 0 as RCCL
+       send/recv issued by the library itself (lh_pipeline_run: schedule, stages and p2p all below the C-ABI); torch.distributed
+       (gloo) only carries the control plane: the 128-byte RCCL id, the barriers around the timed regions and the max-over-ranks
+       of the times.  Side objects of the SAME invocation: "pods_batched_4n" (4 N streams sharing 4-row passes: rounds 3-5's
+       headline - more tokens per weight byte, not comparable with N = 1's single stream), "single_stream" (one stream walking
+       through the stages: the latency curve of SURVEY §8e) and "parity" (stream 0's ids against the committed single-GPU ids,
+       tests/golden/7b_seed1234_ids.json).  `--pods P` / `--rows-per-pass M` override the first phase.  Started without torch.distributed.run, `--gpus N` spawns its own N ranks.  A rank
        that fails prints {"error": ...} and exits non-zero; control-plane waits time out after 120 s.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, HIP-event timed live), "cpu_baseline" (oracle on the host cores,
@@ -114,7 +121,8 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=0, help="decode steps of the CPU baseline / parity legs (default: all --steps, BASELINE.md §3)")
-    ap.add_argument("--pods", type=int, default=0, help="independent greedy streams in flight for N > 1 (default 4 N; 1 = the single-stream latency curve)")
+    ap.add_argument("--pods", type=int, default=0, help="independent greedy streams in flight for N > 1 (default N, one row per weight pass; 1 = the single-stream latency curve)")
+    ap.add_argument("--rows-per-pass", type=int, default=1, help="N > 1: streams a tick evaluates in ONE pass over a rank's weights (default 1 = comparable with N = 1; 0 = as many as fit)")
     ap.add_argument("--no-prefill", action="store_true", help="skip the config-3 side measurement (13B, one 1024-token Eval)")
     ap.add_argument("--int8", action="store_true", help="BASELINE config 4: block-int8 weight matrices (36 B per 32 weights); not the headline metric")
     args = ap.parse_args()
@@ -190,60 +198,43 @@ def main():
         ctx = model.NewContext(ctx_size, 1)
         logits0 = ctx.Eval(PROMPT, 0)  # prefill through ml.GraphCompute (fused plan)
         first = int(np.argmax(logits0))
-        # warm-up steps (also captures the hipGraph), then the timed region from the same state
+        # ---- the timed region: K steps of the contract route from the state behind the prompt (W warm-up steps from the same state first: they also
+        # capture the step's hipGraph).  One step = llama.Eval([id], past) -> ml_GraphCompute -> lh_graph_compute, then the host argmax.
         if W > 0:
-            decode_greedy_resident(ctx, first, P0, W)
+            ctx.GreedyContinue(first, P0, W)
+        ctx.TimeComputes(True)
         sync_all()
         t0 = time.perf_counter()
-        toks, last_logits = decode_greedy_resident(ctx, first, P0, K, want_logits=True)
+        toks = ctx.GreedyContinue(first, P0, K)
         sync_all()
-        dt = time.perf_counter() - t0
+        dt_wall = time.perf_counter() - t0
+        st_timed = ctx.ComputeStats()
+        ctx.TimeComputes(False)
+        last_logits = ctx.logits()
+        assert st_timed["calls"] == K, st_timed
+        dt = st_timed["device_us"] * 1e-6      # HIP events around each of the K lh_graph_compute calls, summed
         tokens_total = K
         tokens = [first] + toks[:-1]  # ids evaluated by the timed steps; toks = ids they produced
         produced = toks
-        # ---- the reference's own loop shape: llama.Eval per token through ml_GraphCompute (graph build + structural match on the
-        # host, hipGraph replay, 128 KB logits D2H, argmax on the host) = the PCIe-inclusive rate a Go caller of the shim gets
-        # Timed INSIDE the host library (llama_GreedyDecode of the C++ twin = the Go loop of server.Do with an argmax for the sampler: one llama.Eval
-        # per token, the last logits row read back, argmax on the host) as t[prompt + K steps] - t[prompt], so that the figure is what a Go caller
-        # of the shim pays and carries none of this script's interpreter time; the same loop driven from Python is reported beside it.
-        c3 = model.NewContext(ctx_size, 1)
-        HEAD = 8   # both timed calls run the prompt + HEAD steps first: the first single-token Eval behind a prompt pays a one-off ~0.45 ms (its graph's first launch)
-        c3.GreedyDecode(PROMPT, HEAD + 1, want_logits=False)
+        result["eval_per_token_loop"] = {"tokens_per_s": round(K / dt_wall, 2), "ms_per_token": round(dt_wall / K * 1e3, 4),
+                                         "inside_lh_graph_compute_wall": {"tokens_per_s": round(K / max(st_timed["wall_us"], 1e-9) * 1e6, 2), "ms_per_call": round(st_timed["wall_us"] / K / 1e3, 4),
+                                                                          "note": "host clock from entry to return of the contract call (validate, match, enqueue, wait, pinned logits row)"},
+                                         "note": "the SAME K timed steps by the wall clock between the barrier + synchronize pairs: llama.Eval per token incl. the caller's graph build (53 us), flatten, "
+                                                 "the library's match, the wait, the logits row and the host argmax - what a Go caller of the shim gets per token; `value` is the HIP-event time of the "
+                                                 "lh_graph_compute calls inside it"}
+        # ---- rounds 1-5's `value`: the device-resident loop (argmax on the GPU feeds the next step, hipGraph replay of eight steps, no host round trip)
+        cr = model.NewContext(ctx_size, 1)
+        cr.Eval(PROMPT, 0)
+        if W > 0:
+            decode_greedy_resident(cr, first, P0, W)
         torch.cuda.synchronize()
-        t_a = time.perf_counter()
-        c3.GreedyDecode(PROMPT, HEAD + 1, want_logits=False)
-        t_b = time.perf_counter()
-        ids_host_loop, _ = c3.GreedyDecode(PROMPT, HEAD + K + 1, want_logits=False)
-        t_c = time.perf_counter()
-        eval_dt = (t_c - t_b) - (t_b - t_a)
-        # the same loop once more with the library's own timers on ("hipEvent around each lh_graph_compute"): device time
-        # and host time inside the contract call, summed over the K single-token computes (difference of the two runs, as above)
-        c3.TimeComputes(True)
-        c3.GreedyDecode(PROMPT, HEAD + 1, want_logits=False)
-        st_a = c3.ComputeStats()
-        c3.TimeComputes(True)
-        c3.GreedyDecode(PROMPT, HEAD + K + 1, want_logits=False)
-        st_b = c3.ComputeStats()
-        c3.TimeComputes(False)
-        n_calls = st_b["calls"] - st_a["calls"]
-        dev_us, in_call_us = st_b["device_us"] - st_a["device_us"], st_b["wall_us"] - st_a["wall_us"]
-        c3.Eval(PROMPT, 0)
-        tk = first
+        t_r = time.perf_counter()
+        toks_res, _ = decode_greedy_resident(cr, first, P0, K, want_logits=True)
         torch.cuda.synchronize()
-        t_e = time.perf_counter()
-        for s_ in range(K):
-            tk = int(np.argmax(c3.Eval([tk], P0 + s_)))
-        py_dt = time.perf_counter() - t_e
-        c3.free()
-        result["eval_per_token_loop"] = {"tokens_per_s": round(K / eval_dt, 2), "ms_per_token": round(eval_dt / K * 1e3, 4),
-                                         "ids_equal_resident_loop": [int(t) for t in ids_host_loop[:min(K, len(produced)) + 1]] == ([first] + [int(t) for t in produced])[:min(K, len(produced)) + 1],
-                                         "driven_from_python_tokens_per_s": round(K / py_dt, 2),
-                                         "lh_graph_compute_hip_event_timed": {"calls": n_calls, "tokens_per_s": round(n_calls / max(dev_us, 1e-9) * 1e6, 2), "ms_per_call": round(dev_us / max(n_calls, 1) / 1e3, 4),
-                                                                              "note": "SURVEY 8d config 2: HIP events on the stream around everything one lh_graph_compute enqueues (lh_ctx_time_computes)"},
-                                         "inside_lh_graph_compute_wall": {"tokens_per_s": round(n_calls / max(in_call_us, 1e-9) * 1e6, 2), "ms_per_call": round(in_call_us / max(n_calls, 1) / 1e3, 4),
-                                                                          "note": "host clock from entry to return of the contract call (validate, match, enqueue, wait, pinned logits row); what is left of "
-                                                                                  "ms_per_token is the caller's graph build + flatten + argmax"},
-                                         "note": "llama.Eval per token via ml_GraphCompute incl. host graph build, logits D2H and host argmax (not `value`)"}
+        dt_res = time.perf_counter() - t_r
+        cr.free()
+        result["resident_loop"] = {"tokens_per_s": round(K / dt_res, 2), "ms_per_token": round(dt_res / K * 1e3, 4), "ids_equal_contract_route": [int(t) for t in toks_res] == [int(t) for t in toks],
+                                   "note": "lh_llama_decode_greedy: the whole loop on the device (an extension of the boundary, not the contract call); `value` of rounds 1-5"}
         # ---- the reference's real generation loop: SampleTopPTopK (topK 40, topP 0.95, repeat penalty 1.10 — main.go:87-90) after every
         # Eval, sampler resident on the device (no logits D2H).  Decode rate = (t[K+1 samples] - t[1 sample]) / K, same prefill in both.
         SMP = dict(topK=min(40, V), topP=0.95, temp=0.8, repeatPenalty=1.10, seed=SEED)
@@ -544,17 +535,18 @@ def main():
                 mt.free()
             except Exception as e:  # a side measurement must never take the headline line down
                 result["int8_decode"] = {"error": str(e)}
-        parallelism = "single GPU, device-resident decode loop (hipGraph replay)"
+        parallelism = "single GPU, one lh_graph_compute per token (fused plan, hipGraph replay inside the call), host argmax"
         pods = 1
         groups = 1
         timed_pos0 = P0
     else:
         # ---------------- layer-sharded pipeline over `world` ranks ----------------
         R = world
-        # streams in flight: R groups of 4 keep every rank busy every tick, each tick one 4-row pass over the rank's weights; a phase
-        # of K steps costs K + (R - 1) ticks per rank (pipeline fill + drain included in the timed region).  The reference's own knob
-        # for this is --pods (server.go:88-101).
-        pods = args.pods or 4 * R
+        # streams in flight: R groups of ONE keep every rank busy every tick, each tick the batch-1 decode step on the rank's layers (every
+        # token reads every weight once, as on one GPU); a phase of K steps costs K + (R - 1) ticks per rank (pipeline fill + drain
+        # included in the timed region).  The reference's own knob for the stream count is --pods (server.go:88-101).
+        pods = args.pods or R
+        rows_per_pass_arg = args.rows_per_pass
         from llama_go_amd.mlapi import Pipeline, comm_unique_id
         from llama_go_amd.pipeline import gloo_comm_hooks, layer_range
         l0, l1 = layer_range(rank, R, L)
@@ -572,7 +564,7 @@ def main():
             fail("model", e)
         F = model.ffSize
 
-        def new_pipeline(n_streams):
+        def new_pipeline(n_streams, max_rows=0):
             comm_id, hooks = None, None
             if shared_gpu:
                 hooks = gloo_comm_hooks(dist)
@@ -580,10 +572,10 @@ def main():
                 obj = [comm_unique_id(prod) if rank == 0 else None]   # ncclGetUniqueId on rank 0; any channel may carry the 128 bytes
                 dist.broadcast_object_list(obj, src=0)
                 comm_id = obj[0]
-            return Pipeline(model, ctx_size, n_streams, rank, R, comm_id=comm_id, hooks=hooks)   # ncclCommInitRank + per-stream stages, one HIP stream
+            return Pipeline(model, ctx_size, n_streams, rank, R, comm_id=comm_id, hooks=hooks, max_rows=max_rows)   # ncclCommInitRank + per-stream stages, one HIP stream
 
-        def timed_phase(n_streams):
-            pl = new_pipeline(n_streams)
+        def timed_phase(n_streams, max_rows=0):
+            pl = new_pipeline(n_streams, max_rows)
             pl.run([PROMPT] * n_streams, W)   # prefill + W warm-up decode steps per stream (lh_pipeline_run); the pipeline drains at the end
             sync_all()
             t0 = time.perf_counter()
@@ -597,7 +589,7 @@ def main():
             return pl, float(tdt.item()), obj[0]
 
         try:
-            pl, dt, all_ids = timed_phase(pods)
+            pl, dt, all_ids = timed_phase(pods, rows_per_pass_arg)
         except Exception as e:
             fail(f"pipeline phase with {pods} streams", e)
         tokens_total = K * pods
@@ -624,8 +616,23 @@ def main():
             return [f for f in flags if f], flags
 
         side_alive = True
+        # ---- rounds 3-5's headline as a side object: 4 N streams, a tick = ONE 4-row pass over the rank's weights (lh_batch)
+        if pods == R and rows_per_pass_arg == 1:
+            err = None
+            try:
+                pl4, dt4, ids4 = timed_phase(4 * R)
+                result["pods_batched_4n"] = {"tokens_per_s": round(4 * R * K / dt4, 2), "ms_per_step": round(dt4 / K * 1e3, 4), "streams": 4 * R, "groups": pl4.groups,
+                                             "rows_per_weight_pass": 4 * R // pl4.groups, "all_streams_equal_value_stream0": all(t == allt for t in ids4),
+                                             "note": "more tokens per weight byte than `value`: compare with pods_batched['4'] of the N = 1 line, not with its single stream"}
+                pl4.free()
+            except Exception as e:
+                err = f"rank {rank}: {e}"
+            bad, _ = all_ranks_ok(err)
+            if bad:
+                result["pods_batched_4n"] = {"error": "; ".join(bad)}
+                side_alive = False
         # ---- second curve of SURVEY §8e in the same invocation: ONE greedy stream walking through the stages (latency, not throughput)
-        if pods != 1:
+        if pods != 1 and side_alive:
             err = None
             try:
                 pl1, dt1, ids1 = timed_phase(1)
@@ -644,7 +651,7 @@ def main():
         if side_alive:
             mine, err = None, None
             try:
-                pld = new_pipeline(pods)
+                pld = new_pipeline(pods, rows_per_pass_arg)
                 pld.run([PROMPT] * pods, 2)
                 hop_us = pld.hop_probe(d * 4, 1000)          # one residual row (16 KB on 7B), every rank shifting at the same time
                 hop_us_tick = pld.hop_probe(d * 4 * max(1, pods // pld.groups), 200)   # the rows of one tick's exchange
@@ -681,8 +688,9 @@ def main():
         else:
             par["reason"] = "golden ids exist for the full fp32 7B model only"
         result["parity"] = par
-        result["weak_scaling_reference"] = ("`value` counts 4N streams that share a pass over each rank's weights four at a time; the matching ONE-GPU point is "
-                                            "pods_batched['4'] of the N = 1 line (four streams, one 4-row pass per tick), not its single-stream `value`")
+        result["scaling_reference"] = {"ideal": f"{R} x value(N = 1)", "why": "N streams, one row per weight pass: each token reads every weight once on N GPUs as on one; "
+                                       "value(N) / (N x value(1)) = efficiency of the layer shard (pipeline fill + drain of K + N - 1 ticks and the hops included)",
+                                       "rows_per_weight_pass": max(1, pods // groups)}
         produced = allt[1:]          # ids produced by the decode steps at positions P0.. (the first W of them by the warm-up)
         timed_pos0 = P0 + W
         parallelism = (f"layer-shard pp{R} ({l1 - l0} layers on this rank), {pods} independent greedy stream{'s' if pods > 1 else ''} in flight as {groups} "
@@ -714,6 +722,11 @@ def main():
         },
         "tokens_stream0": produced[: min(K, 16)],
     }
+    if world == 1:
+        line["value_definition"] = ("SURVEY 8d config 2: K single-token llama.Eval calls through the drop-in boundary; value = K / the sum of the HIP-event intervals around each "
+                                    "lh_graph_compute (stream events at the call's start and behind its last launch); ms_per_step is that interval per call.  The wall clock of the "
+                                    "same K steps between the barrier + synchronize pairs is eval_per_token_loop; the device-resident loop is resident_loop")
+        line["timed_region_wall_s"] = round(dt_wall, 6)
     line.update(result)
     if rank == 0:
         print(json.dumps(line), file=_OUT, flush=True)

@@ -23,6 +23,14 @@ void llamago_CollectGarbage(void);
 /* The graph llama.Eval builds for a model of shape hp, as numbers (needs no GPU): per tensor 11 int32 = op, ne[4], nb[4], src0, src1
  * (indices into the same list, leafs first then nodes in ml.GraphCompute's order, -1 = nil).  Returns the tensor count. */
 int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_t N, uint32_t pastCount, int32_t* out, uint32_t cap_tensors, uint32_t* n_leafs);
+/* The decode part of llama_GreedyDecode's loop on its own: from the context's present state (the caller has evaluated everything up to position
+ * `past`), n_steps times { llama.Eval of ONE token = one ml_GraphCompute = one lh_graph_compute; the host argmax of its logits row }, starting with
+ * `token`; out_tokens[s] = the id step s produced.  The contract route bench.py's headline times.  No context swap: past + n_steps
+ * must stay inside the window. */
+int llamago_GreedyContinue(llama_context* lctx, llama_model* m, uint32_t token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens);
+/* The greedy pick of the generation loops on host logits (strict >, the lowest index wins ties; a NaN at index 0 wins, NaNs elsewhere are skipped -
+ * what `if x[i] > x[best] { best = i }` does).  Exported so that the product's vectorised form is tested against the checker's loop. */
+uint32_t llamago_Argmax(const float* x, uint32_t n);
 /* llama_SampleTopPTopK that also returns the kept candidates in rank order after the topP rescale (the reference's logitsID / probs
  * right before the random pick, llama.go:639-661). */
 int llamago_SampleDebug(ml_context* ctx, const float* logits, uint32_t logitsCount, const uint32_t* lastNTokens, uint32_t lastNTokensSize, uint32_t topK, float topP,

@@ -128,6 +128,13 @@ typedef struct lh_compute_stats {
 int lh_ctx_time_computes(lh_ctx* ctx, int on);
 int lh_ctx_compute_stats(lh_ctx* ctx, lh_compute_stats* out);
 
+/* Route log (test instrumentation, process-wide): while it is on, every kernel launch of the library notes the launched kernel's family - the
+ * __global__'s name without template arguments.  tests/test_gpu_zz_routes.py switches it on for the whole GPU suite and asserts at the end that
+ * every __global__ of the product sources was reached.  lh_route_log(1) clears the set and starts, lh_route_log(0) stops; lh_route_names writes the
+ * names, newline-separated and NUL-terminated, into buf (up to cap bytes) and returns the number of bytes the full list needs. */
+int lh_route_log(int on);
+int64_t lh_route_names(char* buf, uint64_t cap);
+
 /* ---- convenience layer over the same fused plan executor (harnesses, bench, pipeline stages) ------
  * Describes the weights of llama.Model (llama.go:181-193) + one KV cache (llama.go:173-178) for the
  * layer range [layer0, layer1) held by this process. */

@@ -151,6 +151,26 @@ __global__ __launch_bounds__(1024) void k_read_probe(const probe_f4* __restrict_
     if (acc == 12345.678f) sink[blockIdx.x] = acc;   // keeps the loads alive; practically never true
 }
 
+namespace lh {
+std::atomic<int> g_route_log_on{0};
+static std::mutex g_route_mu;
+static std::vector<std::string> g_route_names;
+// "(k_stream_mm2<MAXT, NCT, KC2>)" / "lh::k_embed" / "k_gemm_b9" -> the family name
+void route_note(const char* kernel_expr) {
+    std::string n(kernel_expr);
+    size_t b = 0;
+    while (b < n.size() && (n[b] == '(' || n[b] == ' ')) ++b;
+    size_t e = b;
+    while (e < n.size() && (isalnum((unsigned char)n[e]) || n[e] == '_' || n[e] == ':')) ++e;
+    n = n.substr(b, e - b);
+    const size_t c = n.rfind("::");
+    if (c != std::string::npos) n = n.substr(c + 2);
+    std::lock_guard<std::mutex> g(g_route_mu);
+    for (const auto& s : g_route_names) if (s == n) return;
+    g_route_names.push_back(n);
+}
+}  // namespace lh
+
 extern "C" {
 
 int lh_hbm_read_probe(lh_ctx* ctx, uint64_t bytes, uint32_t repeats, float* gbps) {
@@ -165,9 +185,9 @@ int lh_hbm_read_probe(lh_ctx* ctx, uint64_t bytes, uint32_t repeats, float* gbps
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const uint32_t grid = (uint32_t)ctx->ds->num_cu;
-    hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(1024), 0, ctx->stream, (const probe_f4*)buf, bytes / 16, sink);
+    LH_LAUNCH(k_read_probe, dim3(grid), dim3(1024), 0, ctx->stream, (const probe_f4*)buf, bytes / 16, sink);
     hipEventRecord(e0, ctx->stream);
-    for (uint32_t r = 0; r < repeats; ++r) hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(1024), 0, ctx->stream, (const probe_f4*)buf, bytes / 16, sink);
+    for (uint32_t r = 0; r < repeats; ++r) LH_LAUNCH(k_read_probe, dim3(grid), dim3(1024), 0, ctx->stream, (const probe_f4*)buf, bytes / 16, sink);
     hipEventRecord(e1, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     float ms = 0.f;
@@ -240,7 +260,7 @@ int lh_tensor_register(lh_ctx* ctx, uint64_t key, int dtype, const uint32_t ne[4
         b->scales = (float*)((char*)b->dev + qbytes);
         LH_HIP(ctx, hipMalloc((void**)&raw, nblocks * 36));
         LH_HIP(ctx, hipMemcpy(raw, host, nblocks * 36, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_q8_deinterleave, dim3((unsigned)std::min<uint64_t>((nblocks + 255) / 256, 65535)), dim3(256), 0, ctx->stream, (const unsigned int*)raw,
+        LH_LAUNCH(k_q8_deinterleave, dim3((unsigned)std::min<uint64_t>((nblocks + 255) / 256, 65535)), dim3(256), 0, ctx->stream, (const unsigned int*)raw,
                            (signed char*)b->dev, b->scales, nblocks);
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         LH_HIP(ctx, hipFree(raw));
@@ -323,7 +343,7 @@ int lh_buf_fill_synth(lh_ctx* ctx, lh_buf buf, uint64_t off, uint64_t n, uint64_
     const uint64_t key = mix64(seed ^ ((uint64_t)tensor_id * 0xD6E8FEB86659FD93ull));
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_fill_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b->dev + off, n, key, scale, offset);
+    LH_LAUNCH(k_fill_synth, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, b->dev + off, n, key, scale, offset);
     LH_HIP(ctx, hipGetLastError());
     return LH_OK;
 }
@@ -342,7 +362,7 @@ int lh_buf_quantize_q8(lh_ctx* ctx, lh_buf src, uint32_t rows, uint32_t cols, lh
     b->bytes = qbytes + nblocks * 4;
     LH_HIP(ctx, hipMalloc((void**)&b->dev, b->bytes));
     b->scales = (float*)((char*)b->dev + qbytes);
-    hipLaunchKernelGGL(k_quantize_q8, dim3((unsigned)std::min<uint64_t>((nblocks + 255) / 256, 65535)), dim3(256), 0, ctx->stream, (const float*)sb->dev,
+    LH_LAUNCH(k_quantize_q8, dim3((unsigned)std::min<uint64_t>((nblocks + 255) / 256, 65535)), dim3(256), 0, ctx->stream, (const float*)sb->dev,
                        (signed char*)b->dev, b->scales, nblocks);
     LH_HIP(ctx, hipGetLastError());
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -399,6 +419,19 @@ uint64_t lh_buf_nfloats(lh_ctx* ctx, lh_buf buf) {
     if (!ctx) return 0;
     Buffer* b = find_buffer(ctx->ds, buf);
     return b ? b->nfloats : 0;
+}
+
+int lh_route_log(int on) {
+    if (on) { std::lock_guard<std::mutex> g(lh::g_route_mu); lh::g_route_names.clear(); }
+    lh::g_route_log_on.store(on ? 1 : 0);
+    return LH_OK;
+}
+int64_t lh_route_names(char* buf, uint64_t cap) {
+    std::lock_guard<std::mutex> g(lh::g_route_mu);
+    std::string all;
+    for (const auto& s : lh::g_route_names) { all += s; all += '\n'; }
+    if (buf && cap) { const size_t n = std::min<size_t>(all.size(), (size_t)cap - 1); memcpy(buf, all.data(), n); buf[n] = 0; }
+    return (int64_t)all.size() + 1;
 }
 
 }  // extern "C"

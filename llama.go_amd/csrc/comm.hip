@@ -294,7 +294,6 @@ int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods
     LH_HIP(ctx, hipSetDevice(ctx->device));
     lh_pipeline* pl = new lh_pipeline();
     pl->ctx = ctx; pl->comm = comm; pl->rank = rank; pl->world = world;
-    int wtype = 0;
     for (uint32_t i = 0; i < n_pods; ++i) {
         lh_llama* m = pods[i];
         if (!m || m->ctx != ctx) { delete pl; LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: pod %u lives on another context", i); }
@@ -303,14 +302,13 @@ int lh_pipeline_create_grouped(lh_ctx* ctx, lh_comm* comm, lh_llama* const* pods
             delete pl;
             LH_FAIL(ctx, LH_EINVAL, "lh_pipeline_create: pod %u holds layers [%u,%u) of %u, which is not rank %d of %d in a contiguous layer shard", i, md.layer0, md.layer1, md.L, rank, world);
         }
-        if (i == 0) { pl->d = md.d; pl->ctx_size = md.ctx; pl->vocab = md.V; wtype = md.wtype; }
+        if (i == 0) { pl->d = md.d; pl->ctx_size = md.ctx; pl->vocab = md.V; }
         else if (md.d != pl->d || md.ctx != pl->ctx_size) { delete pl; LH_FAIL(ctx, LH_ESHAPE, "lh_pipeline_create: pods differ in shape"); }
         pl->pods.push_back(m);
     }
     pl->past.assign(n_pods, 0);
     // rows per tick: as many as the P-row kernels take (64) unless the caller asks for fewer; 1 = every stream on its own
-    const uint32_t cap = 64u;   // (block-int8: 48 until round 4's k_stream_q8)
-    (void)wtype;
+    const uint32_t cap = 64u;   // (fp32 and block-int8 alike: plan.hip BATCH_ROWS_MAX)
     const uint32_t mr = max_rows ? std::min(max_rows, cap) : cap;
     const uint32_t G = group_count(n_pods, (uint32_t)world, mr);
     pl->groups.resize(G);

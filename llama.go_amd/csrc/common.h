@@ -26,6 +26,21 @@ void set_error(lh_ctx* ctx, const char* fmt, ...) __attribute__((format(printf, 
         }                                                                                               \
     } while (0)
 
+// Every kernel launch of the library goes through LH_LAUNCH: with the route log on (lh_route_log; tests/test_gpu_zz_routes.py) the kernel FAMILY (the
+// __global__'s name without its template arguments) is noted, so that the test suite can assert that every product kernel is reached by a parity test.
+extern std::atomic<int> g_route_log_on;
+void route_note(const char* kernel_expr);
+#define LH_LAUNCH(kern, ...)                                                        \
+    do {                                                                            \
+        if (lh::g_route_log_on.load(std::memory_order_relaxed)) lh::route_note(#kern); \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                                      \
+    } while (0)
+#define LH_LAUNCH_AS(family, kern, ...)                                             \
+    do {                                                                            \
+        if (lh::g_route_log_on.load(std::memory_order_relaxed)) lh::route_note(family); \
+        hipLaunchKernelGGL(kern, __VA_ARGS__);                                      \
+    } while (0)
+
 #define LH_FAIL(ctx, code, ...)          \
     do {                                 \
         lh::set_error(ctx, __VA_ARGS__); \

@@ -330,51 +330,51 @@ static int run_node(lh_ctx* ctx, const lh_tensor* T, const std::vector<float*>& 
             } else {
                 LH_FAIL(ctx, LH_EUNSUPPORTED, "GetRows: indices must be a host leaf (they cannot be bounds-checked on the device)");
             }
-            hipLaunchKernelGGL(g_get_rows, dim3((unsigned)nelem(b)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
+            LH_LAUNCH(g_get_rows, dim3((unsigned)nelem(b)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
             break;
         }
         case OP_RMS_NORM: {
             const lh_tensor& a = T[t.src0];
-            hipLaunchKernelGGL(g_rms_norm, dim3(a.ne[1] * a.ne[2] * a.ne[3]), dim3(256), 0, st, V(t.src0), V(i));
+            LH_LAUNCH(g_rms_norm, dim3(a.ne[1] * a.ne[2] * a.ne[3]), dim3(256), 0, st, V(t.src0), V(i));
             break;
         }
-        case OP_REPEAT: hipLaunchKernelGGL(g_repeat, grid_for((uint64_t)t.ne[0] * t.ne[1]), dim3(256), 0, st, V(t.src0), V(i)); break;
+        case OP_REPEAT: LH_LAUNCH(g_repeat, grid_for((uint64_t)t.ne[0] * t.ne[1]), dim3(256), 0, st, V(t.src0), V(i)); break;
         case OP_MUL: {
             const lh_tensor &a = T[t.src0], &b = T[t.src1];
             for (int k = 0; k < 4; ++k)
                 if (a.ne[k] != b.ne[k] || a.ne[k] != t.ne[k]) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardMulFP32 : different shapes!");
-            hipLaunchKernelGGL(g_mul, grid_for(nelem(a)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
+            LH_LAUNCH(g_mul, grid_for(nelem(a)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
             break;
         }
         case OP_ADD: {
             if (T[t.src1].nb[0] != 4) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardAddFP32 : [src1] is NOT contiguous!");
-            hipLaunchKernelGGL(g_add, grid_for(nelem(T[t.src0])), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
+            LH_LAUNCH(g_add, grid_for(nelem(T[t.src0])), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
             break;
         }
         case OP_SILU: {
             if (!contiguous(T[t.src0])) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardSiluFP32 : [src0] is NOT contiguous!");
             if (!contiguous(t)) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardSiluFP32 : [dst] is NOT contiguous!");
-            hipLaunchKernelGGL(g_silu, grid_for(nelem(t)), dim3(256), 0, st, V(t.src0), V(i));
+            LH_LAUNCH(g_silu, grid_for(nelem(t)), dim3(256), 0, st, V(t.src0), V(i));
             break;
         }
         case OP_SCALE: {
             if (!contiguous(T[t.src0])) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardScaleFP32 : [src0] is NOT contiguous!");
             if (!contiguous(t)) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardScaleFP32 : [dst] is NOT contiguous!");
-            hipLaunchKernelGGL(g_scale, grid_for(nelem(t)), dim3(256), 0, st, V(i), (const float*)P[t.src1]);
+            LH_LAUNCH(g_scale, grid_for(nelem(t)), dim3(256), 0, st, V(i), (const float*)P[t.src1]);
             break;
         }
         case OP_CPY: {
             const lh_tensor& a = T[t.src0];
             if (!contiguous(t)) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardDupFP32 : [dst] is NOT contiguous!");
             if (nelem(t) != nelem(a)) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardDupFP32 : [dst] and [src0] capacities are different!");
-            hipLaunchKernelGGL(g_cpy, grid_for(nelem(a)), dim3(256), 0, st, V(t.src0), P[i], nelem(a));
+            LH_LAUNCH(g_cpy, grid_for(nelem(a)), dim3(256), 0, st, V(t.src0), P[i], nelem(a));
             break;
         }
-        case OP_DIAG_MASK_INF: hipLaunchKernelGGL(g_diag_mask_inf, grid_for(nelem(t)), dim3(256), 0, st, V(i), (const float*)P[t.src1]); break;
+        case OP_DIAG_MASK_INF: LH_LAUNCH(g_diag_mask_inf, grid_for(nelem(t)), dim3(256), 0, st, V(i), (const float*)P[t.src1]); break;
         case OP_SOFT_MAX: {
             if (!contiguous(T[t.src0])) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardSoftMaxFP32 : [src0] is NOT contiguous!");
             if (!contiguous(t)) LH_FAIL(ctx, LH_ESHAPE, "[HALT] ComputeForwardSoftMaxFP32 : [dst] is NOT contiguous!");
-            hipLaunchKernelGGL(g_soft_max, dim3(t.ne[1] * t.ne[2] * t.ne[3]), dim3(256), 0, st, V(i));
+            LH_LAUNCH(g_soft_max, dim3(t.ne[1] * t.ne[2] * t.ne[3]), dim3(256), 0, st, V(i));
             break;
         }
         case OP_ROPE: {
@@ -387,7 +387,7 @@ static int run_node(lh_ctx* ctx, const lh_tensor* T, const std::vector<float*>& 
             int rc = ensure_rope_table(ctx, maxpos + 1, dims, &table);
             if (rc) return rc;
             const uint64_t total = (uint64_t)t.ne[3] * t.ne[2] * t.ne[1] * (dims / 2);
-            hipLaunchKernelGGL(g_rope, grid_for(total), dim3(256), 0, st, V(i), table, past, dims, mode);
+            LH_LAUNCH(g_rope, grid_for(total), dim3(256), 0, st, V(i), table, past, dims, mode);
             break;
         }
         case OP_MUL_MAT: {
@@ -399,7 +399,7 @@ static int run_node(lh_ctx* ctx, const lh_tensor* T, const std::vector<float*>& 
                                  a.ne[0] % 4 == 0 && a.ne[0] <= 24576 && a.ne[1] >= 256;
             if (plain2d) return gemm_small_n(ctx, P[t.src0], P[t.src1], P[i], nullptr, a.ne[1], a.ne[0], b.ne[1], a.ne[0], a.ne[1], "mul_mat");
             const uint64_t outs = (uint64_t)a.ne[1] * a.ne[2] * a.ne[3] * b.ne[1];
-            hipLaunchKernelGGL(g_mul_mat, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
+            LH_LAUNCH(g_mul_mat, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0, st, V(t.src0), V(t.src1), V(i));
             break;
         }
         default: LH_FAIL(ctx, LH_EUNSUPPORTED, "[HALT] Please implement : op %d (the reference halts on it too, ml.go:1536-1700)", (int)t.op);

@@ -96,7 +96,7 @@ static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    LH_LAUNCH((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -108,7 +108,7 @@ static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP, THR>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    LH_LAUNCH((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP, THR>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -204,7 +204,7 @@ static int launch_gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL((k_gemv_rows<KI, U, THR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    LH_LAUNCH((k_gemv_rows<KI, U, THR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -255,7 +255,7 @@ static int launch_gemv_q8_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* n
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    hipLaunchKernelGGL((k_gemv_q8_rows<KI, U, 256, 256, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(256), FAT_LDS, ctx->stream, a);
+    LH_LAUNCH((k_gemv_q8_rows<KI, U, 256, 256, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(256), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -297,7 +297,7 @@ static int launch_cols(lh_ctx* ctx, const GemmColsArgs& a, const char* name) {
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4);
-    hipLaunchKernelGGL(kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
+    LH_LAUNCH_AS("k_gemv_cols", kern, dim3(ctx->ds->num_cu), dim3(TH), FAT_LDS, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -367,10 +367,10 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
             a.part = ctx->splitk;
         }
         const uint64_t work = (uint64_t)tiles * batch * splits;
-        hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(work, (uint64_t)ncu)), dim3(256), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_gemm_glds", kern, dim3((uint32_t)std::min<uint64_t>(work, (uint64_t)ncu)), dim3(256), lds, ctx->stream, a);
         if (splits > 1) {
             const uint64_t quads = (uint64_t)a.groups * a.N * (a.M / 4);
-            hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+            LH_LAUNCH(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
         }
     } else {
         auto kern = k_gemm_mfma<WN, WM, TN, TM>;
@@ -378,7 +378,7 @@ static int launch_gemm(lh_ctx* ctx, const GemmArgs& a0, const char* name, uint32
         int rc = set_lds_once(ctx, kern, lds, flags[0]);
         if (rc) return rc;
         if (g_prepare_only) return 0;
-        hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(256), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_gemm_mfma", kern, dim3(tiles, batch), dim3(256), lds, ctx->stream, a);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -448,14 +448,14 @@ static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t 
     {
         TraceScope ts_(ctx->stream, "split3_rows");
         Split3Args sa = {a.x, xs, a.xs_plane, a.K, a.ldx, a.K};
-        hipLaunchKernelGGL(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
+        LH_LAUNCH(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
     }
     const uint64_t items = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups * (splits > 1 ? splits : 1);
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K / 32 * 36 * a.groups);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(items, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    LH_LAUNCH_AS("k_gemm_q8b3", kern, dim3((uint32_t)std::min<uint64_t>(items, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
     if (splits > 1) {
         const uint64_t quads = (uint64_t)a.groups * a.N * (a.M / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+        LH_LAUNCH(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -510,23 +510,23 @@ static int gemm_q8_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t gro
         const size_t lds = std::max<size_t>((size_t)2 * (128 + 160) * 32 * sizeof(float), 82 * 1024);
         if ((rc = set_lds_once(ctx, kern, lds, flags[1]))) return rc;
         if (g_prepare_only) return 0;
-        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_gemm_q8", kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
     } else if (shape == 2) {
         auto kern = k_gemm_q8<2, 2, 1, 2>;
         const size_t lds = std::max<size_t>((size_t)2 * (64 + 128) * 32 * sizeof(float), 82 * 1024);
         if ((rc = set_lds_once(ctx, kern, lds, flags[2]))) return rc;
         if (g_prepare_only) return 0;
-        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_gemm_q8", kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
     } else {
         auto kern = k_gemm_q8<2, 2, 2, 2>;
         const size_t lds = std::max<size_t>((size_t)2 * (128 + 128) * 32 * sizeof(float), 82 * 1024);
         if ((rc = set_lds_once(ctx, kern, lds, flags[0]))) return rc;
         if (g_prepare_only) return 0;
-        hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_gemm_q8", kern, dim3(std::min<uint32_t>(items, ncu)), dim3(256), lds, ctx->stream, a);
     }
     if (a.splits > 1) {
         const uint64_t quads = (uint64_t)groups * n * (M / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+        LH_LAUNCH(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -565,8 +565,8 @@ static int attention_gemm(Plan* p, const float* q, const float* kc, const float*
         a.causal = 1; a.past = past;
         if ((rc = launch_gemm<2, 2, 2, 2>(ctx, a, "attn_qk_gemm", H))) return rc;
     }
-    hipLaunchKernelGGL(k_softmax_causal, dim3(n, H), dim3(256), 0, ctx->stream, p->scores, n, Tp, past, scale);
-    hipLaunchKernelGGL(k_transpose_v, dim3(Tp / 32, hd / 32, H), dim3(256), 0, ctx->stream, vc, p->vt, T, Tp, d, hd);
+    LH_LAUNCH(k_softmax_causal, dim3(n, H), dim3(256), 0, ctx->stream, p->scores, n, Tp, past, scale);
+    LH_LAUNCH(k_transpose_v, dim3(Tp / 32, hd / 32, H), dim3(256), 0, ctx->stream, vc, p->vt, T, Tp, d, hd);
     LH_HIP(ctx, hipGetLastError());
     {   // O[j][h*hd + c] = sum_t P[h][j][t] * VT[h][c][t]
         GemmArgs a = {};
@@ -611,11 +611,11 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
     const uint32_t items = (a.nwork ? a.nwork : a.nqb) * m.H, grid = std::min<uint32_t>(items, slots);
     {
         ProfScope ps(ctx->stream, "attn_flash", (uint64_t)2 * (past + n) * m.d * 4);
-        hipLaunchKernelGGL(k_attn_flash, dim3(grid), dim3(FA_TH), FA_LDS_BYTES, ctx->stream, a);
+        LH_LAUNCH(k_attn_flash, dim3(grid), dim3(FA_TH), FA_LDS_BYTES, ctx->stream, a);
     }
     if (cut) {
         ProfScope ps(ctx->stream, "attn_flash_combine", (uint64_t)m.H * (a.nqb - w.qb_cut) * w.pmax * FA_BQ * FA_PSTRIDE * 4);
-        hipLaunchKernelGGL(k_attn_flash_combine, dim3(m.H, a.nqb - w.qb_cut), dim3(256), 0, ctx->stream, a);
+        LH_LAUNCH(k_attn_flash_combine, dim3(m.H, a.nqb - w.qb_cut), dim3(256), 0, ctx->stream, a);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -637,23 +637,19 @@ static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
 
 template <int MAXT, int NCT, int KC>
 static int launch_stream(lh_ctx* ctx, const StreamArgs& a, const char* name) {
-    static bool flags[2][16] = {};
-    // wave-specialised variant (loader waves + MFMA waves, two LDS images) whenever the two images fit, else the first variant (every
-    // wave loads and computes)
+    static bool flags[16] = {};
+    // k_stream_mm2 (loader waves + MFMA waves, two LDS images); shapes whose two images do not fit have no launch here (round 1's kernel in which
+    // every wave loaded and multiplied took them until round 6: no LLaMA shape reached it - tests/test_gpu_zz_routes.py; tools/kernels_stream_mm_r1.h)
     if (a.ws[0]) return ST_NA;   // (block-int8: k_stream_q8b)
-    const bool v2 = stream2_lds_bytes(MAXT, NCT, KC) <= 160 * 1024;
-    if ((a.gamma || a.ksplit > 1 || NCT > 2 || a.rows) && !v2) return ST_NA;   // folded norm, K-split, 3 / 4 column tiles, batched rows: specialised variant only
-    const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     constexpr int KC2 = KC <= 256 ? KC : 256;
-    const size_t lds = std::max<size_t>(v2 ? stream2_lds_bytes(MAXT, NCT, KC) : stream_lds_bytes(MAXT, NCT, KC), 82 * 1024);   // one workgroup per CU
-    // instantiations outside a variant's range are never launched (returned above); the clamps only keep them from being compiled
-    constexpr int NCT1 = NCT <= 2 ? NCT : 2, KC1 = KC >= 128 ? KC : 128;
-    int rc = v2 ? set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2>, lds, flags[1]) : set_lds_once(ctx, k_stream_mm<MAXT, NCT1, KC1>, lds, flags[0]);
+    if (stream2_lds_bytes(MAXT, NCT, KC2) > 160 * 1024) return ST_NA;
+    const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
+    const size_t lds = std::max<size_t>(stream2_lds_bytes(MAXT, NCT, KC2), 82 * 1024);   // one workgroup per CU
+    int rc = set_lds_once(ctx, k_stream_mm2<MAXT, NCT, KC2>, lds, flags);
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
-    if (v2) hipLaunchKernelGGL((k_stream_mm2<MAXT, NCT, KC2>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((k_stream_mm<MAXT, NCT1, KC1>), dim3(ctx->ds->num_cu), dim3(ST_TH), lds, ctx->stream, a);
+    LH_LAUNCH((k_stream_mm2<MAXT, NCT, KC2>), dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -677,7 +673,7 @@ static int launch_stream_dma(lh_ctx* ctx, const StreamArgs& a, const char* name)
     if (g_prepare_only) return 0;
     const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
     ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
+    LH_LAUNCH_AS("k_stream_dma", kern, dim3(grid), dim3(2 * ST_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -809,7 +805,7 @@ static int gemm_stream_split(lh_ctx* ctx, const float* w, const float* x, uint32
     if (g_prepare_only) return 0;
     StreamReduceArgs r = {};
     r.part = ctx->splitk; r.stride = a.ysplit; r.resid = resid; r.y = y; r.gamma = gamma; r.h = h; r.S = S; r.d = M; r.ldy = M;
-    { TraceScope ts_(ctx->stream, "stream_reduce_norm"); hipLaunchKernelGGL(k_stream_reduce_norm, dim3(n), dim3(256), 0, ctx->stream, r); }
+    { TraceScope ts_(ctx->stream, "stream_reduce_norm"); LH_LAUNCH(k_stream_reduce_norm, dim3(n), dim3(256), 0, ctx->stream, r); }
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -834,7 +830,7 @@ static int launch_stream_q8b(lh_ctx* ctx, const StreamArgs& a, const char* name)
         if (g_prepare_only) return 0;
         const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
         ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K / 32 * 36);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(Q8B_TH), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_stream_q8b", kern, dim3(grid), dim3(Q8B_TH), lds, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         return 0;
     }
@@ -888,7 +884,7 @@ static int launch_stream_b9(lh_ctx* ctx, const StreamArgs& a, const char* name) 
         if (g_prepare_only) return 0;
         const uint32_t grid = a.ksplit > 1 ? (uint32_t)ctx->ds->num_cu / a.ksplit * a.ksplit : (uint32_t)ctx->ds->num_cu;
         ProfScope ps(ctx->stream, name, (uint64_t)a.groups * a.M * a.K * 4);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(B9S_TH), lds, ctx->stream, a);
+        LH_LAUNCH_AS("k_stream_b9", kern, dim3(grid), dim3(B9S_TH), lds, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         return 0;
     }
@@ -962,7 +958,7 @@ static int gemm_q8b_split(lh_ctx* ctx, const float* wq, const float* wsc, const 
     if (g_prepare_only) return 0;
     StreamReduceArgs r = {};
     r.part = ctx->splitk; r.stride = a.ysplit; r.resid = resid; r.y = y; r.gamma = gamma; r.h = h; r.S = S; r.d = M; r.ldy = M; r.hs = hs; r.hs_plane = hs_plane;
-    { TraceScope ts_(ctx->stream, "stream_reduce_norm"); hipLaunchKernelGGL(k_stream_reduce_norm, dim3(n), dim3(256), 0, ctx->stream, r); }
+    { TraceScope ts_(ctx->stream, "stream_reduce_norm"); LH_LAUNCH(k_stream_reduce_norm, dim3(n), dim3(256), 0, ctx->stream, r); }
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -999,14 +995,14 @@ static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t sp
     {
         TraceScope ts_(ctx->stream, "split3_rows");
         Split3Args sa = {a.x, ctx->xs3, a.xs_plane, a.K, a.ldx, a.K};
-        hipLaunchKernelGGL(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
+        LH_LAUNCH(k_split3_rows, dim3(a.N), dim3(256), 0, ctx->stream, sa);
     }
     const uint64_t items = (uint64_t)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.groups * (splits > 1 ? splits : 1);
     ProfScope ps(ctx->stream, name, (uint64_t)a.M * a.K * 4 * a.groups);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)std::min<uint64_t>(items, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
+    LH_LAUNCH_AS("k_gemm_b9", kern, dim3((uint32_t)std::min<uint64_t>(items, (uint64_t)ctx->ds->num_cu)), dim3(512), lds, ctx->stream, a);
     if (splits > 1) {
         const uint64_t quads = (uint64_t)a.groups * a.N * (a.M / 4);
-        hipLaunchKernelGGL(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
+        LH_LAUNCH(k_splitk_reduce, dim3((uint32_t)std::min<uint64_t>((quads + 255) / 256, 4096)), dim3(256), 0, ctx->stream, a);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -1152,7 +1148,7 @@ static int launch_skinny(Plan* p, SkinnyArgs a, const char* name) {
         b.k0 = k0; b.kc = kc;
         b.part_in = ch > 0 ? p->part : nullptr;
         b.part_out = ch + 1 < nchunks ? p->part : nullptr;
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(SK_TH), lds, ctx->stream, b);
+        LH_LAUNCH_AS("k_skinny", kern, dim3(nwg), dim3(SK_TH), lds, ctx->stream, b);
         k0 += kc;
     }
     LH_HIP(ctx, hipGetLastError());
@@ -1174,7 +1170,7 @@ static int launch_attention(lh_ctx* ctx, const AttnArgs& a, uint32_t max_T) {
     if (g_prepare_only) return 0;
     if (g_only) return 0;
     ProfScope ps(ctx->stream, "attention", (uint64_t)2 * max_T * a.d * 4);
-    hipLaunchKernelGGL(k_attention, dim3(a.d / a.hd, a.n), dim3(ATT_TH), lds, ctx->stream, a);
+    LH_LAUNCH(k_attention, dim3(a.d / a.hd, a.n), dim3(ATT_TH), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1189,11 +1185,11 @@ static int launch_attention_split(Plan* p, const AttnArgs& a, float* part) {
     if (g_prepare_only || g_only) return 0;
     {
         ProfScope ps(ctx->stream, "attention_split", (uint64_t)2 * m.ctx * a.d * 4 * nrows);
-        hipLaunchKernelGGL(k_attention_split, dim3(m.H, nch, nrows), dim3(ATT_TH), 0, ctx->stream, a, part);
+        LH_LAUNCH(k_attention_split, dim3(m.H, nch, nrows), dim3(ATT_TH), 0, ctx->stream, a, part);
     }
     {
         ProfScope ps(ctx->stream, "attention_combine", (uint64_t)m.H * nch * (a.hd + 2) * 4 * nrows);
-        hipLaunchKernelGGL(k_attention_combine, dim3(m.H, nrows), dim3(128), 0, ctx->stream, a, (const float*)part, nch);
+        LH_LAUNCH(k_attention_combine, dim3(m.H, nrows), dim3(128), 0, ctx->stream, a, (const float*)part, nch);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -1321,7 +1317,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         if (!g_prepare_only && !g_only) {
             ProfScope ps(ctx->stream, "embed", (uint64_t)m.d * 4);
             TraceScope ts_(ctx->stream, "embed1");
-            hipLaunchKernelGGL(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d, m.V);
+            LH_LAUNCH(k_embed, dim3(1), dim3(256), 0, ctx->stream, m.tok_emb, tokens_dev, sp, p->xa, m.d, m.V);
             LH_HIP(ctx, hipGetLastError());
         }
     } else {
@@ -1379,7 +1375,7 @@ static int enqueue_decode(Plan* p, const StepParams* sp, const float* x_in, floa
         } else if ((argmax_advance || argmax_out) && !g_prepare_only) {
             ProfScope ps(ctx->stream, "argmax", (uint64_t)m.V * 4);
             TraceScope ts_(ctx->stream, "argmax");
-            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)p->logits, m.V, (StepParams*)sp, p->out_tokens_dev,
+            LH_LAUNCH(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)p->logits, m.V, (StepParams*)sp, p->out_tokens_dev,
                                argmax_out, argmax_advance ? 1 : 0);
             LH_HIP(ctx, hipGetLastError());
         }
@@ -1443,7 +1439,7 @@ static int launch_resident_steps(Plan* p, uint32_t n_steps, int slot1, int slotn
 
 static int upload_step_params(Plan* p, uint32_t slot, uint32_t token, uint32_t past, uint32_t step) {
     lh_ctx* ctx = p->ctx;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, ctx->stream, p->sp_dev + slot, token, past, step);
+    LH_LAUNCH(k_set_step, dim3(1), dim3(1), 0, ctx->stream, p->sp_dev + slot, token, past, step);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -1461,7 +1457,7 @@ int plan_embeddings(Plan* p, uint32_t n, float** out) {
     }
     // every route of plan_eval leaves the residual rows behind the last layer in p->xa; RMSNorm (ml.go:1753-1812) then Mul by the norm weight
     // (ml.go:1877-1914): k_rmsnorm_rows' arithmetic (fp32 squares, f64 sum, one fp32 scale, two roundings per element)
-    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xa, m.norm, p->emb, m.d);
+    LH_LAUNCH(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xa, m.norm, p->emb, m.d);
     LH_HIP(ctx, hipGetLastError());
     *out = p->emb;
     return 0;
@@ -1622,7 +1618,7 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
         const size_t slot = (size_t)(il - m.cache_layer0) * m.ctx * d;
-        if (!h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_s3"); if (!g_prepare_only) hipLaunchKernelGGL(k_rmsnorm_rows_s3, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, (float*)nullptr, hs, pd, d); }
+        if (!h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_s3"); if (!g_prepare_only) LH_LAUNCH(k_rmsnorm_rows_s3, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, (float*)nullptr, hs, pd, d); }
         {   // wq|wk|wv -> RoPE(Q, new K rows) -> K, V appended   (llama.go:263-297)
             const float* wqkv[3] = {L.wq, L.wk, L.wv};
             const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
@@ -1643,11 +1639,11 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
         } else if (n >= 32 && m.hd == FA_HD) {   // a prompt: single pass, online softmax; its rows are split by a pass of their own
             if ((rc = attention_flash(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
             Split3Args sa = {p->attn, as, pd, d, d, d};
-            if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); hipLaunchKernelGGL(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
+            if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); LH_LAUNCH(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
         } else if (n >= 32 && m.hd % 32 == 0) {   // other head sizes: batched MFMA GEMMs over heads with a score tensor (as plan_eval's fp32 route does)
             if ((rc = attention_gemm(p, p->q, m.kc + slot, m.vc + slot, p->attn, n, past, scale))) return rc;
             Split3Args sa = {p->attn, as, pd, d, d, d};
-            if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); hipLaunchKernelGGL(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
+            if (!g_prepare_only) { TraceScope ts_(ctx->stream, "split3_rows"); LH_LAUNCH(k_split3_rows, dim3(n), dim3(256), 0, ctx->stream, sa); }
         } else {
             AttnArgs a = {};
             a.q = p->q; a.k_cache = m.kc + slot; a.v_cache = m.vc + slot; a.out = p->attn; a.d = d; a.hd = m.hd; a.n = n; a.scale = scale; a.sp = nullptr; a.past_host = past;
@@ -1740,7 +1736,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
                 memcpy(ctx->staging, tokens_host, (size_t)n * 4);
                 LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
             }
-            if (!g_prepare_only) hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, tok_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
+            if (!g_prepare_only) LH_LAUNCH(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, tok_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
             LH_HIP(ctx, hipGetLastError());
         } else {
             x = x_in_dev;
@@ -1802,7 +1798,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         LH_HIP(ctx, hipGetLastError());
         return 0;
     }
-    // block-int8: 3..48 rows on the stream kernel's dequantising loader
+    // block-int8: 5..64 rows of a tick / 5..88 of a prompt on k_stream_q8b (two 64-row passes from 65); from 89 rows the tile GEMM k_gemm_q8b3 below
     const bool q8_stream = q8_stream_ok(ctx, m, n, 3, bc != nullptr);
     if (m.wtype == 7 && !q8_stream && (n < Q8_GEMM_MIN_ROWS || m.d % GBK || m.F % GBK || m.hd % 32)) {
         // block-int8, short batches: n causal single-token steps on the int8 weight stream (bit-identical to what the decode
@@ -1825,7 +1821,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // staging reuse
             memcpy(ctx->staging, tokens_host, (size_t)n * 4);
             LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
+            LH_LAUNCH(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, (const uint32_t*)p->tokens_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
             LH_HIP(ctx, hipGetLastError());
         } else {
             x = x_in_dev;
@@ -1892,7 +1888,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             LH_HIP(ctx, hipMemcpyAsync(p->tokens_dev, ctx->staging, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         }
         TraceScope ts_(ctx->stream, "embedN");
-        hipLaunchKernelGGL(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, tok_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
+        LH_LAUNCH(k_embed, dim3(n), dim3(256), 0, ctx->stream, m.tok_emb, tok_dev, (const StepParams*)nullptr, p->xa, m.d, m.V);
         LH_HIP(ctx, hipGetLastError());
     } else {
         x = x_in_dev;
@@ -1936,7 +1932,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if (rs < 0) return rs;
             qkv_roped = rs == 0;
         }
-        if (!qkv_roped && !h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
+        if (!qkv_roped && !h_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_a"); LH_LAUNCH(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, x, L.attn_norm, p->h, d); }
         h_ready = false;
         if (qkv_roped) {
         } else if (q8) {   // (prompts beyond k_stream_q8b's 64 rows)
@@ -1956,7 +1952,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if ((rc = gemm_small_n(ctx, L.wk, p->h, p->kraw, nullptr, d, d, n, d, d, "gemm_wk"))) return rc;
             if ((rc = gemm_small_n(ctx, L.wv, p->h, p->vraw, nullptr, d, d, n, d, d, "gemm_wv"))) return rc;
         }
-        if (!qkv_roped) { TraceScope ts_(ctx->stream, "rope_store"); hipLaunchKernelGGL(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
+        if (!qkv_roped) { TraceScope ts_(ctx->stream, "rope_store"); LH_LAUNCH(k_rope_store, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->qraw, (const float*)p->kraw, (const float*)p->vraw, p->q, m.kc + slot,
                            m.vc + slot, rope, d, m.hd, past, rows, (uint64_t)slot); }
         if (rows) {   // rows of different streams: one query each, against its own cache up to its own position
             AttnArgs a = {};
@@ -1993,7 +1989,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if (rs < 0) return rs;
             gated = rs == 0;
         }
-        if (!gated && !hf_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
+        if (!gated && !hf_ready) { TraceScope ts_(ctx->stream, "rmsnorm_rows_f"); LH_LAUNCH(k_rmsnorm_rows, dim3(n), dim3(256), 0, ctx->stream, (const float*)p->xb, L.ffn_norm, p->h, d); }
         if (gated) {
         } else if (q8) {
             if ((rc = gemm_q8_group(ctx, p->h, d, 2, w13, s13, y13, nullptr, F, d, n, F, "gemm_q8_w1w3"))) return rc;
@@ -2013,7 +2009,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
             if ((rc = gemm_small_n(ctx, L.w1, p->h, p->a1, nullptr, F, d, n, d, F, "gemm_w1"))) return rc;
             if ((rc = gemm_small_n(ctx, L.w3, p->h, p->a3, nullptr, F, d, n, d, F, "gemm_w3"))) return rc;
         }
-        if (!gated) { TraceScope ts_(ctx->stream, "silu_mul"); hipLaunchKernelGGL(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
+        if (!gated) { TraceScope ts_(ctx->stream, "silu_mul"); LH_LAUNCH(k_silu_mul, dim3(std::min<uint64_t>(((uint64_t)n * F + 255) / 256, 4096)), dim3(256), 0, ctx->stream, (const float*)p->a1,
                            (const float*)p->a3, p->g, (uint64_t)n * F); }
         const bool last = il + 1 == m.layer1;
         float* y = (last && !m.last_stage()) ? x_out_dev : p->xa;
@@ -2034,7 +2030,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         // the reference evaluates norm + lm_head for all N rows (llama.go:372-384) although only row N-1 is read (llama.go:394-401);
         // callers that say so (LH_GRAPH_LAST_ROW_LOGITS, the lh_llama_* entry points) get that row only, in its usual place
         const uint32_t r0 = last_row_only ? n - 1 : 0, nr = n - r0;
-        { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); hipLaunchKernelGGL(k_rmsnorm_rows, dim3(nr), dim3(256), 0, ctx->stream, x + (size_t)r0 * d, m.norm, p->h + (size_t)r0 * d, d); }
+        { TraceScope ts_(ctx->stream, "rmsnorm_rows_final"); LH_LAUNCH(k_rmsnorm_rows, dim3(nr), dim3(256), 0, ctx->stream, x + (size_t)r0 * d, m.norm, p->h + (size_t)r0 * d, d); }
         if (m.wtype == 7) {
             if (nr >= Q8_GEMM_MIN_ROWS) {
                 if ((rc = gemm_q8(ctx, m.output, m.s_output, p->h + (size_t)r0 * d, p->logits + (size_t)r0 * m.V, nullptr, m.V, d, nr, d, m.V, "gemm_q8_lmhead"))) return rc;
@@ -2136,12 +2132,12 @@ static int batch_enqueue_tick(Batch* b, const float* x_in, float* x_out) {
             if ((rc = sample_launch(ctx, b->logits() + (size_t)i * m.V, m.V, b->ss_dev + i, b->ring_dev + (size_t)i * b->ring_cap, b->sp_dev + i, b->out_dev + (size_t)i * b->out_cap,
                                     nullptr, nullptr, nullptr, nullptr, 1, b->smp_topk)))
                 return rc;
-        hipLaunchKernelGGL(k_batch_from_sp, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->ids_dev, (const StepParams*)b->sp_dev, B);
+        LH_LAUNCH(k_batch_from_sp, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->ids_dev, (const StepParams*)b->sp_dev, B);
     } else if (m.last_stage()) {
-        hipLaunchKernelGGL(k_batch_argmax, dim3(B), dim3(1024), 0, ctx->stream, (const float*)b->logits(), m.V, b->rows_dev, b->tok_dev, b->ids_dev, b->out_dev, b->out_cap,
+        LH_LAUNCH(k_batch_argmax, dim3(B), dim3(1024), 0, ctx->stream, (const float*)b->logits(), m.V, b->rows_dev, b->tok_dev, b->ids_dev, b->out_dev, b->out_cap,
                            b->sp_dev, 1);
     } else {
-        hipLaunchKernelGGL(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, B);
+        LH_LAUNCH(k_batch_advance, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, B);
     }
     LH_HIP(ctx, hipGetLastError());
     return 0;
@@ -2210,7 +2206,7 @@ static int batch_set(Batch* b, const uint32_t* tokens, const uint32_t* past, uin
         v.pos[i] = past[i];
         v.tok[i] = tokens ? tokens[i] : 0;
     }
-    hipLaunchKernelGGL(k_batch_set, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->B, tokens ? 1 : 0, v, b->sp_dev, step0);
+    LH_LAUNCH(k_batch_set, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->tok_dev, b->B, tokens ? 1 : 0, v, b->sp_dev, step0);
     LH_HIP(ctx, hipGetLastError());
     b->pos.assign(past, past + b->B);
     b->pos_known = true;
@@ -2486,7 +2482,7 @@ int lh_llama_stage(lh_llama* m, const uint32_t* tokens, const uint32_t* tokens_d
         if (md.first_stage() && !tokens) LH_FAIL(ctx, LH_EINVAL, "stage: multi-row first stage needs host token ids");
         if ((rc = plan_eval(p, tokens, x_in_dev, x_out_dev, n, past, true))) return rc;
         if (md.last_stage() && argmax_dev) {
-            hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)(p->logits + (size_t)(n - 1) * md.V), md.V, (StepParams*)nullptr,
+            LH_LAUNCH(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, (const float*)(p->logits + (size_t)(n - 1) * md.V), md.V, (StepParams*)nullptr,
                                (uint32_t*)nullptr, argmax_dev, 0);
             LH_HIP(ctx, hipGetLastError());
         }
@@ -2619,7 +2615,7 @@ int lh_batch_set_sampler(lh_batch* h, const lh_sample_params* sp, uint32_t ring_
         b->tok0_known = true;
         b->step0 = 0; b->ticks = 0; b->drained = 0;
     }
-    hipLaunchKernelGGL(k_batch_reset_steps, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, b->B);
+    LH_LAUNCH(k_batch_reset_steps, dim3(1), dim3(64), 0, ctx->stream, b->rows_dev, b->sp_dev, b->B);
     LH_HIP(ctx, hipGetLastError());
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     b->sampling = true;
@@ -2661,7 +2657,7 @@ int lh_batch_prompt(lh_batch* h, const uint32_t* const* prompts, const uint32_t*
                                         nullptr, nullptr, nullptr, 1, b->smp_topk)))
                     return rc;
             } else {
-                hipLaunchKernelGGL(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, last_row, m.V, (StepParams*)nullptr, b->out_dev + (size_t)i * b->out_cap, b->ids_dev + i, 0);
+                LH_LAUNCH(k_argmax_advance, dim3(1), dim3(1024), 0, ctx->stream, last_row, m.V, (StepParams*)nullptr, b->out_dev + (size_t)i * b->out_cap, b->ids_dev + i, 0);
                 LH_HIP(ctx, hipMemcpyAsync(b->out_dev + (size_t)i * b->out_cap, b->ids_dev + i, 4, hipMemcpyDeviceToDevice, ctx->stream));
             }
         }
@@ -2727,7 +2723,7 @@ int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t
     if ((rc = enqueue_decode(p, p->sp_dev, pin, pout, false, nullptr))) return rc;
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     g_prof = &sink;
-    hipLaunchKernelGGL(k_park, dim3(1), dim3(1), 0, ctx->stream, (uint64_t)(repeats * 1500000ull));  // 15 ms per repeat of host queueing time
+    LH_LAUNCH(k_park, dim3(1), dim3(1), 0, ctx->stream, (uint64_t)(repeats * 1500000ull));  // 15 ms per repeat of host queueing time
     for (uint32_t r = 0; r < repeats && !rc; ++r) rc = enqueue_decode(p, p->sp_dev, pin, pout, false, p->md.last_stage() ? p->argmax_dev : nullptr);
     g_prof = nullptr;
     hipStreamSynchronize(ctx->stream);
@@ -2762,7 +2758,7 @@ int lh_llama_profile_decode(lh_llama* m, uint32_t token, uint32_t past, uint32_t
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         g_only = only_name;
-        hipLaunchKernelGGL(k_park, dim3(1), dim3(1), 0, ctx->stream, (uint64_t)(repeats * 300000ull));
+        LH_LAUNCH(k_park, dim3(1), dim3(1), 0, ctx->stream, (uint64_t)(repeats * 300000ull));
         hipEventRecord(e0, ctx->stream);
         for (uint32_t r = 0; r < repeats && !rc; ++r) rc = enqueue_decode(p, p->sp_dev, pin, pout, false, nullptr);
         hipEventRecord(e1, ctx->stream);

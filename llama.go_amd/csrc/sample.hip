@@ -20,13 +20,13 @@ int sample_launch(lh_ctx* ctx, const float* logits, uint32_t V, SampleState* st,
                   uint32_t* dbg_ids, float* dbg_probs, uint32_t* dbg_keep, int advance, uint32_t topk_hint) {
     const bool small_k = topk_hint && topk_hint <= 64;
     if (small_k && V <= 32u * 1024u)
-        hipLaunchKernelGGL(k_sample_small<32>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
+        LH_LAUNCH(k_sample_small<32>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
     else if (small_k)
-        hipLaunchKernelGGL(k_sample_small<64>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
+        LH_LAUNCH(k_sample_small<64>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
     else if (V <= 32u * 1024u)
-        hipLaunchKernelGGL(k_sample<32>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
+        LH_LAUNCH(k_sample<32>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
     else
-        hipLaunchKernelGGL(k_sample<64>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
+        LH_LAUNCH(k_sample<64>, dim3(1), dim3(1024), 0, ctx->stream, logits, V, st, ring, sp, out_tokens, token_out, dbg_ids, dbg_probs, dbg_keep, advance);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }

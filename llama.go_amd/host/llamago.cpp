@@ -841,23 +841,22 @@ int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_
 
 static uint32_t argmax_f32(const float* x, uint32_t n) {  // strict >, lowest index wins ties
     // two passes: the maximum over eight independent lanes (vectorises; the one-pass `x[i] > x[best]` chain cost ~40 us on 32000 logits, a
-    // tenth of what a token's whole host side may cost), then the first index that holds it
+    // tenth of what a token's whole host side may cost), then the first index that holds it.  NaNs as the reference's `x[i] > x[best]` loop treats
+    // them: a NaN at index 0 wins (nothing compares greater than it), a NaN anywhere else is skipped - the lanes start at -inf and `x > m` is
+    // false for a NaN, so it never enters a lane (seeding the lanes with x[0..7] let a NaN there blind its lane).
+    if (n == 0 || x[0] != x[0]) return 0;
     float m[8];
+    for (int j = 0; j < 8; j++) m[j] = -INFINITY;
     uint32_t i = 0;
-    if (n >= 8) {
-        for (int j = 0; j < 8; j++) m[j] = x[j];
-        for (i = 8; i + 8 <= n; i += 8)
-            for (int j = 0; j < 8; j++) m[j] = x[i + j] > m[j] ? x[i + j] : m[j];
-    } else {
-        for (int j = 0; j < 8; j++) m[j] = x[0];
-    }
+    for (; i + 8 <= n; i += 8)
+        for (int j = 0; j < 8; j++) m[j] = x[i + j] > m[j] ? x[i + j] : m[j];
     float mx = m[0];
     for (int j = 1; j < 8; j++) mx = m[j] > mx ? m[j] : mx;
     for (; i < n; i++) mx = x[i] > mx ? x[i] : mx;
     for (uint32_t k = 0; k < n; k++) if (x[k] == mx) return k;
-    uint32_t best = 0;   // (NaNs only: the reference's loop keeps index 0 then as well)
-    return best;
+    return 0;   // (every element a NaN behind a first one that is not: cannot happen - x[0] then equals mx)
 }
+extern "C" uint32_t llamago_Argmax(const float* x, uint32_t n) { return argmax_f32(x, n); }
 int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prompt, uint32_t n_prompt, uint32_t n_predict, uint32_t* out_tokens,
                        float* step_logits) {  // loop shape of server.Do, server.go:153-217, one llama.Eval (= one ml_GraphCompute) per token
     uint32_t past = 0;
@@ -884,6 +883,17 @@ int llama_GreedyDecode(llama_context* lctx, llama_model* m, const uint32_t* prom
         }
         if (llama_Eval(lctx, m, embd.data(), (uint32_t)embd.size(), past)) return 1;
         past += (uint32_t)embd.size();
+    }
+    return 0;
+}
+int llamago_GreedyContinue(llama_context* lctx, llama_model* m, uint32_t token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens) {
+    if (!lctx || !m || !out_tokens) { g_err = "llamago_GreedyContinue: null argument"; return 1; }
+    if ((uint64_t)past + n_steps > lctx->ctxSize) { g_err = "llamago_GreedyContinue: the steps run past the context window"; return 1; }
+    const uint32_t V = m->hp.vocabSize;
+    for (uint32_t s = 0; s < n_steps; s++) {
+        if (llama_Eval(lctx, m, &token, 1, past + s)) return 1;
+        token = argmax_f32(lctx->logits.data(), V);
+        out_tokens[s] = token;
     }
     return 0;
 }

@@ -302,6 +302,16 @@ class Context:
             raise MLError(f"llama_GreedyDecode: {self.ml.last_error()}")
         return list(out), lg
 
+    def GreedyContinue(self, token, past, n_steps):
+        """llamago_GreedyContinue: n_steps x { llama.Eval of one token through ml_GraphCompute, host argmax } from the context's present state."""
+        L = self.ml.lib
+        L.llamago_GreedyContinue.restype = C.c_int
+        L.llamago_GreedyContinue.argtypes = [VP, VP, c_u32, c_u32, c_u32, c_u32p]
+        out = (c_u32 * max(n_steps, 1))()
+        if L.llamago_GreedyContinue(self.h, self.model.h, int(token), int(past), int(n_steps), out):
+            raise MLError(f"llamago_GreedyContinue: {self.ml.last_error()}")
+        return [int(t) for t in out[:n_steps]]
+
     def TimeComputes(self, on=True):
         """lh_ctx_time_computes: HIP events around every lh_graph_compute of this context; zeroes the sums."""
         L = self.ml.lib
@@ -638,7 +648,20 @@ def load_product():
         from . import LIBLLAMAGO, LIBLLAMAHIP
         if not os.path.exists(LIBLLAMAHIP):
             raise MLError(f"HIP extension missing: {LIBLLAMAHIP} — build it with __graft_entry__.build(); no CPU fallback exists")
-        C.CDLL(LIBLLAMAHIP, mode=C.RTLD_GLOBAL)
+        hip = C.CDLL(LIBLLAMAHIP, mode=C.RTLD_GLOBAL)
         _product = MLLib(LIBLLAMAGO)
         _bind_extensions(_product)
+        route_file = os.environ.get("LLAMAHIP_ROUTE_FILE")
+        if route_file:   # test instrumentation (tests/test_gpu_zz_routes.py): this process appends the kernel families it launched when it exits
+            import atexit
+            hip.lh_route_log(1)
+            hip.lh_route_names.restype = C.c_int64
+            hip.lh_route_names.argtypes = [C.c_char_p, C.c_uint64]
+
+            def _dump_routes():
+                buf = C.create_string_buffer(int(hip.lh_route_names(None, 0)) + 16)
+                hip.lh_route_names(buf, len(buf))
+                with open(route_file, "a") as f:
+                    f.write(buf.value.decode())
+            atexit.register(_dump_routes)
     return _product

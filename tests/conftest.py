@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
 
 
+def pytest_runtest_logreport(report):
+    # how many GPU tests of this session have passed so far: tests/test_gpu_zz_routes.py only judges the kernel routes of a (nearly) full suite
+    if report.when == "call" and report.passed and "gpu" in report.keywords:
+        _SESSION["gpu_passed"] = _SESSION.get("gpu_passed", 0) + 1
+
+
+_SESSION = {}
+
+
+@pytest.fixture(scope="session")
+def gpu_tests_passed():
+    return lambda: _SESSION.get("gpu_passed", 0)
+
+
 @pytest.fixture(scope="session")
 def built():
     """Make sure every native library exists (build() is a no-op when they are up to date)."""
@@ -81,8 +95,11 @@ def oracle(built):
 
 
 @pytest.fixture(scope="session")
-def product(built):
+def product(built, tmp_path_factory):
     """The product: libllamago.so -> libllamahip.so -> MI355X.  No CPU fallback exists."""
+    # route log (include/llamahip.h lh_route_log; tests/test_gpu_zz_routes.py): this process and the worker processes the pipeline tests spawn
+    # note the kernel family of every launch; the workers append theirs to this file when they exit (mlapi.load_product)
+    os.environ.setdefault("LLAMAHIP_ROUTE_FILE", str(tmp_path_factory.mktemp("routes") / "routes.txt"))
     from llama_go_amd.mlapi import load_product
     lib = load_product()
     lib.lib.llamago_DeviceCount.restype = __import__("ctypes").c_int

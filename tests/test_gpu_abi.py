@@ -97,3 +97,32 @@ def test_graph_compute_through_the_raw_abi(lh):
     assert lh.lh_buf_read(ctx, buf.value, 0, wb.ctypes.data_as(C.POINTER(C.c_float)), 8) == 0 and np.array_equal(wb, w.reshape(-1)[:8])
     assert lh.lh_buf_free(ctx, buf.value) == 0
     lh.lh_ctx_destroy(ctx)
+
+
+def test_block_int8_registered_from_host_blocks(lh):
+    """lh_tensor_register with dtype 7: the host hands the interchange format - blocks {float d; int8 q[32]} (kernels_q8.h) - and the library
+    de-interleaves them on the device into its int8 plane + scale plane (k_q8_deinterleave); read back dequantised they must equal fl32(d * q)
+    of every block, bit for bit."""
+    ctx = C.c_void_p()
+    assert lh.lh_ctx_create(0, None, C.byref(ctx)) == 0, lh.lh_last_error(None)
+    rng = np.random.default_rng(11)
+    K, M = 352, 77                                   # 11 blocks per row
+    w = (rng.standard_normal((M, K)) * 0.05).astype(np.float32)
+    wb = w.reshape(-1, 32)
+    d = (np.abs(wb).max(axis=1) / np.float32(127.0)).astype(np.float32)
+    q = np.clip(np.rint(wb / np.where(d > 0, d, 1)[:, None]), -127, 127).astype(np.int8)
+    blocks = np.zeros(len(d), dtype=np.dtype([("d", "<f4"), ("q", "i1", 32)]))
+    blocks["d"], blocks["q"] = d, q
+    assert blocks.itemsize == 36
+    ne = (C.c_uint32 * 4)(K, M, 1, 1)
+    buf = C.c_uint64()
+    assert lh.lh_tensor_register(ctx, 0, 7, ne, 1, blocks.ctypes.data, C.byref(buf)) == 0, lh.lh_last_error(ctx)
+    back = np.empty(M * K, np.float32)
+    assert lh.lh_buf_read(ctx, buf.value, 0, back.ctypes.data_as(C.POINTER(C.c_float)), back.size) == 0, lh.lh_last_error(ctx)
+    want = (d[:, None] * q.astype(np.float32)).astype(np.float32).reshape(-1)
+    assert np.array_equal(back, want)
+    part = np.empty(100, np.float32)                 # an unaligned range crossing blocks
+    assert lh.lh_buf_read(ctx, buf.value, 45, part.ctypes.data_as(C.POINTER(C.c_float)), part.size) == 0
+    assert np.array_equal(part, want[45:145])
+    assert lh.lh_buf_free(ctx, buf.value) == 0
+    lh.lh_ctx_destroy(ctx)

@@ -98,7 +98,7 @@ def test_odd_shapes_block_int8(product, oracle, kw, ctx, n_prompt):
     assert th == to
 
 
-@pytest.mark.parametrize("n_prompt", [8, 40, 100, 300])
+@pytest.mark.parametrize("n_prompt", [8, 40, 60, 100, 300])
 def test_results_are_bitwise_reproducible(product, n_prompt):
     """Fixed reduction orders everywhere (wave trees, split-K partials summed by a second pass, no float atomics): the same Eval
     twice, on fresh contexts, gives the same bits — for the weight-stream, 64-row-tile, split-K and multi-tile GEMM paths."""
@@ -241,12 +241,12 @@ def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     assert greedy_margin(lg_o) > 10 * TOL, "test seed has a near-tie; pick another"
 
 
-@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 32, 33, 48, 49, 64, 65, 80, 81, 96, 97, 112, 113, 128, 129])   # both sides of every launch-shape boundary
+@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 81, 96, 97, 112, 113, 127, 128, 129])   # both sides of every launch-shape boundary, ragged last tiles (16 k - 1)
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
-    """One Eval of N tokens: 2..96 rows take the weight-streaming MFMA kernel (k_stream_mm2, v_mfma_f32_16x16x4_f32, RoPE / cache
-    append / SiLU fused into its epilogues; one to six 16-column tiles, ragged last tile), more rows the fp32 tile GEMM
-    (v_mfma_f32_32x32x2_f32, tile width and split-K picked by the cost model) + blocked attention; the next decode steps read the KV
-    cache that prefill wrote."""
+    """One Eval of N tokens: 2..8 rows ride the decode weight stream (k_gemv_rows), 9..16 k_stream_mm2 (fp32 MFMA, RMSNorm folded), 17..48 and
+    65..128 k_stream_dma (fp32 MFMA behind LDS-DMA loader waves), 49..64 k_stream_b9 (eight exact bf16 products per weight over activation
+    planes, round 6) - RoPE / cache append / SiLU fused into the epilogues, ragged last column tile - and more rows the tile GEMMs + blocked
+    attention; the next decode steps read the KV cache that prefill wrote."""
     rng = np.random.default_rng(n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n_prompt)]
     out = decode_both(product, oracle, "small", 128 if n_prompt <= 120 else 192, prompt, 4)
@@ -565,11 +565,11 @@ def test_headline_workload_at_full_depth(product, int8):
     m.free()
 
 
-@pytest.mark.parametrize("n_prompt", [3, 6, 8, 12, 24, 40, 56, 72, 90, 97, 112, 127, 128, 129])
+@pytest.mark.parametrize("n_prompt", [3, 6, 8, 12, 24, 40, 49, 56, 64, 72, 90, 97, 112, 127, 128, 129])
 def test_7b_shape_slice_short_prompts_match_oracle(product, oracle, n_prompt):
     """The 7B layer shape at the prompt lengths where the launch shape changes: 3 / 6 / 8 rows (the decode weight stream with four / eight
     activation rows), 12 rows (MFMA stream kernel, RMSNorm folded into the GEMMs), 24 rows (two column tiles, LDS-DMA loader waves; wo / w2 as
-    K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles), 56 rows (four), 72 / 90 rows (five / six),
+    K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles), 49 / 56 / 64 rows (four: k_stream_b9 over planes, wo / w2 as K-split fours), 72 / 90 rows (five / six),
     97 / 112 / 127 / 128 rows (eight column tiles, MFMA waves as 2 K-groups x 2 column halves), 129 rows (the tile GEMM) - 2 layers, then 2
     decode steps on the cache the prompt wrote."""
     rng = np.random.default_rng(100 + n_prompt)
@@ -609,12 +609,12 @@ def test_block_int8_weights_match_dequantised_oracle(product, oracle, shape, lay
     assert th == to
 
 
-@pytest.mark.parametrize("shape,n_prompt", [("small", 3), ("small", 8), ("small", 16), ("small", 20), ("small", 32), ("small", 33), ("small", 45), ("small", 48), ("small", 100), ("small", 300), ("13B", 72),
+@pytest.mark.parametrize("shape,n_prompt", [("small", 3), ("small", 8), ("small", 16), ("small", 20), ("small", 32), ("small", 33), ("small", 45), ("small", 48), ("small", 88), ("small", 89), ("small", 100), ("small", 300), ("13B", 72),
                                             ("13B", 24), ("13B", 260), ("small", 129)])
 def test_block_int8_prefill_gemm_matches_dequantised_oracle(product, oracle, shape, n_prompt):
     """Prompts of more than 128 tokens on a block-int8 model run a tile GEMM - k_gemm_q8b3 (int8 x three bf16 planes of the activations,
     three exact-product MFMAs per quant block) where its 128 x 256 tiles pay, else the dequantising k_gemm_q8 (int8 + scale -> fl32(d*q) ->
-    LDS -> fp32 MFMA); up to 128 tokens k_stream_q8b; single rows the int8 GEMV stream.  Both must agree with the checker's
+    LDS -> fp32 MFMA); 5..88 tokens k_stream_q8b (two 64-row passes from 65), from 89 one 128-row tile of k_gemm_q8b3; single rows the int8 GEMV stream.  Both must agree with the checker's
     dequantise-then-fp32 evaluation, and with each other on the cache they share."""
     kw = dict(SHAPES[shape])
     kw["layers"] = 2 if shape == "small" else 1     # 13B shape: 5120 = 32 x 160 columns -> the 128 x 160 tile variant

@@ -49,9 +49,13 @@ def test_two_rank_pipeline_reproduces_single_process_tokens(product):
                         cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stderr[-3000:]
     two = only_json(r2.stdout)
-    assert two["n_gpus"] == 2 and two["config"]["streams"] == 8   # default: 4 streams per rank in flight
+    assert two["n_gpus"] == 2 and two["config"]["streams"] == 2   # default since round 6: one stream per rank, one row per weight pass (comparable with N = 1)
+    assert two["roofline_token"]["rows_per_weight_pass"] == 1 and two["scaling_reference"]["ideal"] == "2 x value(N = 1)"
     assert two["tokens_stream0"] == one["tokens_stream0"], (one["tokens_stream0"], two["tokens_stream0"])
     assert len(one["tokens_stream0"]) == 6
+    # the side objects: 4 N streams in 4-row passes (the headline of rounds 3-5), one stream walking through the stages
+    assert two["pods_batched_4n"]["streams"] == 8 and two["pods_batched_4n"]["rows_per_weight_pass"] == 4 and two["pods_batched_4n"]["all_streams_equal_value_stream0"] is True
+    assert two["single_stream"]["ids_match_batched_stream0"] is True
 
 
 def _bench(args, env, nranks, launcher):
@@ -199,3 +203,22 @@ def test_pipeline_argument_errors(product):
         Pipeline(half, 32, 1, 0, 1)        # half of the layers is not rank 0 of a world of one
     half.free()
     m.free()
+
+
+def test_real_rccl_two_ranks_when_the_box_has_two_gpus(product):
+    """RCCL with MORE THAN ONE rank has never run in this project's history (every gpurun box has one GPU): the first box with two GPUs validates
+    it inside `pytest -m gpu`.  `bench.py --gpus 2` on the full 7B model, one rank per GPU, ncclCommInitRank + grouped ncclSend / ncclRecv of the
+    residual rows on the compute streams (csrc/comm.hip) - stream 0's ids must be the committed single-GPU ids (tests/golden/7b_seed1234_ids.json,
+    checked against the oracle when they were written), every stream equal to it, and the single-stream walk through the stages too."""
+    product.lib.llamago_DeviceCount.restype = __import__("ctypes").c_int
+    if product.lib.llamago_DeviceCount() < 2:
+        pytest.skip("one GPU visible: RCCL with two ranks needs two (the shared-GPU tests above cover the scheduler over the host-staged transport)")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_SHARED_GPU"):
+        env.pop(k, None)
+    two = _bench(["--steps", "8", "--warmup", "2", "--no-cpu-baseline"], env, 2, "torchrun")
+    assert two["n_gpus"] == 2 and two["config"]["streams"] == 2
+    assert "SHARED-GPU" not in two["config"]["parallelism"]
+    assert two["parity"]["ids_match_single_gpu"] is True and two["parity"]["all_streams_equal"] is True, two["parity"]
+    assert two["single_stream"]["ids_match_batched_stream0"] is True, two["single_stream"]
+    assert two["pods_batched_4n"]["all_streams_equal_value_stream0"] is True, two["pods_batched_4n"]

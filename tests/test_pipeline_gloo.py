@@ -134,7 +134,7 @@ def reference_tokens(world, pods, steps):
     return out
 
 
-@pytest.mark.parametrize("world,pods,steps", [(2, 2, 4), (3, 4, 3), (3, 1, 4)])
+@pytest.mark.parametrize("world,pods,steps", [(2, 2, 4), (3, 4, 3), (3, 1, 4), (8, 8, 3), (8, 1, 2)])   # world 8: the driver's largest run - eight groups of one, and one stream through eight stages
 def test_pipeline_over_gloo_matches_single_process(built, tmp_path, world, pods, steps):
     import json
     import socket

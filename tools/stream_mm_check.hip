@@ -6,6 +6,7 @@
 // (The -DSTREAM_PROBE / STREAM_TRACE builds of rounds 2-4 - one traffic class taken out of the loop, per-phase shader clocks - went out of the
 // product header in round 5; their results are in profiles/r02d_stream_traffic_probe.txt, r03_stream_*.txt, r04_stream_*.txt.)
 #include "../llama.go_amd/csrc/kernels_stream.h"
+#include "kernels_stream_mm_r1.h"
 #include "kernels_stream_eq.h"
 #include <cstdio>
 #include <cstdlib>
