@@ -387,10 +387,15 @@ def main():
                     pb[str(P)] = {"tokens_per_s": round(P * K / d_b, 1), "ms_per_tick": round(tick * 1e3, 4),
                                   "frac_of_hbm_roofline": round(f_hbm, 4), "frac_of_fp32_mfma_peak": round(f_mfma, 4), "bound": "hbm" if f_hbm >= f_mfma else "mfma",
                                   "ids_match_single_stream": all(t[:n_c] == solo[:n_c] for t in ids_b)}
+                    if P >= 49 and not args.int8:   # 49..64 rows: k_stream_b9 - eight exact bf16 products per weight (round 6), priced against ITS pipe as well
+                        pb[str(P)]["matmul_kernel"] = "k_stream_b9 (bf16 matrix pipe, 8 exact products per weight)"
+                        pb[str(P)]["frac_of_exact_split_bf16_roof"] = round(2.0 * P * macs_row * 8 / tick / 2.5e15, 4)
                 result["pods_batched"] = dict(pb, note="P independent greedy streams on ONE GPU, one pass over the weights per tick for all of them "
                                                        "(rows = pods: the decode stream itself up to 8 rows, the MFMA stream kernels beyond; per-row KV cache and position); "
-                                                       "aggregate tokens/s; fractions against 8 TB/s and the 157.3 TFLOP/s fp32 matrix peak (the chip holds ~2.09 GHz under this load, "
-                                                       "i.e. ~137 TFLOP/s: profiles/r04_stream_eight_tiles_clock.txt)")
+                                                       "aggregate tokens/s; fractions against 8 TB/s and the 157.3 TFLOP/s fp32 matrix peak (the chip holds ~2.09 GHz under the fp32-MFMA "
+                                                       "stream kernels, i.e. ~137 TFLOP/s: profiles/r04_stream_eight_tiles_clock.txt); from 49 pods the matmuls run on the bf16 pipe as eight exact "
+                                                       "products per weight (k_stream_b9): frac_of_exact_split_bf16_roof = 8 x the fp32-equivalent flops against 2.5 PFLOP/s - the kernel is "
+                                                       "POWER-bound there (1.6-1.9 GHz, profiles/r06_stream_b9_probe.txt)")
             except Exception as e:  # a side measurement must never take the headline line down
                 result["pods_batched"] = {"error": str(e)}
         ctx.free()

@@ -13,7 +13,7 @@ for step in "$@"; do
   kind=${step%%:*}; rest=${step#*:}; [ "$rest" = "$step" ] && rest=""
   t0=$(date +%s)
   case $kind in
-    tests) if [ -n "$rest" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$rest" > "$O/tests.log" 2>&1; else timeout 1500 python -m pytest tests -m gpu -x -q > "$O/tests.log" 2>&1; fi
+    tests) if [ -n "$rest" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -rs -k "$rest" > "$O/tests.log" 2>&1; else timeout 1500 python -m pytest tests -m gpu -x -q -rs > "$O/tests.log" 2>&1; fi
            echo "rc=$?" >> "$O/tests.log"; grep -E "^(FAILED|ERROR)|passed|failed|^rc=" "$O/tests.log" | tail -8 ;;   # (a tail would show RCCL's exit banner, not the verdict)
     bench) timeout 900 python bench.py $rest > "$O/bench.json" 2> "$O/bench.err"; echo "bench rc=$?"; tail -c 1500 "$O/bench.json" ;;
     trace) tag=${rest%%:*}; cmd=${rest#*:}
