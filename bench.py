@@ -259,11 +259,19 @@ def main():
         per_pair_us = dom["avg_us"]
         if dom["name"] in b2b:  # the dominant kernel's launches of a step back to back between ONE event pair (no per-kernel event cost)
             dom = dict(b2b[dom["name"]], name=dom["name"])
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch from the committed PMC pass (counters cannot be collected from inside this process)
+        traffic, traffic_src, traffic_ok = None, None, None
+        try:  # HBM bytes per launch from the committed PMC pass (counters cannot be collected from inside this process); only believed while the
+            # kernel sources are the ones the pass profiled (tools/source_hash.py: sha256 over csrc/ + include/llamahip.h, stamped by tools/pmc_summary.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from source_hash import kernel_source_hash
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if not args.int8 and args.shape == "7B":
-                traffic, traffic_src = pmc["bytes_per_launch"].get(dom["name"]), pmc["source"]
+                traffic_ok = pmc.get("kernel_source_sha256") == kernel_source_hash()
+                if traffic_ok:
+                    traffic, traffic_src = pmc["bytes_per_launch"].get(dom["name"]), pmc["source"]
+                else:
+                    traffic_src = ("dropped: profiles/pmc_traffic.json was measured on other kernel sources (kernel_source_sha256 differs) - rerun the pmc:f32 step of "
+                                   "tools/gpu/r6_final.sh")
         except Exception:
             pass
         # what this box's HBM delivers to a kernel that only reads (lh_hbm_read_probe: the weight stream's access pattern, no arithmetic),
@@ -277,7 +285,7 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "kernel": dom["name"], "achieved": round(dom["gbps"], 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 4), "measured_read_stream_GBps": round(meas, 1) if meas else None,
-            "frac_of_measured_stream": round(dom["gbps"] / meas, 4) if meas else None, "traffic": traffic, "traffic_source": traffic_src,
+            "frac_of_measured_stream": round(dom["gbps"] / meas, 4) if meas else None, "traffic": traffic, "traffic_source": traffic_src, "traffic_build_matches": traffic_ok,
             "bytes_per_launch": dom["bytes_per_launch"], "avg_us": round(dom["avg_us"], 2), "avg_us_with_event_pair_per_launch": round(per_pair_us, 2),
             "note": "algorithmic bytes = rows*cols*4 of the weights one launch streams (SURVEY 8d); avg_us = HIP events around the kernel's 32 launches "
                     "of a step, back to back, all weights distinct (agrees with the rocprofv3 kernel trace in profiles/); traffic (PMC) in profiles/",

@@ -155,12 +155,20 @@ __global__ __launch_bounds__(WN * WM * 64) void k_gemm_b9(const GemmArgs a) {
             o[d] = __builtin_amdgcn_perm(sb[pl][j][2 * d + 1], sb[pl][j][2 * d], 0x07060302u);
             o[d + 1] = __builtin_amdgcn_perm(sb[pl][j][2 * d + 3], sb[pl][j][2 * d + 2], 0x07060302u);
         };
-        constexpr int NMF = 9 * TN * TM, NDS = 3 * TN + 2 * TM, NPC = 14 * TM;   // MFMAs, LDS reads, vector pieces (8 splits + 6 packs per fragment)
+        // (round 6) EIGHT of the nine products: xl * wl - at most 2^-32 of its product, far below the fp32 accumulator's own rounding - is dropped.  The kernel is
+        // power-bound (1.44-1.74 GHz with every CU on the bf16 pipe), so an MFMA saved is time saved; against an f64 product the error does not move
+        // (profiles/r06_gemm_b9_products.txt; the same measurement on the stream kernel: profiles/r06_stream_b9_probe.txt).  -DB9_PRODUCTS=9 restores it.
+#ifndef B9_PRODUCTS
+#define B9_PRODUCTS 8
+#endif
+        constexpr int NPR = B9_PRODUCTS;
+        static_assert(NPR == 8 || NPR == 9, "products");
+        constexpr int NMF = NPR * TN * TM, NDS = 3 * TN + 2 * TM, NPC = 14 * TM;   // MFMAs, LDS reads, vector pieces (8 splits + 6 packs per fragment)
         constexpr int BQ = NMF / 4;
         // nine exact partial products per (x tile, w tile), the small ones first; consecutive MFMAs go to different accumulators
         auto mfma_q = [&](int set, int q) {
             constexpr int PX[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0}, PW[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0};
-            const int r = q / (TN * TM), i = (q % (TN * TM)) / TM, j = q % TM;
+            const int r = q / (TN * TM) + (9 - NPR), i = (q % (TN * TM)) / TM, j = q % TM;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, xa[set][PX[r]][i]), __builtin_bit_cast(bf16x8g, wq[set][PW[r]][j]), acc[i][j], 0, 0, 0);
         };
         auto piece = [&](int ns, int p) {

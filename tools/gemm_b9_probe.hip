@@ -66,14 +66,20 @@ static int check(uint32_t N, uint32_t M, uint32_t K) {
     a.y[0] = dy2;
     time_glds<2, 2, 2, 2>(a, 1);
     CK(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y2.data(), dy2, y.size() * 4, hipMemcpyDeviceToHost));
-    double e9 = 0, e32 = 0, mx = 0;
+    double e9 = 0, e32 = 0, mx = 0, q9 = 0, q32 = 0; size_t cnt = 0;
     for (uint32_t n = 0; n < N; n += (N > 256 ? 7 : 1)) for (uint32_t m = 0; m < M; m += (M > 512 ? 5 : 1)) {
         double r = 0; for (uint32_t k = 0; k < K; ++k) r += (double)hx[(size_t)n * K + k] * hw[(size_t)m * K + k];
         double a9 = fabs(r - y[(size_t)n * M + m]), a32 = fabs(r - y2[(size_t)n * M + m]);
         if (!(a9 == a9)) a9 = 1e30;
-        e9 = fmax(e9, a9); e32 = fmax(e32, a32); mx = fmax(mx, fabs(r));
+        e9 = fmax(e9, a9); e32 = fmax(e32, a32); mx = fmax(mx, fabs(r)); q9 += a9 * a9; q32 += a32 * a32; ++cnt;
     }
-    printf("check N=%u M=%u K=%u vs the f64 product (max|y| %.3g): bf16 x 9 max err %.3e | fp32 MFMA max err %.3e  %s\n", N, M, K, mx, e9, e32, e9 <= 1.5 * e32 + 1e-7 * mx ? "ok" : "MISMATCH");
+#ifndef B9_PRODUCTS
+#define B9_PRODUCTS_SHOWN 8
+#else
+#define B9_PRODUCTS_SHOWN B9_PRODUCTS
+#endif
+    printf("check N=%u M=%u K=%u vs the f64 product (max|y| %.3g): bf16 x %d max err %.4e rms %.4e | fp32 MFMA max err %.4e rms %.4e  %s\n", N, M, K, mx, B9_PRODUCTS_SHOWN, e9, sqrt(q9 / cnt), e32, sqrt(q32 / cnt),
+           e9 <= 1.5 * e32 + 1e-7 * mx ? "ok" : "MISMATCH");
     hipFree(x); hipFree(w); hipFree(dy); hipFree(dy2); hipFree(xs);
     return e9 <= 1.5 * e32 + 1e-7 * mx ? 0 : 1;
 }

@@ -22,7 +22,7 @@ for step in "$@"; do
            find "$O/prof_$tag" -name "*_kernel_trace.csv" -size +20M -delete ;;
     pmc)   tag=${rest%%:*}; r2=${rest#*:}; ctrs=${r2%%:*}; cmd=${r2#*:}
            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $ctrs -d "$OLDPWD/$O/pmc_$tag" -o "$tag" -- bash -c "cd $OLDPWD && $cmd") > "$O/pmc_$tag.log" 2>&1; echo "pmc $tag rc=$?"
-           python tools/pmc_summary.py "$(find "$O/pmc_$tag" -name '*.db' | head -1)" > "$O/pmc_$tag.txt" 2>&1; head -30 "$O/pmc_$tag.txt"
+           python tools/pmc_summary.py "$(find "$O/pmc_$tag" -name '*.db' | head -1)" "$O/pmc_$tag.json" > "$O/pmc_$tag.txt" 2>&1; head -30 "$O/pmc_$tag.txt"
            find "$O/pmc_$tag" -name "*.csv" -size +20M -delete ;;
     sh)    tag=${rest%%:*}; cmd=${rest#*:}; timeout 900 bash -c "$cmd" > "$O/$tag.log" 2>&1; echo "$tag rc=$?"; tail -25 "$O/$tag.log" ;;
     *) echo "unknown step $step" ;;

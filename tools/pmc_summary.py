@@ -54,5 +54,8 @@ for k, v in sorted(st.items(), key=lambda kv: -sum(x[0] for x in kv[1])):
     print(f"{k:48s} {len(v):6d} {avg:19.1f} {hbm:17.1f} {alg if alg else float('nan'):15.1f} {hbm/alg if alg else float('nan'):11.3f}")
 
 if len(sys.argv) > 2:
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --no-cpu-baseline --no-prefill, x2 gfx950 correction per MI355X_MICROARCH.md "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from source_hash import kernel_source_hash
+    json.dump({"kernel_source_sha256": kernel_source_hash(), "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --no-cpu-baseline --no-prefill, x2 gfx950 correction per MI355X_MICROARCH.md "
                          "(a separate profiling run of the same kernels, not a measurement of this bench run)", "bytes_per_launch": traffic}, open(sys.argv[2], "w"), indent=1)
