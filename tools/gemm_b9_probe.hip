@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <math.h>
+#include <string.h>
 using namespace lh;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -14,12 +15,21 @@ static void split_rows(const float* x, uint16_t* xs, uint32_t N, uint32_t K) {
     Split3Args sa = {x, xs, (uint64_t)N * K, K, K, K};
     hipLaunchKernelGGL(k_split3_rows, dim3(N), dim3(256), 0, 0, sa);
 }
+#ifdef B9_PRESPLIT
+template <int WN, int WM, int TN, int TM, int NST = B9_GST, bool WPRE = false>
+static float time_b9(GemmArgs a, int reps) {
+    constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
+    size_t lds = NST * gemm_b9_stage_bytes(BN, BM, WPRE);
+    if (lds < 82 * 1024) lds = 82 * 1024;
+    auto kern = k_gemm_b9<WN, WM, TN, TM, NST, WPRE>;
+#else
 template <int WN, int WM, int TN, int TM, int NST = B9_GST>
 static float time_b9(GemmArgs a, int reps) {
     constexpr int BN = WN * TN * 32, BM = WM * TM * 32;
     size_t lds = NST * gemm_b9_stage_bytes(BN, BM);
     if (lds < 82 * 1024) lds = 82 * 1024;
     auto kern = k_gemm_b9<WN, WM, TN, TM, NST>;
+#endif
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t tiles = ((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM) * a.groups, grid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WN * WM * 64), lds, 0, a);
@@ -63,6 +73,21 @@ static int check(uint32_t N, uint32_t M, uint32_t K) {
     a.x = x; a.xs = xs; a.xs_plane = (uint64_t)N * K; a.ldxs = K; a.w[0] = w; a.y[0] = dy; a.groups = 1; a.N = N; a.M = M; a.K = K; a.ldx = K; a.ldy = M;
     const int cfg = getenv("B9_8WAVES") ? atoi(getenv("B9_8WAVES")) : 0;
     if (cfg == 3) time_b9<1, 8, 4, 1, 2>(a, 1); else if (cfg) time_b9<2, 4, 2, 1>(a, 1); else time_b9<2, 2, 2, 2>(a, 1);
+#ifdef B9_PRESPLIT   // needs tools/gemm_b9_presplit.patch applied to csrc/ (round 6: measured, not adopted - profiles/r06_gemm_b9_presplit.txt)
+    {   // the pre-split-weights build must give the SAME bits (same products, same order)
+        uint16_t* wps; float* dy3; CK(hipMalloc(&wps, hw.size() * 6)); CK(hipMalloc(&dy3, y.size() * 4)); CK(hipMemset(dy3, 0xff, y.size() * 4));
+        split_rows(w, wps, M, K);
+        GemmArgs b = a; b.wp[0] = wps; b.wp_plane = (uint64_t)M * K; b.y[0] = dy3;
+        time_b9<1, 8, 4, 1, 2, true>(b, 1);
+        a.y[0] = dy; time_b9<1, 8, 4, 1, 2>(a, 1);
+        std::vector<float> y3(y.size()), y1(y.size());
+        CK(hipMemcpy(y3.data(), dy3, y.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y1.data(), dy, y.size() * 4, hipMemcpyDeviceToHost));
+        size_t diff = 0; for (size_t i = 0; i < y.size(); ++i) diff += memcmp(&y3[i], &y1[i], 4) != 0;
+        printf("   pre-split weights vs split on the fly (128 x 256 tiles): %zu of %zu results differ in their bits\n", diff, y.size());
+        hipFree(wps); hipFree(dy3);
+        if (cfg != 3) time_b9<2, 2, 2, 2>(a, 1);
+    }
+#endif
     a.y[0] = dy2;
     time_glds<2, 2, 2, 2>(a, 1);
     CK(hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(y2.data(), dy2, y.size() * 4, hipMemcpyDeviceToHost));
@@ -113,6 +138,22 @@ int main() {
         unsigned long long hc[2]; CK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
         printf("    shader clock while k_gemm_b9 runs: %.3f GHz (%llu clocks in %.1f us)\n", (double)hc[0] / ((double)hc[1] * 10.0), hc[0], (double)hc[1] / 100.0);
         a.clk = nullptr; hipFree(clk);
+#endif
+#ifdef B9_PRESPLIT
+        {   // the same launch on pre-split weights
+            uint16_t* wps; CK(hipMalloc(&wps, (size_t)sh.groups * sh.M * sh.K * 6));
+            split_rows(w, wps, sh.groups * sh.M, sh.K);
+            GemmArgs b = a; b.wp_plane = (uint64_t)sh.groups * sh.M * sh.K;
+            for (uint32_t g = 0; g < sh.groups; ++g) b.wp[g] = wps + (size_t)g * sh.M * sh.K;
+            const float tp = time_b9<1, 8, 4, 1, 2, true>(b, 5);
+#ifdef B9_TRACE
+            unsigned long long hc2[2]; CK(hipMalloc(&b.clk, 16)); CK(hipMemset(b.clk, 0, 16)); time_b9<1, 8, 4, 1, 2, true>(b, 1); CK(hipMemcpy(hc2, b.clk, 16, hipMemcpyDeviceToHost)); hipFree(b.clk);
+            printf("    pre-split weights: %8.1f us = %6.1f TFLOP/s, shader clock %.3f GHz\n", tp * 1e3, fl / tp / 1e9, (double)hc2[0] / ((double)hc2[1] * 10.0));
+#else
+            printf("    pre-split weights: %8.1f us = %6.1f TFLOP/s\n", tp * 1e3, fl / tp / 1e9);
+#endif
+            hipFree(wps);
+        }
 #endif
         const float t32 = time_glds<2, 2, 2, 2>(a, 5), t160 = time_glds<4, 1, 1, 5>(a, 5);
         printf("          fp32 MFMA, 128 x 160 tiles: %8.1f us\n", t160 * 1e3);
