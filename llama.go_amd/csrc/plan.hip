@@ -392,7 +392,7 @@ static uint16_t* ensure_xs3(lh_ctx* ctx, uint64_t elems) {
     if (elems > ctx->xs3_elems) {
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
         if (ctx->xs3) hipFree(ctx->xs3);
-        ctx->xs3 = nullptr; ctx->xs3_elems = 0;
+        ctx->xs3 = nullptr; ctx->xs3_elems = 0; ctx->splitk_gen++;   // (captured graphs that hold the old planes' address are stale: same generation counter as the split-K buffer)
         if (hipMalloc((void**)&ctx->xs3, elems * 2) != hipSuccess) return nullptr;
         ctx->xs3_elems = elems;
     }
@@ -429,7 +429,7 @@ static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t 
     static bool flags[16] = {};
     int rc = set_lds_once(ctx, kern, lds, flags);
     if (rc) return rc;
-    if (g_prepare_only) return 0;
+    // (allocations BEFORE the prepare-only return, as the stream kernels do: a capture pass must find xs3 and the split-K buffer sized - ADVICE r5)
     uint16_t* xs = ensure_xs3(ctx, (uint64_t)3 * a.N * a.K);
     if (!xs) LH_FAIL(ctx, LH_ENOMEM, "%s: planes of %u x %u activations", name, a.N, a.K);
     a.xs = xs; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
@@ -445,6 +445,7 @@ static int launch_gemm_q8b3(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t 
         }
         a.part = ctx->splitk;
     }
+    if (g_prepare_only) return 0;
     {
         TraceScope ts_(ctx->stream, "split3_rows");
         Split3Args sa = {a.x, xs, a.xs_plane, a.K, a.ldx, a.K};
@@ -630,7 +631,9 @@ static int attention_flash(Plan* p, const float* q, const float* kc, const float
 // 65..96 rows (round 3): five / six column tiles on the same half-length chunks (2 x (6 + 6) x 16 x 68 floats = 104 KB; 6 x 6 accumulator tiles =
 // 144 registers of the MFMA waves).  The tile GEMM's single row of 128-row tiles cost 17.6 ms at 65 rows against 10.2 ms at 64.
 static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 64, BATCH_ROWS_MAX = 64;
-static constexpr uint32_t B9S_MIN_ROWS = 49, B9S_MAX_ROWS = 64;   // fp32 on k_stream_b9 (see b9s_shape_ok)
+static constexpr uint32_t B9S_MIN_ROWS = 49, B9S_MAX_ROWS = 64;   // fp32 on k_stream_b9 (see b9s_shape_ok).  Re-checked with the final kernel, same box (profiles/
+// r06_stream_b9_model_ab.txt): 17 / 32 pods 6.36 / 6.55 ms per tick on it against 5.89 / 6.11, 33 / 40 / 48 a tie (6.82 / 6.94 / 7.15 vs 6.92 / 6.97 / 7.11),
+// prompts of 65..128 tokens as two passes 14.0-15.8 ms against 9.7-14.4 in one pass of k_stream_dma: the range stays 49..64
 static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
@@ -977,7 +980,6 @@ static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t sp
     static bool flags[16] = {};
     int rc = set_lds_once(ctx, kern, lds, flags);
     if (rc) return rc;
-    if (g_prepare_only) return 0;
     if (!ensure_xs3(ctx, (uint64_t)3 * a.N * a.K)) LH_FAIL(ctx, LH_ENOMEM, "%s: planes of %u x %u activations", name, a.N, a.K);
     a.xs = ctx->xs3; a.xs_plane = (uint64_t)a.N * a.K; a.ldxs = a.K;
     a.splits = splits > 1 ? splits : 0; a.part = nullptr;
@@ -992,6 +994,7 @@ static int launch_gemm_b9(lh_ctx* ctx, GemmArgs a, const char* name, uint32_t sp
         }
         a.part = ctx->splitk;
     }
+    if (g_prepare_only) return 0;
     {
         TraceScope ts_(ctx->stream, "split3_rows");
         Split3Args sa = {a.x, ctx->xs3, a.xs_plane, a.K, a.ldx, a.K};

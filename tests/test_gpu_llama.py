@@ -669,20 +669,21 @@ def test_long_context_split_attention_matches_oracle(product, oracle):
 @pytest.mark.parametrize("shape,layers", [("13B", 2), ("65B", 1)])
 def test_config3_prefill_1024_tokens_matches_oracle(product, oracle, shape, layers):
     """BASELINE.json configs[2] at its stated size: 13B shape, 2-layer slice, ONE Eval of N = 1024 tokens at
-    past = 0, context 1024 — the run `bench.py`'s prefill_13b object times — plus a 65B-shape 1-layer slice.  Checker: the
+    past = 0 (context 1025: room for the decode step behind it) — the run `bench.py`'s prefill_13b object times — plus a 65B-shape 1-layer slice.  Checker: the
     restatement with the reference's own AVX dot product over 16 host threads (the 1.1 TMAC scalar order would take minutes; both
     orders sit within 1e-5 of the float64 leg, tests/test_oracle.py).  Then one decode step on the cache the prefill wrote."""
     from llama_go_amd.mlapi import usable_threads
     kw = dict(SHAPES[shape])
     kw["layers"] = layers
-    hp = make_hparams(**kw, ctx=1024)
-    toks = [int(t) for t in np.random.default_rng(0).integers(0, kw["vocab"], 1023)]
+    # N = 1024 exactly (the run the bench times: full 128-row tiles of k_gemm_b9 on the 13B shape) in a window of 1025, so that one decode step fits behind it
+    hp = make_hparams(**kw, ctx=1025)
+    toks = [int(t) for t in np.random.default_rng(0).integers(0, kw["vocab"], 1024)]
     res = {}
     for name, lib in (("hip", product), ("orc", oracle)):
         m = lib.NewSyntheticModel(hp, 1234)
-        c = m.NewContext(1024, usable_threads(), True)
+        c = m.NewContext(1025, usable_threads(), True)
         a = c.Eval(toks, 0)
-        b = c.Eval([int(np.argmax(a))], 1023)
+        b = c.Eval([int(np.argmax(a))], 1024)
         res[name] = (a, b)
         if name == "hip":
             product.lib.llamago_LastGraphFused.restype = C.c_int
