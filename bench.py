@@ -488,6 +488,15 @@ def main():
                 result["int8_decode"] = {"tokens_per_s": round(K / dq, 2), "ms_per_token": round(dq / K * 1e3, 4), "bytes_per_token": int(qbytes),
                                          "frac_of_hbm_roofline": round(K / dq * qbytes / (HBM_PEAK_GBPS * 1e9), 4), "tokens": tq[: min(K, 16)],
                                          "note": "BASELINE config 4: block-int8 weight matrices (36 B per 32 weights, format ours), same resident loop"}
+                # what a chain of dependent launches can reach: every launch costs t = 3.2 us + bytes / 7.0 TB/s (fit over the five fp32 decode launches of a
+                # layer; the five per layer are one all-to-all dependency chain), and the int8 streams are 3.55x shorter than the fp32 ones
+                n_launch = 5 * L + 2
+                chain_s = n_launch * 3.2e-6 + qbytes / 7.0e12
+                result["int8_decode"]["launch_chain_ceiling_frac"] = round(qbytes / chain_s / (HBM_PEAK_GBPS * 1e9), 4)
+                result["int8_decode"]["launch_chain_ceiling"] = {"tokens_per_s": round(1.0 / chain_s, 1), "launches_per_token": n_launch,
+                                                                 "fit": "t(launch) = 3.2 us + bytes / 7.0 TB/s, five dependent launches per layer + lm_head + argmax (DESIGN 3a)",
+                                                                 "note": "structural: flat since round 3 (558 -> 550 -> 541 tok/s); resident kernels, cross-kernel prefetch, two-stream overlap, "
+                                                                         "launch-free attention and the Infinity-Cache prefetch were all measured and all lost (DESIGN 3a)"}
                 # dominant int8 kernel, HIP-event timed like the fp32 one (bytes = 36 B per 32 weights of the launch)
                 pq = profile_decode(cq, fq, P0, repeats=2)
                 b2q = {k["name"][:-4]: k for k in pq if k["name"].endswith("/b2b")}

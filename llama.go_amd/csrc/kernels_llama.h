@@ -567,25 +567,29 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
     if (tid == 0) { dst[hd] = m; dst[hd + 1] = psum; }
 }
 
+// (round 6: the chunk weights w_s = exp(m_s - M) are computed ONCE, by thread s, into LDS - every one of the 128 threads evaluated all of them in
+// f64 before, twice: 8.8 us of a 12.6 + 8.8 us attention at T = 1000, profiles/r06_longctx.txt.  Same values, same order of the sums.)
+constexpr int ATT_COMBINE_MAX = 256;   // chunks a combine can weigh in LDS (ctx up to 32768)
 __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, const float* __restrict__ part, uint32_t nch) {
+    __shared__ float wsh[ATT_COMBINE_MAX];
     const uint32_t h = blockIdx.x, hd = a.hd, j = blockIdx.y;
     const uint32_t past = a.rows ? a.rows[j].pos : (a.sp ? a.sp->past : a.past_host);
     const uint32_t T = past + 1, n = (T + ATT_TC - 1) / ATT_TC;  // active chunks
     const float* base = part + ((size_t)j * gridDim.x + h) * nch * (hd + 2);
     float M = -INFINITY;
     for (uint32_t s = 0; s < n; ++s) M = fmaxf(M, base[(size_t)s * (hd + 2) + hd]);
-    float l = 0.f;
-    for (uint32_t s = 0; s < n; ++s) {
-        const float w = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
-        l = fmaf(base[(size_t)s * (hd + 2) + hd + 1], w, l);
+    const bool lds_w = n <= (uint32_t)ATT_COMBINE_MAX;
+    if (lds_w) {
+        for (uint32_t s = threadIdx.x; s < n; s += 128) wsh[s] = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
+        __syncthreads();
     }
+    auto w_of = [&](uint32_t s) { return lds_w ? wsh[s] : (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M)); };
+    float l = 0.f;
+    for (uint32_t s = 0; s < n; ++s) l = fmaf(base[(size_t)s * (hd + 2) + hd + 1], w_of(s), l);
     const float inv = __fdiv_rn(1.0f, l);
     for (uint32_t c = threadIdx.x; c < hd; c += 128) {
         float o = 0.f;
-        for (uint32_t s = 0; s < n; ++s) {
-            const float w = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
-            o = fmaf(base[(size_t)s * (hd + 2) + c], w, o);
-        }
+        for (uint32_t s = 0; s < n; ++s) o = fmaf(base[(size_t)s * (hd + 2) + c], w_of(s), o);
         const float ov = __fmul_rn(o, inv);
         a.out[(size_t)j * a.d + h * hd + c] = ov;
         if (a.out_s3) attn_store_split3(a, (size_t)j * a.d + h * hd + c, ov);

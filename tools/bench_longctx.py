@@ -23,7 +23,7 @@ for P in args.past:
     decode_greedy_resident(c, first, P, 2)
     t0 = time.perf_counter(); decode_greedy_resident(c, first, P, 16); dt = (time.perf_counter() - t0) / 16
     prof = {k["name"]: round(k["avg_us"], 2) for k in profile_decode(c, first, P, 2)}
-    out.append({"past": P, "ms_per_token": round(dt * 1e3, 4), "tok_s": round(1 / dt, 1), "attention_us": prof.get("attention")})
+    out.append({"past": P, "ms_per_token": round(dt * 1e3, 4), "tok_s": round(1 / dt, 1), "attention_us": prof.get("attention"), "attention_split_us": prof.get("attention_split"), "attention_combine_us": prof.get("attention_combine")})
     c.free()
 print(json.dumps(out))
 if args.pods > 1:
