@@ -1046,12 +1046,13 @@ int gemm_mfma_group(lh_ctx* ctx, const float* x, uint32_t ldx, uint32_t groups, 
         const uint64_t tiles9 = (uint64_t)tn * ((a.M + 255) / 256) * a.groups;
         const uint32_t nkf = a.K / GBK;
         const double unit = may_split ? 2.0 * 128 * GBK / (157.3e6 / 256.0) : 1.0;      // cost() is in microseconds when split-K is on the table
-        double c9 = (double)((tiles9 + ncu - 1) / ncu) * (nkf + 8) * 256 * 0.62 * unit;
+        constexpr double B9_SLAB = 0.56;   // a 128 x 256 slab of k_gemm_b9 in units of k_gemm_glds' 128 x 128 slab per tile row (0.62 with nine products, r05; eight: x 8 / 9 measured -9.5 %)
+        double c9 = (double)((tiles9 + ncu - 1) / ncu) * (nkf + 8) * 256 * B9_SLAB * unit;
         uint32_t s9 = 1;
         if (may_split)      // (cost in microseconds: the reduce pass as in pick_splitk)
             for (uint32_t s2 = 2; s2 <= 8; ++s2) {
                 if (nkf / s2 < 16) break;
-                const double c = (double)((tiles9 * s2 + ncu - 1) / ncu) * ((nkf + s2 - 1) / s2 + 8) * 256 * 0.62 * unit + (double)(s2 + 1) * a.groups * n * a.M * 4.0 / 4e6 + 5.0;
+                const double c = (double)((tiles9 * s2 + ncu - 1) / ncu) * ((nkf + s2 - 1) / s2 + 8) * 256 * B9_SLAB * unit + (double)(s2 + 1) * a.groups * n * a.M * 4.0 / 4e6 + 5.0;
                 if (c < c9 * 0.95) { c9 = c; s9 = s2; }
             }
         if (c9 < 0.97 * std::min(c128, std::min(c160, c64))) return launch_gemm_b9(ctx, a, name, s9);
