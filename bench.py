@@ -429,6 +429,10 @@ def main():
                 fl13 = 2.0 * 1024 * L13 * (4 * d13 * d13 + 3 * d13 * F13) + 2.0 * hp13.vocabSize * d13
                 result["prefill_13b"] = {"seconds": round(min(ts13), 4), "n_tokens": 1024, "tflop_weight_matmuls_executed": round(fl13 / 1e12, 2),
                                          "TFLOPs_per_s": round(fl13 / min(ts13) / 1e12, 1), "frac_of_fp32_mfma_peak_157.3": round(fl13 / min(ts13) / 157.3e12, 3),
+                                         "frac_of_exact_split_bf16_roof_312.5": round(fl13 * 8 / min(ts13) / 2.5e15, 3),
+                                         "roofs": "the weight GEMMs run on the bf16 matrix pipe as EIGHT exact products per fp32 product (k_gemm_b9: xl * wl dropped, error vs f64 unchanged - "
+                                                  "profiles/r06_gemm_b9_products.txt): 157.3 TF = the fp32-input MFMA peak it replaces, 312.5 TF = 2.5 PF bf16 / 8 = the roof of the exact split "
+                                                  "itself; the kernel is POWER-bound (1.4-1.7 GHz with every CU on the bf16 pipe), not issue-bound",
                                          "note": "llama.Eval of 1024 tokens incl. host graph build and last-row logits D2H; lm_head for the one row Eval reads"}
                 c13.free()
                 if not args.int8:   # the same Eval on the same model with block-int8 weight matrices (config 4's format at config 3's size; k_gemm_q8b3)
