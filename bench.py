@@ -219,9 +219,9 @@ def main():
         result["eval_per_token_loop"] = {"tokens_per_s": round(K / dt_wall, 2), "ms_per_token": round(dt_wall / K * 1e3, 4),
                                          "inside_lh_graph_compute_wall": {"tokens_per_s": round(K / max(st_timed["wall_us"], 1e-9) * 1e6, 2), "ms_per_call": round(st_timed["wall_us"] / K / 1e3, 4),
                                                                           "note": "host clock from entry to return of the contract call (validate, match, enqueue, wait, pinned logits row)"},
-                                         "note": "the SAME K timed steps by the wall clock between the barrier + synchronize pairs: llama.Eval per token incl. the caller's graph build (53 us), flatten, "
-                                                 "the library's match, the wait, the logits row and the host argmax - what a Go caller of the shim gets per token; `value` is the HIP-event time of the "
-                                                 "lh_graph_compute calls inside it"}
+                                         "note": "the SAME K timed steps by the wall clock between the barrier + synchronize pairs: llama.Eval per token - the host mirror moves the graph it keeps for one-token Evals to the new position (1 us; "
+                                                 "building it anew as the reference's llama.Eval does cost 53 + 13 us, rounds 1-5) - the library's match (12 us), the wait, the logits row and the host argmax; "
+                                                 "`value` is the HIP-event time of the lh_graph_compute calls inside it (it starts at the call's entry: validate and match are in it)"}
         # ---- rounds 1-5's `value`: the device-resident loop (argmax on the GPU feeds the next step, hipGraph replay of eight steps, no host round trip)
         cr = model.NewContext(ctx_size, 1)
         cr.Eval(PROMPT, 0)

@@ -49,6 +49,15 @@ int llamago_ComputeStats(llama_context* c, uint64_t* calls, double* wall_us, dou
 int llamago_LastGraphFused(ml_context* ctx);         /* 1 if the last ml_GraphCompute ran as the fused LLaMA plan */
 int llamago_GraphComputeNoFusion(ml_context* ctx, ml_graph* g);   /* ml_GraphCompute node by node with the generic kernels (op-level parity) */
 
+/* ---- [product] harness helper of the kept decode graph (no GPU needed) -------------------------------------------------- */
+/* The array llama_Eval hands to lh_graph_compute for N tokens (ids 1..N) at pastQuery, as numbers: per tensor 16 int64 = op, dtype, flags, ne[4],
+ * nb[4], src0, src1, storage, view_off, a fold of an owner leaf's host values (0 without).  pastBuild < 0: from a fresh build at pastQuery;
+ * pastBuild >= 0: from the graph llama_Eval KEEPS between one-token calls, learnt around pastBuild and moved to pastQuery (host/llamago.cpp,
+ * eval_cache) - tests require both to be identical.  Returns the tensor count, -1 bad arguments, -2 the kept graph declined. */
+int llamago_DescribeEvalArray(const llama_hparams* hp, uint32_t ctxSize, uint32_t N, int64_t pastBuild, uint32_t pastQuery, int64_t* out, uint32_t cap_tensors, uint32_t* n_leafs);
+/* 0: every llama_Eval builds its graph anew (what LLAMAGO_NO_EVAL_CACHE=1 sets at load); 1 (default): one-token Evals move the kept graph. */
+void llamago_KeepDecodeGraph(int on);
+
 /* ---- [product] device-resident loops on a llama.Context --------------------------------------------------------------- */
 /* n_steps greedy decode steps without host round trips (lh_llama_decode_greedy). */
 int llamago_DecodeGreedyResident(llama_context* c, uint32_t first_token, uint32_t past, uint32_t n_steps, uint32_t* out_tokens, float* logits_last);

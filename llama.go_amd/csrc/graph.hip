@@ -47,6 +47,7 @@ struct Matcher {
     // Every node the pattern walks over is marked; the match only holds if ALL nodes of the graph were claimed (extra outputs or
     // side-effect copies expanded into the same graph would otherwise be silently skipped by the fused plan).
     mutable std::vector<uint8_t> claimed;
+    std::vector<uint32_t> cpy_nodes;
     bool is(int i, int op) const {
         if (i < 0 || (uint32_t)i >= total || T[i].op != op) return false;
         claimed[i] = 1;
@@ -186,8 +187,8 @@ struct Matcher {
         if (koff != (uint64_t)il * md.ctx * d || voff != koff) return false;
         // K / V stores: Cpy(MulMat(wk|wv, h1), View1D(cache, d*(il*ctx + past)))         llama.go:274-278
         bool gotk = false, gotv = false;
-        for (uint32_t i = n_leafs; i < total; ++i) {
-            if (T[i].op != OP_CPY) continue;
+        for (const uint32_t i : cpy_nodes) {   // (every Cpy node of the graph, in graph order: collected once - scanning all nodes here for every layer was
+                                               // most of the 25 us a one-token match took)
             const int src = T[i].src0;
             if (!is(src, OP_MUL_MAT) || s1(src) != h1 || src == mmq) continue;
             const int dstv = T[i].src1;
@@ -275,6 +276,9 @@ struct Matcher {
             if (b->nfloats % per) return false;
             md.ctx = (uint32_t)(b->nfloats / per);
         }
+        cpy_nodes.clear();
+        for (uint32_t i = n_leafs; i < total; ++i)
+            if (T[i].op == OP_CPY) cpy_nodes.push_back(i);
         int xin = -1;
         for (uint32_t k = 0; k < md.L; ++k) {
             const uint32_t il = md.L - 1 - k;

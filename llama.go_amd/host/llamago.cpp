@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -290,12 +291,10 @@ int ml_BuildForwardExpand(ml_graph* g, ml_tensor* t) {  // ml.go:620-644
 uint32_t ml_GraphNodesCount(const ml_graph* g) { return (uint32_t)g->nodes.size(); }
 ml_tensor* ml_GraphNode(const ml_graph* g, uint32_t i) { return i < g->nodes.size() ? g->nodes[i] : nullptr; }
 
-// ml.GraphCompute ml.go:1411-1528 -> ONE call across the C-ABI.
-static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
-    g_err.clear();
-    if (!ctx || !ctx->hip) return halt_rc("ml_GraphCompute: no HIP context");
-    // every storage owner must be part of the array the C side sees; indices live in the tensors (flat_gen / flat_idx)
-    const auto tf0 = std::chrono::steady_clock::now();
+// The array the C side sees: leafs, the storage owners that are not in the graph themselves, then the nodes in the order ml.GraphCompute
+// walks them (ml.go:1501-1526).  Lands in ctx->flat (scratch kept between calls); *nl / *nn = leaf and node counts.
+static void flatten_graph(ml_context* ctx, ml_graph* g, uint32_t* nl_out, uint32_t* nn_out) {
+    // every storage owner must be part of the array; indices live in the tensors (flat_gen / flat_idx)
     std::vector<ml_tensor*>& leafs = ctx->flat_leafs;
     leafs.assign(g->leafs.begin(), g->leafs.end());
     const uint64_t fg = next_mark();
@@ -343,9 +342,18 @@ static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
             t->last_index = i;
         }
     }
+    *nl_out = nl; *nn_out = nn;
+}
+// ml.GraphCompute ml.go:1411-1528 -> ONE call across the C-ABI.
+static int graph_compute(ml_context* ctx, ml_graph* g, uint32_t flags) {
+    g_err.clear();
+    if (!ctx || !ctx->hip) return halt_rc("ml_GraphCompute: no HIP context");
+    const auto tf0 = std::chrono::steady_clock::now();
+    uint32_t nl = 0, nn = 0;
+    flatten_graph(ctx, g, &nl, &nn);
     static const bool timing = getenv("LLAMAGO_TIMING") != nullptr;
     if (timing) fprintf(stderr, "[llamago] flatten %u tensors: %.1f us\n", nl + nn, (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count() / 1000.0);
-    if (lh_graph_compute(ctx->hip, T.data(), nl, nn, flags)) return halt_rc(lh_last_error(ctx->hip));
+    if (lh_graph_compute(ctx->hip, ctx->flat.data(), nl, nn, flags)) return halt_rc(lh_last_error(ctx->hip));
     return 0;
 }
 int ml_GraphCompute(ml_context* ctx, ml_graph* g) {
@@ -400,8 +408,10 @@ struct llama_context {  // llama.go:83-88
     std::vector<float> embedding;  // lctx.Embedding (llama.go:88; allocated when ModelParams.Embedding is set, llama.go:414-419)
     lh_llama* resident = nullptr;  // plan handle for the device-resident loop / stages (created on demand)
     bool holds_model = false;
+    struct eval_cache* decode_graph = nullptr;   // the graph of a one-token Eval, kept between calls (see eval_cache)
 };
 
+static void eval_cache_free(struct eval_cache* c);
 static uint32_t ff_size(uint32_t embd, uint32_t mult) { return ((2 * (4 * embd) / 3 + mult - 1) / mult) * mult; }  // llama.go:761
 
 // persistent device tensor without a host copy
@@ -674,6 +684,7 @@ void llama_ReleaseContext(llama_context* c) {  // llama.go:105-113
     if (!c) return;
     if (c->resident) lh_llama_destroy(c->resident);
     if (c->mlctx) lh_ctx_sync(c->mlctx->hip);
+    eval_cache_free(c->decode_graph);
     free_tensor(c->K); free_tensor(c->V);   // per-pod KV caches go with their context (device memory returns to the pool)
     ml_ReleaseContext(c->mlctx);
     if (c->holds_model) model_release(c->model);
@@ -686,10 +697,11 @@ ml_context* llama_MLContext(llama_context* c) { return c->mlctx; }
 // The graph of llama.Eval (llama.go:232-387) over `model`, the KV tensors kK / kV and N token ids at position pastCount: expanded into
 // `graph`, returns the logits node (NULL on a "[HALT]" condition).  One builder serves llama_Eval and llamago_DescribeEvalGraph.
 static ml_tensor* build_eval_graph(ml_context* ctx0, llama_model* model, ml_tensor* kK, ml_tensor* kV, uint32_t ctxSize, const uint32_t* tokens, uint32_t N,
-                                   uint32_t pastCount, ml_graph* graph) {
+                                   uint32_t pastCount, ml_graph* graph, ml_tensor** embd_out = nullptr) {
     const uint32_t embdSize = model->hp.embdSize, layersCount = model->hp.layersCount;
     const uint32_t headsCount = model->hp.headsCount, rotCount = embdSize / headsCount;
     ml_tensor* embd = new_tensor(ML_TYPE_F32, 1, N, 1, 1, 1, nullptr, 0);  // :239-242 token ids as fp32
+    if (embd_out) *embd_out = embd;
     for (uint32_t i = 0; i < N; i++) embd->data[i] = (float)tokens[i];
     ml_tensor* inpL = ml_GetRows(ctx0, model->tokEmbeddings, embd);         // :244
     for (uint32_t il = 0; il < layersCount; il++) {
@@ -744,6 +756,113 @@ static ml_tensor* build_eval_graph(ml_context* ctx0, llama_model* model, ml_tens
     if (ml_BuildForwardExpand(graph, inpL)) return nullptr;                   // :387
     return inpL;
 }
+// ---- the graph of a one-token Eval, kept between calls -------------------------------------------------------------------------------
+// llama.Eval builds its graph anew for every token (llama.go:232-387): ~1700 tensors, 53 us here, + 13 us to flatten them for the C side, + the
+// release - a fortieth of what the GPU then needs for the token.  For a fixed token count the graph of Eval(N, past) has ONE structure, and
+// every number in its flattened form (extents, strides, view offsets, the Rope / DiagMaskInf parameter values) is an affine function of `past`.
+// So the first one-token Eval of a context builds the graph at three consecutive positions, takes the per-field differences of the flattened
+// arrays, CHECKS on the third that they really are affine (a graph whose shape logic ever stops being so simply is not cached), keeps the first
+// graph and array, and later calls write  value(past) = value(p0) + (past - p0) * difference  into the few hundred fields that move.  Nothing
+// about the shapes is restated here: the builder above stays the only place that knows them.  tests/test_graph_twin.py compares the patched array
+// with a fresh build field by field over many positions (llamago_DescribeEvalArray, no GPU needed).  LLAMAGO_NO_EVAL_CACHE=1 turns it off.
+static std::atomic<int> g_keep_decode_graph{getenv("LLAMAGO_NO_EVAL_CACHE") ? 0 : 1};
+struct eval_cache {
+    llama_model* model = nullptr;
+    uint32_t N = 0, p0 = 0, nl = 0, nn = 0;
+    bool with_emb = false, failed = false;
+    std::vector<ml_tensor*> owned;      // every tensor the kept build constructed (taken off the thread's garbage list)
+    ml_graph* graph = nullptr;
+    ml_tensor* embd = nullptr;          // the token-id leaf
+    std::vector<lh_tensor> flat;        // the array at p0, patched in place
+    struct Patch { uint32_t t, f; int64_t base, d; };   // f: 0-3 ne, 4-7 nb, 8 view_off
+    std::vector<Patch> patches;
+    struct HostPatch { float* p; float base, d; };      // parameter leafs whose VALUE moves with past (Rope, DiagMaskInf)
+    std::vector<HostPatch> hpatches;
+    uint32_t logits_index = 0;
+    int emb_index = -1;
+};
+static void eval_cache_free(eval_cache* c) {
+    if (!c) return;
+    if (c->graph) delete c->graph;      // its tensors are in `owned`
+    for (ml_tensor* t : c->owned) free_tensor(t);
+    delete c;
+}
+static int64_t flat_field(const lh_tensor& t, uint32_t f) { return f < 4 ? (int64_t)t.ne[f] : f < 8 ? (int64_t)t.nb[f - 4] : (int64_t)t.view_off; }
+static eval_cache* eval_cache_build(ml_context* ctx0, llama_model* model, ml_tensor* kK, ml_tensor* kV, uint32_t ctxSize, uint32_t N, uint32_t pastHint, bool with_emb) {
+    eval_cache* c = new eval_cache();
+    c->model = model; c->N = N; c->with_emb = with_emb; c->failed = true;
+    if ((uint64_t)N + 2 > ctxSize) return c;
+    c->p0 = std::min<uint32_t>(pastHint, ctxSize - N - 2);
+    std::vector<lh_tensor> F[3];
+    std::vector<std::vector<float>> H[3];           // host data of the owner leafs, in array order
+    const std::vector<uint32_t> tokens(N, 0u);
+    const bool save = g_gc_enabled;
+    g_gc_enabled = true;
+    bool ok = true;
+    for (int b = 0; b < 3 && ok; b++) {
+        ml_tensor* const mark = g_gc_head;
+        ml_graph* g = ml_NewGraph();
+        ml_tensor *embd = nullptr, *inpL = build_eval_graph(ctx0, model, kK, kV, ctxSize, tokens.data(), N, c->p0 + (uint32_t)b, g, &embd);
+        ok = inpL != nullptr;
+        uint32_t nl = 0, nn = 0;
+        if (ok) {
+            if (with_emb && inpL->src1) inpL->src1->want_output = true;
+            flatten_graph(ctx0, g, &nl, &nn);
+            F[b] = ctx0->flat;
+            for (uint32_t i = 0; i < nl + nn; i++) {
+                const lh_tensor& t = F[b][i];
+                std::vector<float> h;
+                if (t.host) h.assign(t.host, t.host + (uint64_t)t.ne[0] * t.ne[1] * t.ne[2] * t.ne[3]);
+                H[b].push_back(std::move(h));
+            }
+        }
+        if (b == 0 && ok) {
+            c->graph = g; c->embd = embd; c->nl = nl; c->nn = nn;
+            c->logits_index = inpL->last_index;
+            c->emb_index = (with_emb && inpL->src1) ? (int)inpL->src1->last_index : -1;
+            while (g_gc_head && g_gc_head != mark) { ml_tensor* t = g_gc_head; gc_unlink(t); c->owned.push_back(t); }
+        } else {
+            ml_FreeGraph(g);
+            gc_free_down_to(mark);
+        }
+    }
+    g_gc_enabled = save;
+    if (!ok || F[1].size() != F[0].size() || F[2].size() != F[0].size()) return c;
+    for (uint32_t i = 0; i < F[0].size(); i++) {
+        const lh_tensor &a = F[0][i], &b1 = F[1][i], &b2 = F[2][i];
+        for (const lh_tensor* o : {&b1, &b2})
+            if (o->op != a.op || o->dtype != a.dtype || o->flags != a.flags || o->src0 != a.src0 || o->src1 != a.src1 || o->storage != a.storage || o->buf != a.buf ||
+                (o->host == nullptr) != (a.host == nullptr)) return c;
+        for (uint32_t f = 0; f < 9; f++) {
+            const int64_t v0 = flat_field(a, f), d = flat_field(b1, f) - v0;
+            if (flat_field(b2, f) - v0 != 2 * d) return c;
+            if (d) c->patches.push_back({i, f, v0, d});
+        }
+        if (a.host && a.host != c->embd->data) {
+            const std::vector<float>&h0 = H[0][i], &h1 = H[1][i], &h2 = H[2][i];
+            if (h1.size() != h0.size() || h2.size() != h0.size()) return c;
+            for (size_t k = 0; k < h0.size(); k++) {
+                const float d = h1[k] - h0[k];
+                if (h2[k] != h0[k] + 2.f * d) return c;
+                if (d != 0.f) c->hpatches.push_back({const_cast<float*>(a.host) + k, h0[k], d});
+            }
+        }
+    }
+    c->flat = std::move(F[0]);
+    c->failed = false;
+    return c;
+}
+// the cached graph at position `past` with these tokens: c->flat is then what flatten_graph would have produced for a fresh build
+static void eval_cache_patch(eval_cache* c, const uint32_t* tokens, uint32_t past) {
+    for (uint32_t i = 0; i < c->N; i++) c->embd->data[i] = (float)tokens[i];
+    const int64_t k = (int64_t)past - (int64_t)c->p0;
+    for (const eval_cache::Patch& p : c->patches) {
+        lh_tensor& t = c->flat[p.t];
+        const int64_t v = p.base + p.d * k;
+        if (p.f < 4) t.ne[p.f] = (uint32_t)v; else if (p.f < 8) t.nb[p.f - 4] = (uint64_t)v; else t.view_off = (uint64_t)v;
+    }
+    for (const eval_cache::HostPatch& h : c->hpatches) *h.p = h.base + h.d * (float)k;
+}
 extern "C" {
 
 int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, uint32_t N, uint32_t pastCount) {  // llama.go:211-426
@@ -754,6 +873,28 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
     static const bool timing = getenv("LLAMAGO_TIMING") != nullptr;  // stderr: host-side phases of one Eval in microseconds
     const auto tp0 = std::chrono::steady_clock::now();
     auto us_since = [](std::chrono::steady_clock::time_point a) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count(); };
+    static const bool no_fusion = getenv("LLAMAGO_NO_FUSION") && getenv("LLAMAGO_NO_FUSION")[0] == '1';
+    if (N == 1 && !no_fusion && g_keep_decode_graph.load(std::memory_order_relaxed)) {   // the decode loop (server.go:153-217): the kept graph of a one-token Eval, moved to this position
+        const bool with_emb = !lctx->embedding.empty();
+        eval_cache* c = lctx->decode_graph;
+        if (c && (c->model != model || c->with_emb != with_emb)) { eval_cache_free(c); c = lctx->decode_graph = nullptr; }
+        if (!c) c = lctx->decode_graph = eval_cache_build(ctx0, model, lctx->K, lctx->V, ctxSize, 1, pastCount, with_emb);
+        if (!c->failed) {
+            g_err.clear();
+            if (!ctx0 || !ctx0->hip) return halt_rc("ml_GraphCompute: no HIP context");
+            eval_cache_patch(c, tokens, pastCount);
+            const long t_build = us_since(tp0);
+            const auto tp1 = std::chrono::steady_clock::now();
+            ctx0->generation++;   // nodes of the caller's earlier graphs are no longer the last computed ones (ml_TensorRead)
+            if (lh_graph_compute(ctx0->hip, c->flat.data(), c->nl, c->nn, LH_GRAPH_LAST_ROW_LOGITS)) return halt_rc(lh_last_error(ctx0->hip));
+            const long t_compute = us_since(tp1);
+            const auto tp2 = std::chrono::steady_clock::now();
+            if (lh_node_read(ctx0->hip, c->logits_index, 0, lctx->logits.data(), vocabSize)) return halt_rc(lh_last_error(ctx0->hip));
+            if (with_emb && c->emb_index >= 0 && lh_node_read(ctx0->hip, (uint32_t)c->emb_index, 0, lctx->embedding.data(), model->hp.embdSize)) return halt_rc(lh_last_error(ctx0->hip));
+            if (timing) fprintf(stderr, "[llamago] Eval N=1: kept graph moved in %ld us (%zu + %zu fields), GraphCompute %ld us, logits read %ld us\n", t_build, c->patches.size(), c->hpatches.size(), t_compute, us_since(tp2));
+            return 0;
+        }
+    }
     ml_graph* graph = ml_NewGraph();
     int rc = 1;
     const bool save = g_gc_enabled;
@@ -790,31 +931,46 @@ int llama_Eval(llama_context* lctx, llama_model* model, const uint32_t* tokens, 
 // Per tensor 11 int32: op, ne[4], nb[4], src0, src1 — sources are indices into this same list (leafs first, then nodes, the order
 // ml_GraphCompute walks), -1 = nil.  The checker library exports the same function over its own builders: tests compare the two
 // lists so that the product's host mirror and the checker cannot drift apart unnoticed.  Returns the number of tensors.
+}  // extern "C"
+namespace {
+struct shape_model {   // a model of shape `hp` whose tensors have extents and no storage: enough to BUILD graphs over (no GPU)
+    llama_model m;
+    std::vector<ml_tensor*> mine;
+    ml_tensor *kK = nullptr, *kV = nullptr;
+    ml_tensor* shape_leaf(uint32_t dims, uint32_t ne0, uint32_t ne1) { ml_tensor* t = new_leaf(ML_TYPE_F32, dims, ne0, ne1, 1, false); mine.push_back(t); return t; }
+    shape_model(const llama_hparams* hp, uint32_t ctxSize) {
+        m.hp = *hp;
+        m.ffSize = ff_size(hp->embdSize, hp->multSize);
+        m.layer0 = 0; m.layer1 = hp->layersCount;
+        const uint32_t d = hp->embdSize, V = hp->vocabSize, F = m.ffSize;
+        m.tokEmbeddings = shape_leaf(2, d, V); m.norm = shape_leaf(1, d, 1); m.output = shape_leaf(2, d, V);
+        m.layers.assign(hp->layersCount, llama_layer{});
+        for (llama_layer& l : m.layers) {
+            l.attentionNorm = shape_leaf(1, d, 1); l.wq = shape_leaf(2, d, d); l.wk = shape_leaf(2, d, d); l.wv = shape_leaf(2, d, d); l.wo = shape_leaf(2, d, d);
+            l.ffn_norm = shape_leaf(1, d, 1); l.w1 = shape_leaf(2, d, F); l.w2 = shape_leaf(2, F, d); l.w3 = shape_leaf(2, d, F);
+        }
+        const uint32_t kvn = d * hp->layersCount * ctxSize;
+        kK = shape_leaf(1, kvn, 1); kV = shape_leaf(1, kvn, 1);
+    }
+    ~shape_model() {
+        for (ml_tensor* t : mine) free_tensor(t);
+        m.tokEmbeddings = m.norm = m.output = nullptr;
+        m.layers.clear();
+    }
+};
+}  // namespace
+extern "C" {
 int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_t N, uint32_t pastCount, int32_t* out, uint32_t cap_tensors, uint32_t* n_leafs) {
     g_err.clear();
     if (!hp || !N || (uint64_t)pastCount + N > ctxSize) return -1;
-    llama_model m;
-    m.hp = *hp;
-    m.ffSize = ff_size(hp->embdSize, hp->multSize);
-    m.layer0 = 0; m.layer1 = hp->layersCount;
-    const uint32_t d = hp->embdSize, V = hp->vocabSize, F = m.ffSize;
-    std::vector<ml_tensor*> mine;
-    auto shape_leaf = [&](uint32_t dims, uint32_t ne0, uint32_t ne1) { ml_tensor* t = new_leaf(ML_TYPE_F32, dims, ne0, ne1, 1, false); mine.push_back(t); return t; };
-    m.tokEmbeddings = shape_leaf(2, d, V); m.norm = shape_leaf(1, d, 1); m.output = shape_leaf(2, d, V);
-    m.layers.assign(hp->layersCount, llama_layer{});
-    for (llama_layer& l : m.layers) {
-        l.attentionNorm = shape_leaf(1, d, 1); l.wq = shape_leaf(2, d, d); l.wk = shape_leaf(2, d, d); l.wv = shape_leaf(2, d, d); l.wo = shape_leaf(2, d, d);
-        l.ffn_norm = shape_leaf(1, d, 1); l.w1 = shape_leaf(2, d, F); l.w2 = shape_leaf(2, F, d); l.w3 = shape_leaf(2, d, F);
-    }
-    const uint32_t kvn = d * hp->layersCount * ctxSize;
-    ml_tensor *kK = shape_leaf(1, kvn, 1), *kV = shape_leaf(1, kvn, 1);
+    shape_model sm(hp, ctxSize);
     std::vector<uint32_t> tokens(N, 1u);
     ml_graph* g = ml_NewGraph();
     const bool save = g_gc_enabled;
     g_gc_enabled = true;
     ml_tensor* const gc_mark = g_gc_head;
     int count = -1;
-    if (build_eval_graph(nullptr, &m, kK, kV, ctxSize, tokens.data(), N, pastCount, g)) {
+    if (build_eval_graph(nullptr, &sm.m, sm.kK, sm.kV, ctxSize, tokens.data(), N, pastCount, g)) {
         std::unordered_map<const ml_tensor*, int> idx;
         std::vector<ml_tensor*> all(g->leafs);
         all.insert(all.end(), g->nodes.begin(), g->nodes.end());
@@ -833,9 +989,59 @@ int llamago_DescribeEvalGraph(const llama_hparams* hp, uint32_t ctxSize, uint32_
     ml_FreeGraph(g);
     gc_free_down_to(gc_mark);
     g_gc_enabled = save;
-    for (ml_tensor* t : mine) free_tensor(t);
-    m.tokEmbeddings = m.norm = m.output = nullptr;
-    m.layers.clear();
+    return count;
+}
+// Harness extension (no GPU): the array llama_Eval hands to lh_graph_compute for N tokens (ids 1..N) at `pastQuery`, as numbers - per tensor 16
+// int64: op, dtype, flags, ne[4], nb[4], src0, src1, storage, view_off, and the bit patterns of an owner leaf's host values folded into one
+// number (0 without host data).  pastBuild < 0: from a fresh build at pastQuery (what every Eval did before round 6).  pastBuild >= 0: from
+// the KEPT graph of the decode loop, learnt around pastBuild and moved to pastQuery (eval_cache) - tests require the two to be identical.
+// Returns the number of tensors, -1 on bad arguments, -2 when the kept graph declined (its affine check failed).
+void llamago_KeepDecodeGraph(int on) { g_keep_decode_graph.store(on ? 1 : 0); }
+int llamago_DescribeEvalArray(const llama_hparams* hp, uint32_t ctxSize, uint32_t N, int64_t pastBuild, uint32_t pastQuery, int64_t* out, uint32_t cap_tensors, uint32_t* n_leafs) {
+    g_err.clear();
+    if (!hp || !N || (uint64_t)pastQuery + N > ctxSize || (pastBuild >= 0 && (uint64_t)pastBuild + N > ctxSize)) return -1;
+    shape_model sm(hp, ctxSize);
+    std::vector<uint32_t> tokens(N);
+    for (uint32_t i = 0; i < N; i++) tokens[i] = i + 1;
+    ml_context scratch;
+    scratch.maxThreads = 1; scratch.hip = nullptr;
+    const lh_tensor* T = nullptr;
+    uint32_t nl = 0, nn = 0;
+    eval_cache* c = nullptr;
+    ml_graph* g = nullptr;
+    const bool save = g_gc_enabled;
+    ml_tensor* const gc_mark = g_gc_head;
+    int count = -1;
+    if (pastBuild >= 0) {
+        c = eval_cache_build(&scratch, &sm.m, sm.kK, sm.kV, ctxSize, N, (uint32_t)pastBuild, false);
+        if (c->failed) count = -2;
+        else { eval_cache_patch(c, tokens.data(), pastQuery); T = c->flat.data(); nl = c->nl; nn = c->nn; }
+    } else {
+        g = ml_NewGraph();
+        g_gc_enabled = true;
+        if (build_eval_graph(&scratch, &sm.m, sm.kK, sm.kV, ctxSize, tokens.data(), N, pastQuery, g)) { flatten_graph(&scratch, g, &nl, &nn); T = scratch.flat.data(); }
+    }
+    if (T) {
+        count = (int)(nl + nn);
+        if (n_leafs) *n_leafs = nl;
+        for (uint32_t i = 0; i < nl + nn && i < cap_tensors && out; ++i) {
+            const lh_tensor& t = T[i];
+            int64_t* o = out + (size_t)i * 16;
+            o[0] = t.op; o[1] = t.dtype; o[2] = t.flags;
+            for (int k = 0; k < 4; ++k) { o[3 + k] = t.ne[k]; o[7 + k] = (int64_t)t.nb[k]; }
+            o[11] = t.src0; o[12] = t.src1; o[13] = t.storage; o[14] = (int64_t)t.view_off;
+            uint64_t h = 0;
+            if (t.host) {
+                const uint64_t n = (uint64_t)t.ne[0] * t.ne[1] * t.ne[2] * t.ne[3];
+                for (uint64_t k = 0; k < n; k++) { uint32_t bits; memcpy(&bits, t.host + k, 4); h = h * 1000003ull + bits + 1; }
+            }
+            o[15] = (int64_t)(h & 0x7fffffffffffffffull);
+        }
+    }
+    if (g) ml_FreeGraph(g);
+    gc_free_down_to(gc_mark);
+    g_gc_enabled = save;
+    eval_cache_free(c);
     return count;
 }
 

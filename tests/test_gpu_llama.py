@@ -391,6 +391,41 @@ def test_resident_greedy_loop_equals_eval_loop(product):
     m.free()
 
 
+def test_kept_decode_graph_gives_the_bits_of_a_fresh_build(product):
+    """llama_Eval keeps the graph of a one-token Eval and moves it to the next position instead of building ~1700 tensors per token
+    (host/llamago.cpp, eval_cache).  Same context, same positions, the kept graph on and off (llamago_KeepDecodeGraph): logits and the
+    embedding row bit for bit - from the first position of the window to its last, across a prompt in between (the kept graph must
+    survive Evals of other shapes), with the embedding output switched on half way (a different graph: the kept one is rebuilt)."""
+    product.lib.llamago_KeepDecodeGraph.restype = None
+    product.lib.llamago_KeepDecodeGraph.argtypes = [C.c_int]
+    hp = make_hparams(**SHAPES["small"], ctx=40)
+    m = product.NewSyntheticModel(hp, 7)
+    runs = {}
+    try:
+        for keep in (1, 0):
+            product.lib.llamago_KeepDecodeGraph(keep)
+            c = m.NewContext(40, 1)
+            out = []
+            tok = 5
+            for past in range(0, 12):                       # decode from an empty context
+                lg = c.Eval([tok], past); out.append(lg.copy()); tok = int(np.argmax(lg))
+            lg = c.Eval([3, 1658, 278, 9, 11], 12); out.append(lg.copy())   # a prompt in between
+            c.EnableEmbedding()
+            tok = int(np.argmax(lg))
+            for past in range(17, 40):                      # ... and on to the last position of the window
+                lg = c.Eval([tok], past); out.append(lg.copy()); out.append(c.Embedding().copy()); tok = int(np.argmax(lg))
+            with pytest.raises(Exception):
+                c.Eval([tok], 40)
+            runs[keep] = out
+            c.free()
+    finally:
+        product.lib.llamago_KeepDecodeGraph(1)
+    m.free()
+    assert len(runs[0]) == len(runs[1])
+    for k, (a, b) in enumerate(zip(runs[1], runs[0])):
+        assert np.array_equal(a, b), k
+
+
 def test_ggjt_roundtrip_through_hbm(product, oracle, tmp_path):
     """Model written by the oracle as ggjt v1 (f32 and f16), loaded by the product loader straight into HBM,
     evaluates like the oracle's own load of the same file (llama.go:712-976)."""
