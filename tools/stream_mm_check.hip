@@ -93,7 +93,7 @@ template <int MAXT, int NCT, int KC, int NIMG> static void run_dma_p(const Strea
     } else printf("k_stream_dma: two column tiles on\n");
 }
 template <int MAXT, int NCT, int KC> static void run_dma(const StreamArgs& a, int nCU) {
-    if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
+    if (g_nimg == 2) run_dma_p<MAXT, NCT, KC, 2>(a, nCU); else if (g_nimg == 4) run_dma_p<MAXT, NCT, KC, 4>(a, nCU); else if (g_nimg == 5) run_dma_p<MAXT, NCT, KC, 5>(a, nCU); else run_dma_p<MAXT, NCT, KC, 3>(a, nCU);
 }
 static int g_eq = 0;
 template <int MAXT, int NIMG> static void run_eq_img(const StreamArgs& a, int nCU) {
