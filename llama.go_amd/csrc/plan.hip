@@ -634,6 +634,10 @@ static constexpr uint32_t STREAM_ROWS_BUILT = 128, STREAM_ROWS_Q8 = 64, BATCH_RO
 static constexpr uint32_t B9S_MIN_ROWS = 49, B9S_MAX_ROWS = 64;   // fp32 on k_stream_b9 (see b9s_shape_ok).  Re-checked with the final kernel, same box (profiles/
 // r06_stream_b9_model_ab.txt): 17 / 32 pods 6.36 / 6.55 ms per tick on it against 5.89 / 6.11, 33 / 40 / 48 a tie (6.82 / 6.94 / 7.15 vs 6.92 / 6.97 / 7.11),
 // prompts of 65..128 tokens as two passes 14.0-15.8 ms against 9.7-14.4 in one pass of k_stream_dma: the range stays 49..64
+// fp32 prompts of 129..STREAM_TWO_PASS_MAX tokens: every matrix in TWO passes of the stream kernels (ceil(n / 2) rows each) instead of the tile GEMM, whose
+// launches cost what 256 rows cost.  7B, ms per Eval, same box (profiles/r06_two_pass_prompts.txt): 129 / 144 / 160 / 176 / 192 tokens 17.8 / 19.4 / 19.5 / 22.2 / 22.2
+// against 23.9 / 24.0 / 24.2 / 24.2 / 24.4 on the tile GEMM; from 200 tokens the two passes lose (25.1 against 24.4; 240: 28.3 against 24.7).
+static constexpr uint32_t STREAM_TWO_PASS_MAX = 192;
 static int stream_nct(uint32_t n) { return (int)((n + 15) / 16); }
 static int stream_kc(uint32_t n) { return n <= 48 ? 128 : 64; }
 static constexpr uint32_t stream_max_rows() { return STREAM_ROWS_BUILT; }
@@ -1909,6 +1913,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const int rs = eval_q8b_layers(p, x, x_out_dev, n, past, last_row_only, bc);
         if (rs != ST_NA) return rs;   // (ST_NA comes back before anything is enqueued: the fp32-MFMA route below takes the Eval)
     }
+    // fp32 prompts just past the stream kernels' 128 rows: two passes over the weights, ceil(n / 2) rows each (the rows of a pass are independent of the other
+    // pass's in every launch but attention, which runs once over all n as before).  Measurements: STREAM_TWO_PASS_MAX.
+    static const uint32_t two_pass_max = getenv("LLAMAHIP_TWO_PASS_MAX") ? (uint32_t)atoi(getenv("LLAMAHIP_TWO_PASS_MAX")) : STREAM_TWO_PASS_MAX;   // (A/B switch: 128 = off)
+    const bool two_pass = !bc && m.wtype == 0 && n > stream_max_rows() && n <= two_pass_max && n <= 2 * stream_max_rows() && d % GBK == 0 && F % GBK == 0 && stream_shape_ok(ctx, m);
+    const uint32_t sb = two_pass ? (n + 1) / 2 : n;   // rows per pass of the stream kernels
     bool h_ready = false;   // p->h already holds this layer's RMSNorm * attn_norm rows (written by the previous layer's w2 reduce pass)
     for (uint32_t il = m.layer0; il < m.layer1; ++il) {
         const LayerW& L = m.layers[il];
@@ -1917,7 +1926,7 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         const bool q8 = m.wtype == 7;
         bool qkv_roped = false, gated = false;
         // 17..64 rows: wo / w2 as K-split pairs whose reduce pass also writes the next norm's rows into p->h (gemm_stream_split)
-        const bool ksp = n > 16 && n <= stream_max_rows() && !q8 && mfma;
+        const bool ksp = sb > 16 && sb <= stream_max_rows() && !q8 && mfma;
         bool hf_ready = false;
         const float* wqkv[3] = {L.wq, L.wk, L.wv};
         const float* sqkv[3] = {L.s_wq, L.s_wk, L.s_wv};
@@ -1942,7 +1951,12 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (q8) {   // (prompts beyond k_stream_q8b's 64 rows)
             if ((rc = gemm_q8_group(ctx, p->h, d, 3, wqkv, sqkv, yqkv, nullptr, d, d, n, d, "gemm_q8_wqkv"))) return rc;
         } else if (mfma) {
-            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 3, wqkv, nullptr, nullptr, d, d, n, d, "stream_wqkv_rope", &fq) : ST_NA;
+            int rs = ST_NA;
+            for (uint32_t b0 = 0; b0 < n && sb <= stream_max_rows(); b0 += sb) {
+                StreamArgs fb = fq;
+                fb.q_out = p->q + (size_t)b0 * d; fb.past = past + b0;
+                if ((rs = gemm_stream_group(ctx, p->h + (size_t)b0 * d, d, 3, wqkv, nullptr, nullptr, d, d, std::min(sb, n - b0), d, "stream_wqkv_rope", &fb))) break;
+            }
             if (rs == ST_NA && n > 64) {   // long prompts: the same epilogue in the tile GEMM
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_QKV_ROPE; ga.q_out = p->q; ga.k_cache = m.kc + slot; ga.v_cache = m.vc + slot; ga.rope = rope; ga.hd = m.hd; ga.past = past;
@@ -1974,7 +1988,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         }
         int wo_rs = ST_NA;
         if (ksp) {
-            wo_rs = gemm_stream_split(ctx, L.wo, p->attn, d, d, d, n, x, p->xb, L.ffn_norm, p->h, "stream_wo_ksplit");
+            for (uint32_t b0 = 0; b0 < n; b0 += sb)
+                if ((wo_rs = gemm_stream_split(ctx, L.wo, p->attn + (size_t)b0 * d, d, d, d, std::min(sb, n - b0), x + (size_t)b0 * d, p->xb + (size_t)b0 * d, L.ffn_norm, p->h + (size_t)b0 * d, "stream_wo_ksplit"))) break;
             if (wo_rs < 0) return wo_rs;
             hf_ready = wo_rs == 0;
         }
@@ -2000,7 +2015,11 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         } else if (mfma) {
             StreamArgs fa = {};   // short prompts: silu(w1 h) * (w3 h) in the epilogue of (w1, w3) tile pairs
             fa.epi = ST_EPI_SILU_MUL;
-            int rs = n <= stream_max_rows() ? gemm_stream_group(ctx, p->h, d, 2, w13, yg, nullptr, F, d, n, F, "stream_w1w3_silu", &fa) : ST_NA;
+            int rs = ST_NA;
+            for (uint32_t b0 = 0; b0 < n && sb <= stream_max_rows(); b0 += sb) {
+                float* ygb[2] = {p->g + (size_t)b0 * F, nullptr};
+                if ((rs = gemm_stream_group(ctx, p->h + (size_t)b0 * d, d, 2, w13, ygb, nullptr, F, d, std::min(sb, n - b0), F, "stream_w1w3_silu", &fa))) break;
+            }
             if (rs == ST_NA && n > 64) {
                 GemmArgs ga = {};
                 ga.epi = GEMM_EPI_SILU_MUL;
@@ -2020,7 +2039,8 @@ int plan_eval(Plan* p, const uint32_t* tokens_host, const float* x_in_dev, float
         int w2_rs = ST_NA;
         if (ksp) {
             const float* next_gamma = last ? nullptr : m.layers[il + 1].attn_norm;   // the next layer's first norm rides on the reduce pass
-            w2_rs = gemm_stream_split(ctx, L.w2, p->g, F, d, F, n, p->xb, y, next_gamma, p->h, "stream_w2_ksplit");
+            for (uint32_t b0 = 0; b0 < n; b0 += sb)
+                if ((w2_rs = gemm_stream_split(ctx, L.w2, p->g + (size_t)b0 * F, F, d, F, std::min(sb, n - b0), p->xb + (size_t)b0 * d, y + (size_t)b0 * d, next_gamma, p->h + (size_t)b0 * d, "stream_w2_ksplit"))) break;
             if (w2_rs < 0) return w2_rs;
             h_ready = w2_rs == 0 && next_gamma != nullptr;
         }

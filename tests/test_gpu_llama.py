@@ -241,15 +241,16 @@ def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     assert greedy_margin(lg_o) > 10 * TOL, "test seed has a near-tie; pick another"
 
 
-@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 81, 96, 97, 112, 113, 127, 128, 129])   # both sides of every launch-shape boundary, ragged last tiles (16 k - 1)
+@pytest.mark.parametrize("n_prompt", [2, 5, 8, 9, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 81, 96, 97, 112, 113, 127, 128, 129, 130, 145, 161, 191, 192, 193])   # both sides of every launch-shape boundary, ragged last tiles (16 k - 1)
 def test_prefill_mfma_path_matches_oracle(product, oracle, n_prompt):
     """One Eval of N tokens: 2..8 rows ride the decode weight stream (k_gemv_rows), 9..16 k_stream_mm2 (fp32 MFMA, RMSNorm folded), 17..48 and
     65..128 k_stream_dma (fp32 MFMA behind LDS-DMA loader waves), 49..64 k_stream_b9 (eight exact bf16 products per weight over activation
-    planes, round 6) - RoPE / cache append / SiLU fused into the epilogues, ragged last column tile - and more rows the tile GEMMs + blocked
-    attention; the next decode steps read the KV cache that prefill wrote."""
+    planes, round 6), 129..192 k_stream_dma again in TWO passes of ceil(N / 2) rows per matrix (round 6) - RoPE / cache append / SiLU fused into
+    the epilogues, ragged last column tile - and more rows the tile GEMMs + blocked attention; the next decode steps read the KV cache that
+    prefill wrote."""
     rng = np.random.default_rng(n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["small"]["vocab"], n_prompt)]
-    out = decode_both(product, oracle, "small", 128 if n_prompt <= 120 else 192, prompt, 4)
+    out = decode_both(product, oracle, "small", 128 if n_prompt <= 120 else (192 if n_prompt <= 180 else 256), prompt, 4)
     toks_h, lg_h = out["hip"]
     toks_o, lg_o = out["orc"]
     assert out["fused"] == 1
@@ -600,16 +601,16 @@ def test_headline_workload_at_full_depth(product, int8):
     m.free()
 
 
-@pytest.mark.parametrize("n_prompt", [3, 6, 8, 12, 24, 40, 49, 56, 64, 72, 90, 97, 112, 127, 128, 129])
+@pytest.mark.parametrize("n_prompt", [3, 6, 8, 12, 24, 40, 49, 56, 64, 72, 90, 97, 112, 127, 128, 129, 160, 193])
 def test_7b_shape_slice_short_prompts_match_oracle(product, oracle, n_prompt):
     """The 7B layer shape at the prompt lengths where the launch shape changes: 3 / 6 / 8 rows (the decode weight stream with four / eight
     activation rows), 12 rows (MFMA stream kernel, RMSNorm folded into the GEMMs), 24 rows (two column tiles, LDS-DMA loader waves; wo / w2 as
     K-split pairs + reduce pass that writes the next norm), 40 rows (three column tiles), 49 / 56 / 64 rows (four: k_stream_b9 over planes, wo / w2 as K-split fours), 72 / 90 rows (five / six),
-    97 / 112 / 127 / 128 rows (eight column tiles, MFMA waves as 2 K-groups x 2 column halves), 129 rows (the tile GEMM) - 2 layers, then 2
-    decode steps on the cache the prompt wrote."""
+    97 / 112 / 127 / 128 rows (eight column tiles, MFMA waves as 2 K-groups x 2 column halves), 129 / 160 rows (two passes of 65 + 64 / 80 + 80
+    rows per matrix), 193 rows (the tile GEMM) - 2 layers, then 2 decode steps on the cache the prompt wrote."""
     rng = np.random.default_rng(100 + n_prompt)
     prompt = [int(t) for t in rng.integers(0, SHAPES["7B"]["vocab"], n_prompt)]
-    out = decode_both(product, oracle, "7B", 64 if n_prompt <= 56 else (128 if n_prompt <= 120 else 192), prompt, 3, layers=2, threads=64)
+    out = decode_both(product, oracle, "7B", 64 if n_prompt <= 56 else (128 if n_prompt <= 120 else (192 if n_prompt <= 180 else 256)), prompt, 3, layers=2, threads=64)
     toks_h, lg_h = out["hip"]
     toks_o, lg_o = out["orc"]
     assert out["fused"] == 1
