@@ -477,6 +477,18 @@ def main():
                         ct.Eval(toks, 0)
                         tl.append(time.perf_counter() - t_p)
                     by_len[str(n_p)] = round(min(tl) * 1e3, 3)
+                ct.free()
+                ct = mt.NewContext(256, 1)   # (the decode phases' window is shorter than these prompts)
+                for n_p in (128, 160):       # 128: one pass of the stream kernels; 160: every matrix in two passes of 80 rows (round 6; the tile GEMM before)
+                    toks = [PROMPT[i % len(PROMPT)] for i in range(n_p)]
+                    ct.Eval(toks, 0)
+                    tl = []
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t_p = time.perf_counter()
+                        ct.Eval(toks, 0)
+                        tl.append(time.perf_counter() - t_p)
+                    by_len[str(n_p)] = round(min(tl) * 1e3, 3)
                 result["prompt_8_tokens"]["ms_by_prompt_length"] = by_len
                 ct.free()
                 mt.QuantizeQ8()
