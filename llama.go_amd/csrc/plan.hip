@@ -1691,6 +1691,15 @@ static int eval_q8b_layers(Plan* p, const float* x, float* x_out_dev, uint32_t n
             float* yb = yv + (size_t)b0 * m.V;
             const uint32_t nb = std::min(STREAM_ROWS_Q8, nr - b0);
             rc = gemm_q8b_group(ctx, hs + (size_t)(r0 + b0) * d, pd, d, 1, &wv, &sv, &yb, nullptr, m.V, d, nb, m.V, m.wtype == 7 ? "q8b_lmhead" : "b9s_lmhead");
+            if (rc == ST_NA && m.wtype == 0 && nb > 1 && m.V % 32 == 0) {
+                // fp32 output matrix with eight row tiles per workgroup next to four column tiles (7B at 49..64 rows): no k_stream_b9 launch of that shape - the two halves
+                // of the vocabulary have one each (four row tiles).  64 pods, 7B: 172 us on k_stream_dma -> see profiles/r06_lmhead_halves.txt
+                const uint32_t Vh = m.V / 2;
+                const float* wh[2] = {m.output, m.output + (size_t)Vh * d};
+                float* yh[2] = {yb, yb + Vh};
+                for (int h2 = 0; h2 < 2; ++h2)
+                    if ((rc = gemm_q8b_group(ctx, hs + (size_t)(r0 + b0) * d, pd, d, 1, &wh[h2], &sv, &yh[h2], nullptr, Vh, d, nb, m.V, "b9s_lmhead"))) break;
+            }
             if (rc == ST_NA && m.wtype == 0) {   // fp32 output matrix without a k_stream_b9 launch (eight row tiles next to four column tiles): the fp32 rows
                 if (nb == 1) {
                     GemvArgs ga = {};
