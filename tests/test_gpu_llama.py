@@ -230,6 +230,31 @@ def test_chunked_prefill_all_kernel_families(product, oracle):
         assert rel(a, b) <= TOL
 
 
+def test_two_pass_prompts_continue_a_non_empty_cache(product, oracle):
+    """fp32 prompts of 129..192 tokens run every matrix in two passes of the stream kernels (plan_eval, round 6): the second pass's rows sit at
+    positions past + ceil(n / 2).. of the RoPE table and the cache.  Chunks of 150 and 131 tokens behind 30 cached ones, then decode steps on
+    the cache they wrote."""
+    kw = dict(SHAPES["small"])
+    kw["layers"] = 2
+    hp = make_hparams(**kw, ctx=320)
+    rng = np.random.default_rng(23)
+    toks = [int(t) for t in rng.integers(0, kw["vocab"], 315)]
+    chunks = [30, 150, 131, 1, 1]
+    res = {}
+    for name, lib in (("hip", product), ("orc", oracle)):
+        m = lib.NewSyntheticModel(hp, 1234)
+        c = m.NewContext(320, 16, False)
+        out, past = [], 0
+        for n in chunks:
+            out.append(c.Eval(toks[past:past + n], past))
+            past += n
+        c.free()
+        m.free()
+        res[name] = out
+    for k, (a, b) in enumerate(zip(res["hip"], res["orc"])):
+        assert rel(a, b) <= TOL, k
+
+
 @pytest.mark.parametrize("shape,prompt", [("tiny", [1, 5, 9, 200, 17, 3, 44, 100]), ("tiny", [7]), ("small", [1, 306, 1658, 278, 1593, 310, 834, 338])])
 def test_greedy_decode_matches_oracle(product, oracle, shape, prompt):
     out = decode_both(product, oracle, shape, 64, prompt, 12)
