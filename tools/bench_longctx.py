@@ -1,6 +1,9 @@
 """Decode step time vs position (long-context check): LLaMA-7B fp32, prefill P tokens, then 16 resident decode steps.
 Then the same for 8 pods in one weight pass (lh_batch ticks: per-row split-T attention), every pod behind its own P-token prompt.
-usage: python tools/bench_longctx.py [--past 1000] [--pods 8]"""
+usage: python tools/bench_longctx.py [--past 1000] [--pods 8]
+(Under rocprofv3 give ONE position per invocation: with four or more contexts captured one after the other in one traced process - each with its 8-step decode graphs of
+~1800 kernel nodes - the profiler's tool library segfaults inside the fourth context's first graph launch; the same sequence runs clean without the profiler, also under
+MALLOC_CHECK_=3, and every single position runs clean with it: profiles/r06_longctx.txt.)"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
