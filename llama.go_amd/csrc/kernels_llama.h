@@ -570,26 +570,48 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
 // (round 6: the chunk weights w_s = exp(m_s - M) are computed ONCE, by thread s, into LDS - every one of the 128 threads evaluated all of them in
 // f64 before, twice: 8.8 us of a 12.6 + 8.8 us attention at T = 1000, profiles/r06_longctx.txt.  Same values, same order of the sums.)
 constexpr int ATT_COMBINE_MAX = 256;   // chunks a combine can weigh in LDS (ctx up to 32768)
+// (after the evidence session: the loops over the chunks fetch EIGHT partials at a time before they use them - one thread walked its column chunk by chunk, a
+// dependent L2 round trip each: 8.6 us of a 15.8 + 8.6 us attention at T = 2000.  Same values, same order of every sum.)
 __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, const float* __restrict__ part, uint32_t nch) {
     __shared__ float wsh[ATT_COMBINE_MAX];
     const uint32_t h = blockIdx.x, hd = a.hd, j = blockIdx.y;
     const uint32_t past = a.rows ? a.rows[j].pos : (a.sp ? a.sp->past : a.past_host);
     const uint32_t T = past + 1, n = (T + ATT_TC - 1) / ATT_TC;  // active chunks
     const float* base = part + ((size_t)j * gridDim.x + h) * nch * (hd + 2);
+    const size_t st = hd + 2;
+    constexpr uint32_t PF = 8;
     float M = -INFINITY;
-    for (uint32_t s = 0; s < n; ++s) M = fmaxf(M, base[(size_t)s * (hd + 2) + hd]);
+    for (uint32_t s0 = 0; s0 < n; s0 += PF) {
+        float v[PF];
+#pragma unroll
+        for (uint32_t u = 0; u < PF; ++u) v[u] = s0 + u < n ? base[(size_t)(s0 + u) * st + hd] : -INFINITY;
+#pragma unroll
+        for (uint32_t u = 0; u < PF; ++u) M = fmaxf(M, v[u]);
+    }
     const bool lds_w = n <= (uint32_t)ATT_COMBINE_MAX;
     if (lds_w) {
-        for (uint32_t s = threadIdx.x; s < n; s += 128) wsh[s] = (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M));
+        for (uint32_t s = threadIdx.x; s < n; s += 128) wsh[s] = (float)exp((double)__fsub_rn(base[(size_t)s * st + hd], M));
         __syncthreads();
     }
-    auto w_of = [&](uint32_t s) { return lds_w ? wsh[s] : (float)exp((double)__fsub_rn(base[(size_t)s * (hd + 2) + hd], M)); };
+    auto w_of = [&](uint32_t s) { return lds_w ? wsh[s] : (float)exp((double)__fsub_rn(base[(size_t)s * st + hd], M)); };
     float l = 0.f;
-    for (uint32_t s = 0; s < n; ++s) l = fmaf(base[(size_t)s * (hd + 2) + hd + 1], w_of(s), l);
+    for (uint32_t s0 = 0; s0 < n; s0 += PF) {
+        float v[PF];
+#pragma unroll
+        for (uint32_t u = 0; u < PF; ++u) v[u] = s0 + u < n ? base[(size_t)(s0 + u) * st + hd + 1] : 0.f;
+#pragma unroll
+        for (uint32_t u = 0; u < PF; ++u) if (s0 + u < n) l = fmaf(v[u], w_of(s0 + u), l);
+    }
     const float inv = __fdiv_rn(1.0f, l);
     for (uint32_t c = threadIdx.x; c < hd; c += 128) {
         float o = 0.f;
-        for (uint32_t s = 0; s < n; ++s) o = fmaf(base[(size_t)s * (hd + 2) + c], w_of(s), o);
+        for (uint32_t s0 = 0; s0 < n; s0 += PF) {
+            float v[PF];
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) v[u] = s0 + u < n ? base[(size_t)(s0 + u) * st + c] : 0.f;
+#pragma unroll
+            for (uint32_t u = 0; u < PF; ++u) if (s0 + u < n) o = fmaf(v[u], w_of(s0 + u), o);
+        }
         const float ov = __fmul_rn(o, inv);
         a.out[(size_t)j * a.d + h * hd + c] = ov;
         if (a.out_s3) attn_store_split3(a, (size_t)j * a.d + h * hd + c, ov);
