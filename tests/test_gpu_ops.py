@@ -98,6 +98,46 @@ def test_mul_mat_weights(pair, K, M, N):
     assert close(out["hip"][0], ref64, 1e-5)
 
 
+@pytest.mark.parametrize("N", [1, 5, 8, 33, 128, 300])
+@pytest.mark.parametrize("K,M", [(4096, 11008), (11008, 4096), (4096, 4096)])
+def test_mul_mat_full_7b_matrices_exact_properties(product, K, M, N):
+    """BASELINE's full matrix sizes (LLaMA-7B: w1 / w3 11008 x 4096, w2 4096 x 11008, wq..wo 4096 x 4096) cost the checker's scalar loop minutes per
+    product, so at these sizes the MulMat of the path (ml.go:1976-2098) is held to three properties that need no checker, are independent of the
+    size, and hold BIT FOR BIT whatever order a kernel sums in - as long as that order depends on nothing but the contraction index:
+      (1) powers of two commute with every rounding:  MulMat(4 W, x / 2) == 2 MulMat(W, x)
+      (2) a weight row's result does not depend on where the row stands:  MulMat(W[p], x) == MulMat(W, x)[:, p]
+      (3) a token row's result does not depend on its neighbours:  MulMat(W, x[q]) == MulMat(W, x)[q]
+    and the values themselves to a float64 product within the tolerance of the small cases above."""
+    ml = product
+    ml.lib.llamago_GraphComputeNoFusion.restype = C.c_int
+    ml.lib.llamago_GraphComputeNoFusion.argtypes = [C.c_void_p, C.c_void_p]
+    r = rng(K * 7 + M * 3 + N)
+    w = (r.standard_normal((M, K), dtype=np.float32) / np.float32(np.sqrt(K))).astype(np.float32)
+    x = r.standard_normal((N, K), dtype=np.float32)
+    p, q = r.permutation(M), r.permutation(N)
+    ctx = ml.NewContext(1, False, False)
+    g = ml.NewGraph()
+    try:
+        W, X = leaf(ml, ctx, w), leaf(ml, ctx, x)
+        ys = [ml.MulMat(ctx, W, X),
+              ml.MulMat(ctx, leaf(ml, ctx, w * np.float32(4)), leaf(ml, ctx, x * np.float32(0.5))),
+              ml.MulMat(ctx, leaf(ml, ctx, w[p]), X),
+              ml.MulMat(ctx, W, leaf(ml, ctx, x[q]))]
+        for t in ys:
+            ml.BuildForwardExpand(g, t)
+        if ml.lib.llamago_GraphComputeNoFusion(ctx, g):
+            raise RuntimeError(ml.last_error())
+        y, y_scaled, y_rows, y_tokens = (ml.read(ctx, t).reshape(N, M).copy() for t in ys)
+    finally:
+        ml.FreeGraph(g)
+        ml.ReleaseContext(ctx)
+    assert np.array_equal(y_scaled, y * np.float32(2)), f"scaling by powers of two changed {np.count_nonzero(y_scaled != y * np.float32(2))} sums"
+    assert np.array_equal(y_rows, y[:, p]), f"{np.count_nonzero(y_rows != y[:, p])} sums depend on the weight row's place"
+    assert np.array_equal(y_tokens, y[q]), f"{np.count_nonzero(y_tokens != y[q])} sums depend on the token row's place"
+    ref64 = x.astype(np.float64) @ w.astype(np.float64).T
+    assert close(y, ref64, 1e-5)
+
+
 @pytest.mark.parametrize("T,N,H,hd,past", [(1, 1, 4, 64, 0), (7, 1, 4, 128, 6), (24, 8, 2, 128, 16), (5, 5, 3, 32, 0)])
 def test_attention_chain(pair, T, N, H, hd, past):
     """KQ (strided operands) -> Scale -> DiagMaskInf -> SoftMax -> KQV through a transposing Cpy -> merge Cpy
