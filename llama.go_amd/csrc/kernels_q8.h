@@ -74,6 +74,19 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     const uint64_t dq2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.w[2]) - q0 - dq1 : 0, ds2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.ws[2]) - s0 - ds1 : 0;
     const uint64_t xdummy = (uint64_t)sgpr_ptr(a.x);   // 4K bytes: covers a quant row (K bytes) and a scale row (K/8 bytes)
     const uint32_t rpm = a.rows_per_mat;
+    // MAP_BLOCK (round 6): "virtual" bases base_m - m * rpm * K, so that a row's address is  virtual base + row * K  with the VIRTUAL row index, and
+    // the workgroup's matrix is chosen once: its rows cross at most one matrix boundary (`bnd`), which costs one compare + select per row.  The
+    // general form (m from two compares, r = row - m * rpm, three selects per plane) stood in front of every row's loads, and with one wave per
+    // SIMD nothing hides scalar work: wq|wk|wv of 7B 12.7 -> 11.8 us standalone, against 10.9 us for the same bytes as ONE matrix and 32.9 / 32.7 us
+    // on the fp32 kernel, whose rows are four times as long (tools/q8s_phase_probe, profiles/r06_q8s_phase_probe.txt).
+    const uint64_t srow = (uint64_t)(K >> 5) * 4u;
+    // (selects against the constant 0 again: a select among three 64-bit values becomes a table in scratch memory, 4x slower - measured)
+    const uint64_t e1q = dq1 - (uint64_t)rpm * K, e2q = dq2 - (uint64_t)rpm * K, e1s = ds1 - (uint64_t)rpm * srow, e2s = ds2 - (uint64_t)rpm * srow;
+    const uint32_t mlo = (r0 >= rpm ? 1u : 0u) + (r0 >= 2u * rpm ? 1u : 0u), mhi = (r1 - 1u >= rpm ? 1u : 0u) + (r1 - 1u >= 2u * rpm ? 1u : 0u);
+    const bool one_mat = mhi - mlo <= 1u;     // at most ONE matrix boundary inside the workgroup's rows (always, unless a matrix is shorter than a workgroup's block)
+    const uint64_t qv_wg = q0 + (mlo >= 1u ? e1q : 0) + (mlo == 2u ? e2q : 0), sv_wg = s0 + (mlo >= 1u ? e1s : 0) + (mlo == 2u ? e2s : 0);
+    const uint32_t bnd = (mlo + 1u) * rpm;    // rows from here on belong to the next matrix
+    const uint64_t nq = (mlo == 0u ? e1q : 0) + (mlo == 1u ? e2q : 0), ns = (mlo == 0u ? e1s : 0) + (mlo == 1u ? e2s : 0);
     f4 xr[KI][4];
     bool act[KI];
     uint32_t qoff[KI], soff[KI];
@@ -99,6 +112,7 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     float resid_pre;
     double2 cs_pre;
     uint32_t past_pre;
+    // (requested in FRONT of the first weight rows: behind them the position -> RoPE entry chain waits for the rows, loads return in order - measured 11.97 -> 12.72 us)
     gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
 
     // slot u of this group holds row rb + G*u
@@ -107,12 +121,22 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
         for (int u = 0; u < U; ++u) {
             const uint32_t row = row_base + G * u;
             uint64_t qb = xdummy, sb = xdummy;
+            if (MAP == MAP_BLOCK) {
+                if (row < r1) {
+                    uint64_t bq = qv_wg + (row >= bnd ? nq : 0), bs = sv_wg + (row >= bnd ? ns : 0);
+                    if (!one_mat) {
+                        bq = q0 + (row >= rpm ? e1q : 0) + (row >= 2u * rpm ? e2q : 0);
+                        bs = s0 + (row >= rpm ? e1s : 0) + (row >= 2u * rpm ? e2s : 0);
+                    }
+                    qb = bq + (uint64_t)row * K;
+                    sb = bs + (uint64_t)row * srow;
+                }
+            } else
             if (row < r1) {   // scalar condition: s_cselect on the two addresses, no exec masking
                 uint32_t m = 0, r = row;
-                if (MAP == MAP_BLOCK) { m = (row >= rpm ? 1u : 0u) + (row >= 2u * rpm ? 1u : 0u); r = row - m * rpm; }
                 if (MAP == MAP_PAIR) { m = row & 1u; r = row >> 1; }
-                qb = q0 + (m >= 1u ? dq1 : 0) + (m == 2u ? dq2 : 0) + (uint64_t)r * K;
-                sb = s0 + (m >= 1u ? ds1 : 0) + (m == 2u ? ds2 : 0) + (uint64_t)r * (K >> 5) * 4u;
+                qb = q0 + (m >= 1u ? dq1 : 0) + (uint64_t)r * K;
+                sb = s0 + (m >= 1u ? ds1 : 0) + (uint64_t)r * srow;
             }
             // addresses rebuilt from integers: say that they are GLOBAL memory, or the loads become flat_load (counted on both wait counters)
             typedef const u4 __attribute__((address_space(1))) gu4;
@@ -127,6 +151,7 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     u4 wA[U][KI], wB[U][KI];
     float scA[U][KI], scB[U][KI];
     fetch(wA, scA, r0 + grp);
+    constexpr uint32_t STEP = G * U;
 
     if (PRO == PRO_RMSNORM) {
         double s = 0.0;
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
             }
         }
     };
-    constexpr uint32_t STEP = G * U;
+    // (both register sets requested in front of the norm: nothing, 18.60 / 18.58 us on w1|w3, 12.73 / 12.99 on wq|wk|wv - same probe)
     for (uint32_t rb = r0 + grp; rb < r1; rb += 2 * STEP) {
         fetch(wB, scB, rb + STEP);
         consume(wA, scA, rb);

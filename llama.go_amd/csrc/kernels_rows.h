@@ -230,6 +230,14 @@ __global__ __launch_bounds__(TH) void k_gemv_q8_rows(const GemvRowsArgs a) {
     const uint64_t dq2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.w[2]) - q0 - dq1 : 0, ds2 = MAP == MAP_BLOCK ? (uint64_t)sgpr_ptr(a.ws[2]) - s0 - ds1 : 0;
     const uint64_t xdummy = (uint64_t)sgpr_ptr(a.x);         // 4K bytes: covers a quant row (K bytes) and a scale row (K / 8 bytes)
     const uint32_t rpm = a.rows_per_mat;
+    // MAP_BLOCK: virtual bases + the workgroup's matrix chosen once, one compare + select per row for the one boundary its rows may cross (see k_gemv_q8s)
+    const uint64_t srow = (uint64_t)(K >> 5) * 4u;
+    const uint64_t e1q = dq1 - (uint64_t)rpm * K, e2q = dq2 - (uint64_t)rpm * K, e1s = ds1 - (uint64_t)rpm * srow, e2s = ds2 - (uint64_t)rpm * srow;
+    const uint32_t mlo = (r0 >= rpm ? 1u : 0u) + (r0 >= 2u * rpm ? 1u : 0u), mhi = (r1 - 1u >= rpm ? 1u : 0u) + (r1 - 1u >= 2u * rpm ? 1u : 0u);
+    const bool one_mat = mhi - mlo <= 1u;
+    const uint64_t qv_wg = q0 + (mlo >= 1u ? e1q : 0) + (mlo == 2u ? e2q : 0), sv_wg = s0 + (mlo >= 1u ? e1s : 0) + (mlo == 2u ? e2s : 0);
+    const uint32_t bnd = (mlo + 1u) * rpm;
+    const uint64_t nq = (mlo == 0u ? e1q : 0) + (mlo == 1u ? e2q : 0), ns = (mlo == 0u ? e1s : 0) + (mlo == 1u ? e2s : 0);
     bool act[KI];
     uint32_t qoff[KI], soff[KI];
     f4 xr[NC][KI][4];
@@ -251,12 +259,22 @@ __global__ __launch_bounds__(TH) void k_gemv_q8_rows(const GemvRowsArgs a) {
         for (int u = 0; u < U; ++u) {
             const uint32_t row = row_base + G * u;
             uint64_t qb = xdummy, sb = xdummy;
+            if (MAP == MAP_BLOCK) {
+                if (row < r1) {
+                    uint64_t bq = qv_wg + (row >= bnd ? nq : 0), bs = sv_wg + (row >= bnd ? ns : 0);
+                    if (!one_mat) {
+                        bq = q0 + (row >= rpm ? e1q : 0) + (row >= 2u * rpm ? e2q : 0);
+                        bs = s0 + (row >= rpm ? e1s : 0) + (row >= 2u * rpm ? e2s : 0);
+                    }
+                    qb = bq + (uint64_t)row * K;
+                    sb = bs + (uint64_t)row * srow;
+                }
+            } else
             if (row < r1) {   // scalar condition
                 uint32_t m = 0, r = row;
-                if (MAP == MAP_BLOCK) { m = (row >= rpm ? 1u : 0u) + (row >= 2u * rpm ? 1u : 0u); r = row - m * rpm; }
                 if (MAP == MAP_PAIR) { m = row & 1u; r = row >> 1; }
-                qb = q0 + (m >= 1u ? dq1 : 0) + (m == 2u ? dq2 : 0) + (uint64_t)r * K;
-                sb = s0 + (m >= 1u ? ds1 : 0) + (m == 2u ? ds2 : 0) + (uint64_t)r * (K >> 5) * 4u;
+                qb = q0 + (m >= 1u ? dq1 : 0) + (uint64_t)r * K;
+                sb = s0 + (m >= 1u ? ds1 : 0) + (uint64_t)r * srow;
             }
             typedef const u4 __attribute__((address_space(1))) gu4;
             typedef const float __attribute__((address_space(1))) gf32;
