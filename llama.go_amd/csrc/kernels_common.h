@@ -72,6 +72,24 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
+// The block of weight rows [r0, r1) of workgroup b in the weight-stream kernels: the M / 2 row PAIRS dealt as evenly as possible, the first
+// `wg_r` workgroups one pair more, the last workgroup also an odd last row.  wg_q / wg_r = quotient and remainder of (M / 2) / #workgroups, computed
+// by the HOST (launch_* in plan.hip).  Until round 6 every kernel computed floor(b * pairs / #workgroups) itself: two 64-bit divisions by a run-time
+// value - ~250 scalar and vector instructions in front of the first weight load of a launch that lasts 5..60 us (ISA of k_gemv_q8s; the decode step
+// has 160 such launches).  wg_q == wg_r == 0 (a caller that does not fill them: the probes under tools/) keeps the old formula.  Which rows a
+// workgroup owns changes no sum.
+__device__ __forceinline__ void wg_row_block(uint32_t M, uint32_t wg_q, uint32_t wg_r, uint32_t* r0, uint32_t* r1) {
+    const uint32_t b = blockIdx.x, nwg = gridDim.x;
+    if (wg_q | wg_r) {
+        *r0 = 2u * (b * wg_q + (b < wg_r ? b : wg_r));
+        *r1 = (b + 1 == nwg) ? M : 2u * ((b + 1) * wg_q + (b + 1 < wg_r ? b + 1 : wg_r));
+    } else {
+        const uint32_t npairs = M >> 1;
+        *r0 = 2u * (uint32_t)(((uint64_t)b * npairs) / nwg);
+        *r1 = (b + 1 == nwg) ? M : 2u * (uint32_t)(((uint64_t)(b + 1) * npairs) / nwg);
+    }
+}
+
 // A pointer pinned into a scalar register pair and made opaque to the optimiser.
 __device__ __forceinline__ const char* sgpr_ptr(const void* p) {
     uint32_t lo = (uint32_t)(uintptr_t)p, hi = (uint32_t)((uintptr_t)p >> 32);

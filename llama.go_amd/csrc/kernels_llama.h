@@ -37,6 +37,7 @@ struct GemvArgs {
     uint32_t hd;            // head dim (= rope dims)
     uint32_t d;             // embd
     const StepParams* sp;   // past
+    uint32_t wg_q, wg_r;    // (M / 2) / #workgroups and its remainder (wg_row_block; filled by launch_gemv / launch_gemv_q8)
 };
 
 template <int KI, int TH>
@@ -163,10 +164,8 @@ __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
     float* red = (float*)(smem_raw + NW * 8);        // [rows of this workgroup][NW] per-wave partial dot products
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t K4 = a.K >> 2;
-    const uint32_t nwg = gridDim.x;
-    const uint32_t npairs = a.M >> 1;
-    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
-    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    uint32_t r0, r1;
+    wg_row_block(a.M, a.wg_q, a.wg_r, &r0, &r1);
     const char *w0 = (const char*)a.w[0], *w1 = (const char*)a.w[1], *w2 = (const char*)a.w[2];
     const char* xdummy = (const char*)a.x;           // K floats = exactly one row's extent: any lane offset stays inside it
     const uint32_t rpm = a.rows_per_mat;

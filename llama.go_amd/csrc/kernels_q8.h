@@ -61,10 +61,8 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     const int tr = tid % TPR, wr = wave % NWR;
     const uint32_t grp = (uint32_t)__builtin_amdgcn_readfirstlane(tid / TPR);   // uniform within a wave
     const uint32_t K = a.K, K16 = K >> 4;
-    const uint32_t nwg = gridDim.x;
-    const uint32_t npairs = a.M >> 1;
-    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
-    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    uint32_t r0, r1;
+    wg_row_block(a.M, a.wg_q, a.wg_r, &r0, &r1);
     // Matrix bases as scalar integers: base of matrix 0 plus the DISTANCES to matrices 1 and 2, so that choosing a matrix is
     // `base + (m >= 1 ? d1 : 0) + (m == 2 ? d2 : 0)` — selects against the constant 0.  (A select among three pointer variables is
     // folded by the compiler into an indexed read of a table it builds in scratch memory, which vectorises the whole address path:

@@ -32,6 +32,7 @@ struct GemvRowsArgs {
     const BatchRow* rows;   //   rows of different streams: row r at position rows[r].pos of the cache rows[r].kc / .vc + kv_off
     uint64_t kv_off;
     uint32_t ldx, ldy, hd, d, past, n;   // n <= NC activation rows
+    uint32_t wg_q, wg_r;    // (M / 2) / #workgroups and its remainder (wg_row_block; filled by launch_gemv_rows / launch_gemv_q8_rows)
 };
 
 template <int KI, int U, int TH, int NC, int PRO, int EPI, int MAP>
@@ -42,10 +43,8 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
     float* red = (float*)(smem_raw + NC * NW * 8);          // [weight rows of this workgroup][NC][NW] per-wave partial dot products
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t K4 = a.K >> 2;
-    const uint32_t nwg = gridDim.x;
-    const uint32_t npairs = a.M >> 1;
-    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
-    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    uint32_t r0, r1;
+    wg_row_block(a.M, a.wg_q, a.wg_r, &r0, &r1);
     const char *w0 = (const char*)a.w[0], *w1 = (const char*)a.w[1], *w2 = (const char*)a.w[2];
     const char* xdummy = (const char*)a.x;                  // K floats = exactly one row's extent: any lane offset stays inside it
     const uint32_t rpm = a.rows_per_mat;
@@ -220,10 +219,8 @@ __global__ __launch_bounds__(TH) void k_gemv_q8_rows(const GemvRowsArgs a) {
     const int tr = tid % TPR, wr = wave % NWR;
     const uint32_t grp = (uint32_t)__builtin_amdgcn_readfirstlane(tid / TPR);   // uniform within a wave
     const uint32_t K = a.K, K16 = K >> 4;
-    const uint32_t nwg = gridDim.x;
-    const uint32_t npairs = a.M >> 1;
-    const uint32_t r0 = 2u * (uint32_t)(((uint64_t)blockIdx.x * npairs) / nwg);
-    const uint32_t r1 = (blockIdx.x + 1 == nwg) ? a.M : 2u * (uint32_t)(((uint64_t)(blockIdx.x + 1) * npairs) / nwg);
+    uint32_t r0, r1;
+    wg_row_block(a.M, a.wg_q, a.wg_r, &r0, &r1);
     // matrix bases as scalar integers + distances (see k_gemv_q8s)
     const uint64_t q0 = (uint64_t)sgpr_ptr(a.w[0]), s0 = (uint64_t)sgpr_ptr(a.ws[0]);
     const uint64_t dq1 = MAP == MAP_SINGLE ? 0 : (uint64_t)sgpr_ptr(a.w[1]) - q0, ds1 = MAP == MAP_SINGLE ? 0 : (uint64_t)sgpr_ptr(a.ws[1]) - s0;
@@ -270,7 +267,7 @@ __global__ __launch_bounds__(TH) void k_gemv_q8_rows(const GemvRowsArgs a) {
                     sb = bs + (uint64_t)row * srow;
                 }
             } else
-            if (row < r1) {   // scalar condition
+            if (row < r1) {   // scalar condition: s_cselect on the two addresses, no exec masking
                 uint32_t m = 0, r = row;
                 if (MAP == MAP_PAIR) { m = row & 1u; r = row >> 1; }
                 qb = q0 + (m >= 1u ? dq1 : 0) + (uint64_t)r * K;

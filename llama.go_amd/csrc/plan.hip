@@ -96,7 +96,9 @@ static int launch_gemv(lh_ctx* ctx, const GemvArgs& a, const char* name, uint64_
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    LH_LAUNCH((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    GemvArgs b = a;
+    b.wg_q = (a.M / 2) / (uint32_t)ctx->ds->num_cu; b.wg_r = (a.M / 2) % (uint32_t)ctx->ds->num_cu;   // wg_row_block
+    LH_LAUNCH((k_gemv_sa<KI, U, THR, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, b);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -108,7 +110,9 @@ static int launch_gemv_q8(lh_ctx* ctx, const GemvArgs& a, const char* name, uint
     if (rc) return rc;
     if (skip_launch(name)) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    LH_LAUNCH((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP, THR>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    GemvArgs b = a;
+    b.wg_q = (a.M / 2) / (uint32_t)ctx->ds->num_cu; b.wg_r = (a.M / 2) % (uint32_t)ctx->ds->num_cu;   // wg_row_block
+    LH_LAUNCH((k_gemv_q8s<KI, U, TPR, PRO, EPI, MAP, THR>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, b);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -204,7 +208,9 @@ static int launch_gemv_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* name
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    LH_LAUNCH((k_gemv_rows<KI, U, THR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, a);
+    GemvRowsArgs b = a;
+    b.wg_q = (a.M / 2) / (uint32_t)ctx->ds->num_cu; b.wg_r = (a.M / 2) % (uint32_t)ctx->ds->num_cu;   // wg_row_block
+    LH_LAUNCH((k_gemv_rows<KI, U, THR, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(THR), FAT_LDS, ctx->stream, b);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -255,7 +261,9 @@ static int launch_gemv_q8_rows(lh_ctx* ctx, const GemvRowsArgs& a, const char* n
     if (rc) return rc;
     if (g_prepare_only) return 0;
     ProfScope ps(ctx->stream, name, bytes);
-    LH_LAUNCH((k_gemv_q8_rows<KI, U, 256, 256, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(256), FAT_LDS, ctx->stream, a);
+    GemvRowsArgs b = a;
+    b.wg_q = (a.M / 2) / (uint32_t)ctx->ds->num_cu; b.wg_r = (a.M / 2) % (uint32_t)ctx->ds->num_cu;   // wg_row_block
+    LH_LAUNCH((k_gemv_q8_rows<KI, U, 256, 256, NC, PRO, EPI, MAP>), dim3(ctx->ds->num_cu), dim3(256), FAT_LDS, ctx->stream, b);
     LH_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -13,6 +13,7 @@ using namespace lh;
 
 static char* pool; static const size_t POOL = (size_t)3 << 30;
 static hipStream_t st; static hipEvent_t e0, e1; static int nCU;
+static bool g_hostpart = false;   // the row blocks of the workgroups from the host's quotient / remainder (wg_row_block) instead of the kernels' own divisions
 
 int main() {
     CK(hipSetDevice(0)); hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); nCU = p.multiProcessorCount;
@@ -39,6 +40,7 @@ int main() {
         auto launch = [&](int i) {
             GemvArgs b = a; const char* bs = pool + (size_t)(i % nmat) * slot;
             for (uint32_t m = 0; m < mats; ++m) { b.w[m] = (const float*)(bs + m * QB); b.ws[m] = (const float*)(bs + mats * QB + m * SB); }
+            if (g_hostpart) { b.wg_q = (b.M / 2) / (uint32_t)nCU; b.wg_r = (b.M / 2) % (uint32_t)nCU; }
             hipLaunchKernelGGL(kern, dim3(nCU), dim3(256), 96 * 1024, st, b); };
         double best = 1e30;
         for (int rep = 0; rep < 3; ++rep) {
@@ -51,12 +53,17 @@ int main() {
         }
         printf("  %-66s %8.2f us  %7.1f GB/s\n", label, best, B / best / 1e3); CK(hipGetLastError());
     };
+    for (int pass = 0; pass < 2; ++pass) {
+    g_hostpart = pass == 1;
+    printf("===== row blocks: %s\n", g_hostpart ? "host quotient / remainder (wg_row_block, as shipped)" : "two 64-bit divisions in the kernel (until round 6)");
     printf("[w1|w3 2 x 11008 x 4096 block-int8: k_gemv_q8s<1, 4, 256, ., ., MAP_PAIR, 256>]\n");
     { GemvArgs a = base(2 * F, d);
       runq("plain / store (bare stream)", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_STORE, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / store", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_STORE, MAP_PAIR, 256>, a, 2, F, d);
       runq("plain / silu*mul", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / silu*mul (shipped)", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
+      runq("rmsnorm / store as ONE matrix of 22016 rows (MAP_SINGLE)", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE, 256>, base(2 * F, d), 1, 2 * F, d);
+      runq("plain / store as ONE matrix of 22016 rows (MAP_SINGLE)", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE, 256>, base(2 * F, d), 1, 2 * F, d);
       runq("rmsnorm / silu*mul, U = 2", k_gemv_q8s<1, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / silu*mul, U = 6", k_gemv_q8s<1, 6, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / silu*mul, U = 8", k_gemv_q8s<1, 8, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d); }
@@ -85,6 +92,7 @@ int main() {
           auto launch = [&](int i) {
               GemvArgs b = a; const char* bs = pool + (size_t)(i % nmat) * slot;
               for (uint32_t m = 0; m < mats; ++m) b.w[m] = (const float*)(bs + m * MB);
+              if (g_hostpart) { b.wg_q = (b.M / 2) / (uint32_t)nCU; b.wg_r = (b.M / 2) % (uint32_t)nCU; }
               hipLaunchKernelGGL(kern, dim3(nCU), dim3(256), 96 * 1024, st, b); };
           double best = 1e30;
           for (int rep = 0; rep < 3; ++rep) {
@@ -101,7 +109,10 @@ int main() {
       runf("rmsnorm / store, MAP_BLOCK", k_gemv_sa<4, 2, 256, PRO_RMSNORM, EPI_STORE, MAP_BLOCK>, base(3 * d, d), 3, d, d);
       runf("rmsnorm / store as ONE matrix of 12288 rows (MAP_SINGLE)", k_gemv_sa<4, 2, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE>, base(3 * d, d), 1, 3 * d, d);
       runf("plain / store, MAP_BLOCK", k_gemv_sa<4, 2, 256, PRO_PLAIN, EPI_STORE, MAP_BLOCK>, base(3 * d, d), 3, d, d);
-      runf("plain / store, MAP_SINGLE", k_gemv_sa<4, 2, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, base(3 * d, d), 1, 3 * d, d); }
+      runf("plain / store, MAP_SINGLE", k_gemv_sa<4, 2, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE>, base(3 * d, d), 1, 3 * d, d);
+      runf("fp32 wo 4096 x 4096 plain / + residual (shipped)", k_gemv_sa<4, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE>, base(d, d), 1, d, d);
+      runf("fp32 w1|w3 rmsnorm / silu*mul (shipped)", k_gemv_sa<4, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR>, base(2 * F, d), 2, F, d); }
+    }
     printf("done\n");
     return 0;
 }
