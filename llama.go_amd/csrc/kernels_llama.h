@@ -364,8 +364,12 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
     float* scratch = pr + Tp;         // [ATT_TH] PV partials / reduction scratch
     const uint32_t d = a.d, hd = a.hd;
     const float* q = a.q + (size_t)j * d + h * hd;
-    const float* Kc = (a.rows ? a.rows[j].kc + a.kv_off : a.k_cache) + h * hd;
-    const float* Vc = (a.rows ? a.rows[j].vc + a.kv_off : a.v_cache) + h * hd;
+    // (the cache pointers come out of a select between a kernel argument and a pointer read from the row table: say that they are GLOBAL memory, or every
+    // K / V load is a flat_load - counted on the LDS counter too, so each wait for cache rows also drained the LDS queue; round 6, ISA of this kernel)
+    typedef const float __attribute__((address_space(1))) gfl;
+    typedef const f4 __attribute__((address_space(1))) gf4;
+    gfl* Kc = (gfl*)(uintptr_t)((a.rows ? a.rows[j].kc + a.kv_off : a.k_cache) + h * hd);
+    gfl* Vc = (gfl*)(uintptr_t)((a.rows ? a.rows[j].vc + a.kv_off : a.v_cache) + h * hd);
     // The cache rows of one head are 512 B segments strided by embd: every loop below keeps several INDEPENDENT row
     // loads in flight per lane (a dependent one-row-per-iteration loop costs a full L2 latency per key: 0.27 us/key measured).
     const uint32_t phases = ATT_TH / hd;  // hd = 128 -> 8 key phases in the PV step
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const uint32_t t = t0 + u * NG;
-                kv[u] = *(const f4*)(Kc + (size_t)(t < T ? t : 0) * d + gl * 4);
+                kv[u] = *(gf4*)(Kc + (size_t)(t < T ? t : 0) * d + gl * 4);
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
         for (uint32_t t = g; t < T; t += NG) {
             float s = 0.f;
             for (uint32_t cc = gl * 4; cc < hd; cc += 128) {
-                const f4 kv = *(const f4*)(Kc + (size_t)t * d + cc);
+                const f4 kv = *(gf4*)(Kc + (size_t)t * d + cc);
                 const f4 qv = *(const f4*)(q + cc);
                 s = fmaf(kv.x, qv.x, s); s = fmaf(kv.y, qv.y, s); s = fmaf(kv.z, qv.z, s); s = fmaf(kv.w, qv.w, s);
             }
@@ -508,8 +512,10 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
     const uint32_t Tl = (T - c0 < (uint32_t)ATT_TC) ? T - c0 : (uint32_t)ATT_TC;  // keys of this chunk
     const uint32_t d = a.d, hd = a.hd;
     const float* q = a.q + (size_t)j * d + h * hd;
-    const float* Kc = (a.rows ? a.rows[j].kc + a.kv_off : a.k_cache) + (size_t)c0 * d + h * hd;
-    const float* Vc = (a.rows ? a.rows[j].vc + a.kv_off : a.v_cache) + (size_t)c0 * d + h * hd;
+    typedef const float __attribute__((address_space(1))) gfl;   // (global, not flat: see k_attention)
+    typedef const f4 __attribute__((address_space(1))) gf4;
+    gfl* Kc = (gfl*)(uintptr_t)((a.rows ? a.rows[j].kc + a.kv_off : a.k_cache) + (size_t)c0 * d + h * hd);
+    gfl* Vc = (gfl*)(uintptr_t)((a.rows ? a.rows[j].vc + a.kv_off : a.v_cache) + (size_t)c0 * d + h * hd);
     const uint32_t phases = ATT_TH / hd, c = tid % hd, ph = tid / hd;
     constexpr int VP = ATT_TC / 8;  // hd = 128: 8 phases x 16 keys = the whole chunk in flight
     float vpre[VP];
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const uint32_t t = g + u * NG;
-            kv[u] = *(const f4*)(Kc + (size_t)(t < Tl ? t : 0) * d + gl * 4);
+            kv[u] = *(gf4*)(Kc + (size_t)(t < Tl ? t : 0) * d + gl * 4);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
