@@ -61,10 +61,14 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     v = row16_sum(v);
     return v + __shfl_xor(v, 16, 64);
 }
+// Maximum over the 64 lanes, uniform in every lane: four DPP steps inside the rows of 16 + four lane reads (the butterfly of six ds_bpermute shuffles it
+// replaces, round 6, stood on the decode attention's critical path - ~0.2 us of a 2 us kernel body; a maximum does not depend on the order it is taken in).
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)));  // row_half_mirror
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)));  // row_mirror
+    return fmaxf(fmaxf(rdlane(v, 0), rdlane(v, 16)), fmaxf(rdlane(v, 32), rdlane(v, 48)));
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll

@@ -82,6 +82,41 @@ int main() {
     printf("[lm_head 32000 x 4096 block-int8]\n");
     { runq("rmsnorm / store <1, 4, 256> shipped", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE, 256>, base(V, d), 1, V, d);
       runq("plain / store <1, 4, 256>", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE, 256>, base(V, d), 1, V, d); }
+    // the four launches of a layer in ROTATION (as the decode step issues them) against the sum of the four alone: does a kernel pay for finding its code
+    // cold (five different kernels alternate in the model, each of them a few KB of instructions) or its operands in another XCD's L2?
+    printf("[block-int8 layer rotation wq|wk|wv -> wo -> w1|w3 -> w2, per ROUND of four launches]\n");
+    { GemvArgs aq = base(3 * d, d), ao = base(d, d), a1 = base(2 * F, d), a2 = base(d, F);
+      const size_t QBq = (size_t)d * d, QB1 = (size_t)F * d;
+      const size_t Bq = 3 * (QBq + QBq / 8), Bo = QBq + QBq / 8, B1 = 2 * (QB1 + QB1 / 8), B2 = QB1 + QB1 / 8, Ball = Bq + Bo + B1 + B2;
+      const size_t slot = (Ball + (1 << 20)) & ~(size_t)4095, nmat = POOL / slot;
+      auto kq = k_gemv_q8s<1, 6, 256, PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK, 256>; auto ko = k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>;
+      auto k1 = k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>; auto k2 = k_gemv_q8s<3, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>;
+      for (auto kp : {(const void*)kq, (const void*)ko, (const void*)k1, (const void*)k2}) CK(hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      auto part = [&](GemvArgs& b) { if (g_hostpart) { b.wg_q = (b.M / 2) / (uint32_t)nCU; b.wg_r = (b.M / 2) % (uint32_t)nCU; } };
+      auto round = [&](int i, int which) {   // which: bit mask of the launches to issue
+          const char* bs = pool + (size_t)(i % nmat) * slot;
+          if (which & 1) { GemvArgs b = aq; for (int m = 0; m < 3; ++m) { b.w[m] = (const float*)(bs + m * QBq); b.ws[m] = (const float*)(bs + 3 * QBq + m * (QBq / 8)); } part(b); hipLaunchKernelGGL(kq, dim3(nCU), dim3(256), 96 * 1024, st, b); }
+          bs += Bq;
+          if (which & 2) { GemvArgs b = ao; b.w[0] = (const float*)bs; b.ws[0] = (const float*)(bs + QBq); part(b); hipLaunchKernelGGL(ko, dim3(nCU), dim3(256), 96 * 1024, st, b); }
+          bs += Bo;
+          if (which & 4) { GemvArgs b = a1; for (int m = 0; m < 2; ++m) { b.w[m] = (const float*)(bs + m * QB1); b.ws[m] = (const float*)(bs + 2 * QB1 + m * (QB1 / 8)); } part(b); hipLaunchKernelGGL(k1, dim3(nCU), dim3(256), 96 * 1024, st, b); }
+          bs += B1;
+          if (which & 8) { GemvArgs b = a2; b.w[0] = (const float*)bs; b.ws[0] = (const float*)(bs + QB1); part(b); hipLaunchKernelGGL(k2, dim3(nCU), dim3(256), 96 * 1024, st, b); }
+      };
+      auto timew = [&](const char* label, int which) {
+          double best = 1e30;
+          for (int rep = 0; rep < 3; ++rep) {
+              for (int i = 0; i < 5; ++i) round(i, which);
+              CK(hipStreamSynchronize(st)); CK(hipEventRecord(e0, st));
+              for (int i = 0; i < 100; ++i) round(i, which);
+              CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+              float ms; CK(hipEventElapsedTime(&ms, e0, e1)); const double us = ms * 1e3 / 100; best = us < best ? us : best;
+          }
+          printf("  %-66s %8.2f us\n", label, best); return best;
+      };
+      const double tq = timew("wq|wk|wv alone", 1), to = timew("wo alone", 2), t1 = timew("w1|w3 alone", 4), t2 = timew("w2 alone", 8);
+      const double tr = timew("the four in rotation", 15);
+      printf("  sum of the four alone %.2f us, in rotation %.2f us: %+.2f us per round\n", tq + to + t1 + t2, tr, tr - (tq + to + t1 + t2)); }
     // fp32 twin: does k_gemv_sa pay for MAP_BLOCK's row addressing too?  (rows are 4x longer: the scalar work per row weighs a quarter)
     printf("[fp32 wq|wk|wv 3 x 4096 x 4096: k_gemv_sa<4, 2, 256, ., ., ., 256>]\n");
     { auto runf = [&](const char* label, auto kern, GemvArgs a, uint32_t mats, uint32_t rows, uint32_t K) {
