@@ -512,8 +512,10 @@ def main():
                 result["int8_decode"]["launch_chain_ceiling_frac"] = round(qbytes / chain_s / (HBM_PEAK_GBPS * 1e9), 4)
                 result["int8_decode"]["launch_chain_ceiling"] = {"tokens_per_s": round(1.0 / chain_s, 1), "launches_per_token": n_launch,
                                                                  "fit": "t(launch) = 3.2 us + bytes / 7.0 TB/s, five dependent launches per layer + lm_head + argmax (DESIGN 3a)",
-                                                                 "note": "structural: flat since round 3 (558 -> 550 -> 541 tok/s); resident kernels, cross-kernel prefetch, two-stream overlap, "
-                                                                         "launch-free attention and the Infinity-Cache prefetch were all measured and all lost (DESIGN 3a)"}
+                                                                 "note": "structural: 558 -> 550 -> 541 tok/s over rounds 3-5 (resident kernels, cross-kernel prefetch, two-stream overlap, launch-free "
+                                                                         "attention and the Infinity-Cache prefetch all measured, all lost: DESIGN 3a); round 6 took scalar work out of "
+                                                                         "the launches' first microsecond (row addressing of wq|wk|wv, the row-block divisions, flat cache loads in the "
+                                                                         "attention): 551 -> 570 tok/s same box (profiles/r06_q8s_phase_probe.txt)"}
                 # dominant int8 kernel, HIP-event timed like the fp32 one (bytes = 36 B per 32 weights of the launch)
                 pq = profile_decode(cq, fq, P0, repeats=2)
                 b2q = {k["name"][:-4]: k for k in pq if k["name"].endswith("/b2b")}

@@ -171,6 +171,12 @@ __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
     const uint32_t rpm = a.rows_per_mat;
     const uint64_t row_bytes = (uint64_t)a.K * 4;
 
+    // (epilogue operands first: the position -> RoPE entry chain of wq|wk|wv flies while the x / gamma loads are issued - see k_gemv_q8s)
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    float resid_pre;
+    double2 cs_pre;
+    uint32_t past_pre;
+    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
     f4 xr[KI];
     f4 gr[KI];
     bool act[KI];
@@ -182,11 +188,6 @@ __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
         xr[j] = act[j] ? ((const f4*)a.x)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
         if (PRO == PRO_RMSNORM) gr[j] = act[j] ? ((const f4*)a.gamma)[tid + j * TH] : f4{0.f, 0.f, 0.f, 0.f};
     }
-    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
-    float resid_pre;
-    double2 cs_pre;
-    uint32_t past_pre;
-    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
     f4 w[U][KI];
 #pragma unroll
     for (int u = 0; u < U; ++u) {

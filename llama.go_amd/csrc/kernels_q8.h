@@ -85,6 +85,14 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
     const uint64_t qv_wg = q0 + (mlo >= 1u ? e1q : 0) + (mlo == 2u ? e2q : 0), sv_wg = s0 + (mlo >= 1u ? e1s : 0) + (mlo == 2u ? e2s : 0);
     const uint32_t bnd = (mlo + 1u) * rpm;    // rows from here on belong to the next matrix
     const uint64_t nq = (mlo == 0u ? e1q : 0) + (mlo == 1u ? e2q : 0), ns = (mlo == 0u ? e1s : 0) + (mlo == 1u ? e2s : 0);
+    // Epilogue operands first of all: for wq|wk|wv they hang on a dependent chain (position -> RoPE entry) whose scalar load then flies while the x / gamma
+    // loads are issued; behind the x loads the wave waited for it in front of its first weight row (+0.45 us on that launch), and behind the first weight
+    // rows the chain waits for the rows (loads return in order: 11.97 -> 12.72 us).  tools/q8s_phase_probe.
+    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
+    float resid_pre;
+    double2 cs_pre;
+    uint32_t past_pre;
+    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
     f4 xr[KI][4];
     bool act[KI];
     uint32_t qoff[KI], soff[KI];
@@ -106,12 +114,6 @@ __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) gr[j][k] = act[j] ? ((const f4*)a.gamma)[(tr + j * TPR) * 4 + k] : f4{0.f, 0.f, 0.f, 0.f};
     }
-    const uint32_t fin = (EPI == EPI_STORE || EPI == EPI_RESID) ? (uint32_t)tid : 2u * (uint32_t)tid;
-    float resid_pre;
-    double2 cs_pre;
-    uint32_t past_pre;
-    // (requested in FRONT of the first weight rows: behind them the position -> RoPE entry chain waits for the rows, loads return in order - measured 11.97 -> 12.72 us)
-    gemv_prefetch_fin<EPI>(a, r0, r1, fin, &resid_pre, &cs_pre, &past_pre);
 
     // slot u of this group holds row rb + G*u
     auto fetch = [&](u4 (&wd)[U][KI], float (&sd)[U][KI], uint32_t row_base) {

@@ -78,6 +78,12 @@ int main() {
       runq("rmsnorm / rope + cache as ONE matrix of 12288 rows (MAP_SINGLE)", k_gemv_q8s<1, 6, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE, 256>, base(3 * d, d), 1, 3 * d, d); }
     printf("[wo 4096 x 4096 / w2 4096 x 11008 block-int8, plain / + residual]\n");
     { runq("wo <1, 4, 256> shipped", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, d), 1, d, d);
+      runq("wo <1, 8, 256>", k_gemv_q8s<1, 8, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, d), 1, d, d);
+      runq("wo <1, 6, 256>", k_gemv_q8s<1, 6, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, d), 1, d, d);
+      runq("wo <1, 2, 256>", k_gemv_q8s<1, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, d), 1, d, d);
+      runq("w2 <3, 3, 256>", k_gemv_q8s<3, 3, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, F), 1, d, F);
+      runq("w2 <3, 4, 256>", k_gemv_q8s<3, 4, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, F), 1, d, F);
+      runq("w2 <3, 1, 256>", k_gemv_q8s<3, 1, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, F), 1, d, F);
       runq("w2 <3, 2, 256> shipped", k_gemv_q8s<3, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, F), 1, d, F); }
     printf("[lm_head 32000 x 4096 block-int8]\n");
     { runq("rmsnorm / store <1, 4, 256> shipped", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE, 256>, base(V, d), 1, V, d);
