@@ -94,6 +94,15 @@ __device__ __forceinline__ void wg_row_block(uint32_t M, uint32_t wg_q, uint32_t
     }
 }
 
+// Kernel arguments are read with scalar loads where the code first needs them; the compiler sinks those loads into the branches that use a field, so a
+// kernel that tests one argument, then follows another, then a third pays a scalar-cache miss per 64-byte line of its argument block ONE AFTER THE OTHER
+// (k_attention: rows -> sp -> the position: three dependent misses in front of its first cache row).  Naming one field of every line in an empty asm at
+// the top of the kernel makes all lines arrive behind one wait; the later loads hit the scalar cache.
+#define LH_TOUCH_ARGS(...) do { lh::touch_args_(__VA_ARGS__); } while (0)
+template <typename A, typename B> __device__ __forceinline__ void touch_args_(A a, B b) { asm volatile("" ::"s"(a), "s"(b)); }
+template <typename A, typename B, typename C> __device__ __forceinline__ void touch_args_(A a, B b, C c) { asm volatile("" ::"s"(a), "s"(b), "s"(c)); }
+template <typename A, typename B, typename C, typename D> __device__ __forceinline__ void touch_args_(A a, B b, C c, D d) { asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d)); }
+
 // A pointer pinned into a scalar register pair and made opaque to the optimiser.
 __device__ __forceinline__ const char* sgpr_ptr(const void* p) {
     uint32_t lo = (uint32_t)(uintptr_t)p, hi = (uint32_t)((uintptr_t)p >> 32);

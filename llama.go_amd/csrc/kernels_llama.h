@@ -158,6 +158,7 @@ __device__ __forceinline__ const char* gemv_row_base(const char* w0, const char*
 
 template <int KI, int U, int TH, int PRO, int EPI, int MAP>
 __global__ __launch_bounds__(TH) void k_gemv_sa(const GemvArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.x, a.hd, a.wg_r);   // the argument block's lines (0x00 / 0x40 / 0x80 / 0x94) behind one wait
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = TH / 64;
     double* sred = (double*)smem_raw;                // [NW]
@@ -353,6 +354,7 @@ __device__ __forceinline__ void attn_store_split3(const AttnArgs& a, size_t idx,
 constexpr int ATT_TH = 1024;
 
 __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
+    LH_TOUCH_ARGS(a.q, a.sp, a.rows);   // both lines of the argument block at once (rows -> sp -> position was three dependent scalar misses)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NWV = ATT_TH / 64, NG = ATT_TH / 32;  // waves, 32-lane key groups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
 constexpr int ATT_TC = 128;
 
 __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, float* __restrict__ part) {
+    LH_TOUCH_ARGS(a.q, a.sp, a.rows);
     __shared__ float sc[ATT_TC];
     __shared__ float pr[ATT_TC];
     __shared__ float scratch[ATT_TH];

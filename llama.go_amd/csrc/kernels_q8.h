@@ -52,6 +52,7 @@ __device__ __forceinline__ float dot16_q8(const u4 q, const f4 (&x)[4]) {
 // ---------------------------------------------------------------------------------------------------
 template <int KI, int U, int TPR, int PRO, int EPI, int MAP, int TH = 1024>
 __global__ __launch_bounds__(TH) void k_gemv_q8s(const GemvArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.x, a.hd, a.wg_r);   // the argument block's lines behind one wait (kernels_common.h)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = TH / TPR, NWR = TPR / 64;
     static_assert(TPR % 64 == 0, "a row group must be a whole number of waves");
