@@ -102,6 +102,9 @@ __device__ __forceinline__ void wg_row_block(uint32_t M, uint32_t wg_q, uint32_t
 template <typename A, typename B> __device__ __forceinline__ void touch_args_(A a, B b) { asm volatile("" ::"s"(a), "s"(b)); }
 template <typename A, typename B, typename C> __device__ __forceinline__ void touch_args_(A a, B b, C c) { asm volatile("" ::"s"(a), "s"(b), "s"(c)); }
 template <typename A, typename B, typename C, typename D> __device__ __forceinline__ void touch_args_(A a, B b, C c, D d) { asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d)); }
+template <typename A, typename B, typename C, typename D, typename E, typename F> __device__ __forceinline__ void touch_args_(A a, B b, C c, D d, E e, F f) {
+    asm volatile("" ::"s"(a), "s"(b), "s"(c), "s"(d), "s"(e), "s"(f));
+}
 
 // A pointer pinned into a scalar register pair and made opaque to the optimiser.
 __device__ __forceinline__ const char* sgpr_ptr(const void* p) {

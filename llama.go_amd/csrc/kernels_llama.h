@@ -582,6 +582,7 @@ constexpr int ATT_COMBINE_MAX = 256;   // chunks a combine can weigh in LDS (ctx
 // (after the evidence session: the loops over the chunks fetch EIGHT partials at a time before they use them - one thread walked its column chunk by chunk, a
 // dependent L2 round trip each: 8.6 us of a 15.8 + 8.6 us attention at T = 2000.  Same values, same order of every sum.)
 __global__ __launch_bounds__(128) void k_attention_combine(const AttnArgs a, const float* __restrict__ part, uint32_t nch) {
+    LH_TOUCH_ARGS(a.q, a.sp, a.rows, nch);
     __shared__ float wsh[ATT_COMBINE_MAX];
     const uint32_t h = blockIdx.x, hd = a.hd, j = blockIdx.y;
     const uint32_t past = a.rows ? a.rows[j].pos : (a.sp ? a.sp->past : a.past_host);

@@ -37,6 +37,7 @@ struct GemvRowsArgs {
 
 template <int KI, int U, int TH, int NC, int PRO, int EPI, int MAP>
 __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.x, a.rows, a.wg_q);   // the argument block's lines behind one wait (kernels_common.h)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = TH / 64;
     double* sred = (double*)smem_raw;                       // [NC][NW]
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(TH) void k_gemv_rows(const GemvRowsArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int KI, int U, int TPR, int TH, int NC, int PRO, int EPI, int MAP>
 __global__ __launch_bounds__(TH) void k_gemv_q8_rows(const GemvRowsArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.x, a.rows, a.wg_q);   // the argument block's lines behind one wait (kernels_common.h)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = TH / TPR, NWR = TPR / 64;
     static_assert(TPR % 64 == 0, "a row group must be a whole number of waves");

@@ -269,6 +269,7 @@ template <int MAXT, int NCT, int KC>
 #define STREAM_KERNEL_ATTR           // probe builds: e.g. -DSTREAM_KERNEL_ATTR='__attribute__((amdgpu_waves_per_eu(4,4)))' for two workgroups per CU
 #endif
 __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(const StreamArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.r[2], a.epi, a.gamma, a.ys_plane, a.ldys);   // the argument block's lines behind one wait (kernels_common.h)
     static_assert(KC == 64 || KC == 128 || KC == 256, "chunk");   // 64: four column tiles (49..64 rows) - half-length chunks make room for 6 + 4 tiles twice
     constexpr int ST_PITCH = KC + 4, RPP = 1024 / KC;
     constexpr int NW = MAXT * 16 / RPP, NX = NCT * 16 / RPP;
@@ -586,6 +587,7 @@ __host__ __device__ inline size_t stream_dma_lds_bytes(int maxt, int nct, int kc
 
 template <int MAXT, int NCT, int KC, int NIMG, bool PIPE, int CS = 1>
 __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.r[2], a.epi, a.gamma, a.ys_plane, a.ldys);   // the argument block's lines behind one wait (kernels_common.h)
     static_assert(KC == 64 || KC == 128, "chunk");
     static_assert(NIMG >= 2 && NIMG <= 5, "ring");
     constexpr int GR = KC / 4;                  // 16-byte granules per image row
@@ -764,6 +766,7 @@ struct StreamReduceArgs {
     uint64_t hs_plane;
 };
 __global__ __launch_bounds__(256) void k_stream_reduce_norm(const StreamReduceArgs a) {
+    LH_TOUCH_ARGS(a.part, a.hs);
     __shared__ double sred[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NV = 8;

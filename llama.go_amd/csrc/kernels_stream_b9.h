@@ -75,6 +75,7 @@ __host__ __device__ constexpr int stream_b9_nimg(int maxt, int nct, int cap) {
 __host__ __device__ constexpr bool stream_b9_csp(int maxt, int nct) { return (maxt & 1) && nct % 2 == 0; }
 template <int MAXT, int NCT, int NIMG, int NPROD = 9, bool CSP = stream_b9_csp(MAXT, NCT)>
 __global__ __launch_bounds__(B9S_TH) void k_stream_b9(const StreamArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.r[2], a.epi, a.gamma, a.ys_plane, a.ldys);   // the argument block's lines behind one wait (kernels_common.h)
     constexpr int KC = B9S_KC;
     static_assert(NIMG >= 2 && NIMG <= 5, "ring");
     static_assert(NCT >= 1 && NCT <= 4, "column tiles");

@@ -142,6 +142,7 @@ constexpr int stream_q8b_xr(int nct, uint32_t n) { return (nct == 1 && n <= 8) ?
 constexpr int Q8B_TH = 1024;
 template <int MAXT, int NCT, int KC, int NIMG, int XR, int TH = Q8B_TH>
 __global__ __launch_bounds__(TH) void k_stream_q8b(const StreamArgs a) {
+    LH_TOUCH_ARGS(a.w[0], a.r[2], a.epi, a.gamma, a.ys_plane, a.ldys);   // the argument block's lines behind one wait (kernels_common.h)
     static_assert(KC == 128 || KC == 256 || KC == 512, "chunk");
     static_assert(NIMG >= 2 && NIMG <= 4, "ring");   // (the product launches up to three)
     static_assert(XR == NCT * 16 || (NCT == 1 && XR == 8), "staged activation rows");
