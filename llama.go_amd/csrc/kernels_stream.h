@@ -156,7 +156,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs& a, char* smem_
     const bool pairs = a.epi == ST_EPI_SILU_MUL;
     auto tile_of = [&](uint32_t v, uint32_t* g, uint32_t* tile) {   // virtual tile -> (matrix, 16-row tile in it)
         if (pairs) { *g = v & 1u; *tile = v >> 1; }
-        else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
+        else { *g = (v >= tiles_per_mat ? 1u : 0u) + (v >= 2 * tiles_per_mat ? 1u : 0u); *tile = v - *g * tiles_per_mat; }   // (<= 3 matrices: no division)
     };
     constexpr int NC = NCT * 16, NKG = NB > 0 ? NB : (TS == 2 ? 2 : 4 / CS), NCW = NCT / CS;   // K-groups whose partial tiles meet; column tiles per MFMA wave
     const uint32_t TGX = NB > 0 ? ((uint32_t)blockDim.x >> 6) / (uint32_t)(NB > 0 ? NB * CS : 1) : 1u;   // tile groups of an equal-waves workgroup
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(2 * ST_TH) STREAM_KERNEL_ATTR void k_stream_mm2(con
     if (t1 <= t0) return;
     auto tile_of = [&](uint32_t v, uint32_t* g, uint32_t* tile) {   // virtual tile -> (matrix, 16-row tile in it)
         if (pairs) { *g = v & 1u; *tile = v >> 1; }
-        else { *g = v / tiles_per_mat; *tile = v - *g * tiles_per_mat; }
+        else { *g = (v >= tiles_per_mat ? 1u : 0u) + (v >= 2 * tiles_per_mat ? 1u : 0u); *tile = v - *g * tiles_per_mat; }   // (<= 3 matrices: no division)
     };
     const uint32_t nt = t1 - t0;
     const uint32_t nch_all = a.K / KC, ch0 = (uint32_t)(((uint64_t)ks * nch_all) / S);
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(2 * ST_TH) void k_stream_dma(const StreamArgs a) {
                 const uint32_t v = t0 + ti;
                 uint32_t g, tile;
                 if (pairs) { g = v & 1u; tile = v >> 1; }
-                else { g = v / tiles_per_mat; tile = v - g * tiles_per_mat; }
+                else { g = (v >= tiles_per_mat ? 1u : 0u) + (v >= 2 * tiles_per_mat ? 1u : 0u); tile = v - g * tiles_per_mat; }   // (<= 3 matrices: no division)
                 const float* mb = g == 0 ? a.w[0] : (g == 1 ? a.w[1] : a.w[2]);
                 base[j] = mb + (size_t)tile * 16 * a.K + kbase;
                 voff[j] = ((rr & 15u) * a.K + gs * 4u) * 4u;

@@ -13,7 +13,8 @@ using namespace lh;
 
 static char* pool; static const size_t POOL = (size_t)3 << 30;
 static hipStream_t st; static hipEvent_t e0, e1; static int nCU;
-static bool g_hostpart = false;   // the row blocks of the workgroups from the host's quotient / remainder (wg_row_block) instead of the kernels' own divisions
+static bool g_hostpart = false;
+static size_t g_skew = 0;   // bytes the planes of matrix m are shifted by (m * skew): does it matter WHERE the second matrix of a pair lies?   // the row blocks of the workgroups from the host's quotient / remainder (wg_row_block) instead of the kernels' own divisions
 
 int main() {
     CK(hipSetDevice(0)); hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); nCU = p.multiProcessorCount;
@@ -35,11 +36,11 @@ int main() {
     auto runq = [&](const char* label, auto kern, GemvArgs a, uint32_t mats, uint32_t rows, uint32_t K) {
         const size_t QB = (size_t)rows * K, SB = QB / 32 * 4, B = (size_t)mats * (QB + SB);
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        const size_t slot = (B + (1 << 20)) & ~(size_t)4095;
+        const size_t slot = (B + (8 << 20)) & ~(size_t)4095;
         const size_t nmat = POOL / slot; const int iters = 200;
         auto launch = [&](int i) {
             GemvArgs b = a; const char* bs = pool + (size_t)(i % nmat) * slot;
-            for (uint32_t m = 0; m < mats; ++m) { b.w[m] = (const float*)(bs + m * QB); b.ws[m] = (const float*)(bs + mats * QB + m * SB); }
+            for (uint32_t m = 0; m < mats; ++m) { b.w[m] = (const float*)(bs + m * (QB + g_skew)); b.ws[m] = (const float*)(bs + mats * (QB + g_skew) + m * (SB + g_skew)); }
             if (g_hostpart) { b.wg_q = (b.M / 2) / (uint32_t)nCU; b.wg_r = (b.M / 2) % (uint32_t)nCU; }
             hipLaunchKernelGGL(kern, dim3(nCU), dim3(256), 96 * 1024, st, b); };
         double best = 1e30;
@@ -64,6 +65,11 @@ int main() {
       runq("rmsnorm / silu*mul (shipped)", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / store as ONE matrix of 22016 rows (MAP_SINGLE)", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE, 256>, base(2 * F, d), 1, 2 * F, d);
       runq("plain / store as ONE matrix of 22016 rows (MAP_SINGLE)", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_STORE, MAP_SINGLE, 256>, base(2 * F, d), 1, 2 * F, d);
+      for (size_t sk : {(size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)(1 << 20) + 4096, (size_t)(2 << 20)}) {
+          g_skew = sk; char lb[96]; snprintf(lb, sizeof lb, "rmsnorm / silu*mul, w3's planes shifted by %zu bytes", sk);
+          runq(lb, k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
+      }
+      g_skew = 0;
       runq("rmsnorm / silu*mul, U = 2", k_gemv_q8s<1, 2, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / silu*mul, U = 6", k_gemv_q8s<1, 6, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d);
       runq("rmsnorm / silu*mul, U = 8", k_gemv_q8s<1, 8, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a, 2, F, d); }
