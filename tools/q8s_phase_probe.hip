@@ -14,7 +14,8 @@ using namespace lh;
 static char* pool; static const size_t POOL = (size_t)3 << 30;
 static hipStream_t st; static hipEvent_t e0, e1; static int nCU;
 static bool g_hostpart = false;
-static size_t g_skew = 0;   // bytes the planes of matrix m are shifted by (m * skew): does it matter WHERE the second matrix of a pair lies?   // the row blocks of the workgroups from the host's quotient / remainder (wg_row_block) instead of the kernels' own divisions
+static size_t g_skew = 0;
+static bool g_separate = false;   // every matrix slot its own hipMalloc (as the model's weights are) instead of a slice of one 3 GB allocation: page-table fragments / TLB reach   // bytes the planes of matrix m are shifted by (m * skew): does it matter WHERE the second matrix of a pair lies?   // the row blocks of the workgroups from the host's quotient / remainder (wg_row_block) instead of the kernels' own divisions
 
 int main() {
     CK(hipSetDevice(0)); hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0)); nCU = p.multiProcessorCount;
@@ -38,8 +39,10 @@ int main() {
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         const size_t slot = (B + (8 << 20)) & ~(size_t)4095;
         const size_t nmat = POOL / slot; const int iters = 200;
+        std::vector<char*> sep;
+        if (g_separate) { sep.resize(nmat); for (size_t k = 0; k < nmat; ++k) CK(hipMalloc((void**)&sep[k], slot)); }
         auto launch = [&](int i) {
-            GemvArgs b = a; const char* bs = pool + (size_t)(i % nmat) * slot;
+            GemvArgs b = a; const char* bs = g_separate ? sep[(size_t)i % nmat] : pool + (size_t)(i % nmat) * slot;
             for (uint32_t m = 0; m < mats; ++m) { b.w[m] = (const float*)(bs + m * (QB + g_skew)); b.ws[m] = (const float*)(bs + mats * (QB + g_skew) + m * (SB + g_skew)); }
             if (g_hostpart) { b.wg_q = (b.M / 2) / (uint32_t)nCU; b.wg_r = (b.M / 2) % (uint32_t)nCU; }
             hipLaunchKernelGGL(kern, dim3(nCU), dim3(256), 96 * 1024, st, b); };
@@ -53,7 +56,25 @@ int main() {
             best = us < best ? us : best;
         }
         printf("  %-66s %8.2f us  %7.1f GB/s\n", label, best, B / best / 1e3); CK(hipGetLastError());
+        for (char* q : sep) CK(hipFree(q));
     };
+    if (getenv("PROBE_SEPARATE")) {
+        // the same launches out of ONE 3 GB allocation and out of one hipMalloc per matrix slot (the pool is freed first: the separate slots need the room)
+        g_hostpart = true;
+        GemvArgs a1 = base(2 * F, d), aq = base(3 * d, d);
+        for (int sepa = 0; sepa < 2; ++sepa) {
+            g_separate = sepa == 1;
+            if (g_separate) { CK(hipFree(pool)); pool = nullptr; }
+            printf("===== weights: %s\n", g_separate ? "one hipMalloc per matrix slot (as the model allocates)" : "slices of one 3 GB hipMalloc");
+            runq("w1|w3 rmsnorm / silu*mul", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_SILU_MUL, MAP_PAIR, 256>, a1, 2, F, d);
+            runq("wq|wk|wv rmsnorm / rope + cache", k_gemv_q8s<1, 6, 256, PRO_RMSNORM, EPI_QKV_ROPE, MAP_BLOCK, 256>, aq, 3, d, d);
+            runq("wo plain / + residual", k_gemv_q8s<1, 4, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, d), 1, d, d);
+            runq("w2 plain / + residual", k_gemv_q8s<3, 2, 256, PRO_PLAIN, EPI_RESID, MAP_SINGLE, 256>, base(d, F), 1, d, F);
+            runq("lm_head rmsnorm / store", k_gemv_q8s<1, 4, 256, PRO_RMSNORM, EPI_STORE, MAP_SINGLE, 256>, base(V, d), 1, V, d);
+        }
+        printf("done\n");
+        return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
     g_hostpart = pass == 1;
     printf("===== row blocks: %s\n", g_hostpart ? "host quotient / remainder (wg_row_block, as shipped)" : "two 64-bit divisions in the kernel (until round 6)");
