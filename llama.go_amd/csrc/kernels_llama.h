@@ -421,17 +421,20 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
     // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum
     float inv;
     if (T <= 128) {
-        // short rows: every wave evaluates the whole row redundantly with wave-level reductions (same code -> same bits):
-        // no block barrier in this phase; waves only read sc[] and write identical values to pr[]
+        // short rows: every wave takes the row's maximum and sum with wave-level reductions (same code -> same bits)
         float m = -INFINITY;
         for (uint32_t t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
         m = wave_max(m);
-        float psum = 0.f;
-        for (uint32_t t = lane; t < T; t += 64) {
-            const float p = (float)exp((double)__fsub_rn(sc[t], m));
-            pr[t] = p;
-            psum += p;
+        // The f64 exponentials ONCE per row, not once per wave: waves 0 / 1 take keys 0..63 / 64..127 (one per lane).  Until round 6 every one of the
+        // sixteen waves evaluated them - the same instruction stream four times per SIMD, ~1000 clocks of issue contention that the workgroup's second
+        // barrier then waited out (s_memtime stamps, tools/attn_latency_probe).  The sums below keep their order: same bits.
+        if (wave < 2) {
+            const uint32_t t = (uint32_t)lane + 64u * (uint32_t)wave;
+            if (t < T) pr[t] = (float)exp((double)__fsub_rn(sc[t], m));
         }
+        __syncthreads();
+        float psum = 0.f;
+        for (uint32_t t = lane; t < T; t += 64) psum += pr[t];
         psum = wave_sum(psum);
         inv = __fdiv_rn(1.0f, psum);
     } else {
@@ -460,8 +463,7 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
         inv = __fdiv_rn(1.0f, tot);
         __syncthreads();
     }
-    // --- PV: thread (c, ph) accumulates its key phase, VP independent row loads in flight.  (T <= 128: DS operations of a
-    // wave execute in order, so pr[] written above by this wave is visible to its own reads; T > 128: barrier above.)
+    // --- PV: thread (c, ph) accumulates its key phase, VP independent row loads in flight (pr[] is complete: barrier above on both paths)
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < VP; ++i) {
@@ -548,16 +550,21 @@ __global__ __launch_bounds__(ATT_TH) void k_attention_split(const AttnArgs a, fl
         }
     }
     __syncthreads();
-    // chunk-local softmax statistics, evaluated redundantly per wave (Tl <= 128: at most 2 exps per lane)
+    // chunk-local softmax statistics: maximum and sum per wave (same code -> same bits), the f64 exponentials once per chunk (waves 0 / 1 take keys
+    // 0..63 / 64..127; sixteen waves evaluating all of them was the same instruction stream four times per SIMD - see k_attention)
     float m = -INFINITY;
     for (uint32_t t = lane; t < Tl; t += 64) m = fmaxf(m, sc[t]);
     m = wave_max(m);
-    float psum = 0.f;
-    for (uint32_t t = lane; t < Tl; t += 64) {
-        const float p = (float)exp((double)__fsub_rn(sc[t], m));
-        pr[t] = p;
-        psum += p;
+    {
+        const int wave = tid >> 6;
+        if (wave < 2) {
+            const uint32_t t = (uint32_t)lane + 64u * (uint32_t)wave;
+            if (t < Tl) pr[t] = (float)exp((double)__fsub_rn(sc[t], m));
+        }
     }
+    __syncthreads();
+    float psum = 0.f;
+    for (uint32_t t = lane; t < Tl; t += 64) psum += pr[t];
     psum = wave_sum(psum);
     float acc = 0.f;
 #pragma unroll
