@@ -420,7 +420,25 @@ __global__ __launch_bounds__(ATT_TH) void k_attention(const AttnArgs a) {
     __syncthreads();
     // --- softmax (ml.go:2432-2505): max, p = fl32(exp_f64(fl32(s - max))), fp32 sum, p *= 1/sum
     float inv;
-    if (T <= 128) {
+    if (T <= 64) {
+        // rows of at most 64 keys (one per lane): wave 0 alone takes the maximum, the exponentials, the sum and 1 / sum and leaves the latter where the scores
+        // were; the other fifteen waves wait at the barrier instead of issuing the same reductions four deep per SIMD (the contention showed as ~1000 clocks
+        // of waiting at the second barrier: s_memtime stamps, tools/attn_latency_probe).  The same operations in the same order as the path below: same bits.
+        if (wave == 0) {
+            float m = (uint32_t)lane < T ? sc[lane] : -INFINITY;
+            m = wave_max(m);
+            float psum = 0.f;
+            if ((uint32_t)lane < T) {
+                const float p = (float)exp((double)__fsub_rn(sc[lane], m));
+                pr[lane] = p;
+                psum += p;
+            }
+            psum = wave_sum(psum);
+            if (lane == 0) sc[0] = __fdiv_rn(1.0f, psum);   // (every lane of this wave has read its score above; nobody reads the scores again)
+        }
+        __syncthreads();
+        inv = sc[0];
+    } else if (T <= 128) {
         // short rows: every wave takes the row's maximum and sum with wave-level reductions (same code -> same bits)
         float m = -INFINITY;
         for (uint32_t t = lane; t < T; t += 64) m = fmaxf(m, sc[t]);
